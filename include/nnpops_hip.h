@@ -1,0 +1,152 @@
+/*
+ * nnpops_hip.h -- C ABI of libnnpops_hip.so, the MI355X (gfx950) implementation of the NNPOps
+ * per-atom hot path: ANI symmetry functions, SchNet CFConv (+ neighbour list) and
+ * getNeighborPairs.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one method of the reference's
+ * device-agnostic C++ core (the layer its torch binding calls into) or one torch dispatcher
+ * kernel, and keeps that method's argument meaning:
+ *
+ *   nnpops_ani_create / _destroy     ANISymmetryFunctions ctor/dtor        src/ani/ANISymmetryFunctions.h:60-66
+ *   nnpops_ani_set_stream            CudaANISymmetryFunctions::setStream   src/ani/CudaANISymmetryFunctions.h (setStream)
+ *   nnpops_ani_compute               computeSymmetryFunctions              src/ani/ANISymmetryFunctions.h:78
+ *   nnpops_ani_backprop              backprop                              src/ani/ANISymmetryFunctions.h:92
+ *   nnpops_cfconv_neighbors_*        CFConvNeighbors ctor / build          src/schnet/CFConv.h:37-85
+ *   nnpops_cfconv_create / compute / backprop   CFConv ctor / compute / backprop   src/schnet/CFConv.h:109-217
+ *   nnpops_neighbor_pairs_forward / _backward   neighbors::getNeighborPairs forward/backward kernels
+ *                                               src/pytorch/neighbors/getNeighborPairsCUDA.cu:31-101
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes.  No torch / C++ types cross this boundary.
+ *   - every pointer documented "device" is a HIP device pointer valid on the handle's device;
+ *     "host" pointers are read during the call only.  float = IEEE fp32, indices = int32.
+ *   - all work is enqueued on the handle's stream (default: the null stream); nothing
+ *     synchronises the host unless the function says so.  Calls are graph-capturable unless noted.
+ *   - every function returns 0 on success or a negative nnpops_status; nnpops_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - a handle is not thread-safe and not re-entrant, like the reference's objects
+ *     (backprop consumes state left by the last compute -- ANISymmetryFunctions.h:83-84).
+ */
+#ifndef NNPOPS_HIP_H
+#define NNPOPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    NNPOPS_OK = 0,
+    NNPOPS_ERR_INVALID_ARGUMENT = -1,
+    NNPOPS_ERR_HIP = -2,            /* a HIP runtime call failed; message carries hipGetErrorString */
+    NNPOPS_ERR_UNSUPPORTED = -3,    /* configuration outside what the kernels were built for */
+    NNPOPS_ERR_CAPACITY = -4,       /* a neighbour list outgrew its buffers (see *_check) */
+    NNPOPS_ERR_NO_DEVICE = -5
+} nnpops_status;
+
+const char* nnpops_last_error(void);
+/* Library / build identification: "nnpops_hip <version> gfx950". */
+const char* nnpops_version(void);
+/* Number of HIP devices visible; negative nnpops_status when the runtime is unusable. */
+int nnpops_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ANI symmetry functions (replaces ANISymmetryFunctions / CudaANISymmetryFunctions)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nnpops_ani* nnpops_ani_t;
+
+/* radial_eta_rs:            host, [num_radial][2]   = {eta, rs}                 (RadialFunction,  ANISymmetryFunctions.h:29-32)
+ * angular_eta_rs_zeta_ths:  host, [num_angular][4]  = {eta, rs, zeta, thetas}   (AngularFunction, ANISymmetryFunctions.h:34-39)
+ * atom_species:             host, [num_atoms], values in [0, num_species)
+ * periodic / torchani:      as the reference constructor flags
+ * device:                   HIP device ordinal the handle lives on
+ * The angular set must factor as {(eta,rs)} x {(zeta,thetas)} (every set the reference's torch
+ * binding can build does: SymmetryFunctions.cpp:115-120); otherwise NNPOPS_ERR_UNSUPPORTED. */
+int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float radial_cutoff, float angular_cutoff,
+                      int periodic, const int32_t* atom_species, int num_radial, const float* radial_eta_rs,
+                      int num_angular, const float* angular_eta_rs_zeta_ths, int torchani, int device);
+int nnpops_ani_destroy(nnpops_ani_t h);
+/* stream: a hipStream_t passed as void* (NULL = null stream). */
+int nnpops_ani_set_stream(nnpops_ani_t h, void* stream);
+
+/* positions: device [num_atoms][3]; box: device [3][3] rows = box vectors (ignored, may be NULL,
+ * when the handle is not periodic); radial: device [num_atoms][num_species][num_radial];
+ * angular: device [num_atoms][num_species*(num_species+1)/2][num_angular].  Outputs are fully
+ * overwritten.  Positions / box / neighbour lists are retained for backprop. */
+int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box, float* radial, float* angular);
+/* radial_deriv / angular_deriv: device, shapes as the outputs above; position_deriv: device
+ * [num_atoms][3], fully overwritten.  Must follow a compute() on the same handle. */
+int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* angular_deriv, float* position_deriv);
+/* Blocks on the handle's stream and reports whether the last compute() overflowed a neighbour
+ * buffer (NNPOPS_ERR_CAPACITY; the handle has then already grown its buffers, so simply call
+ * compute() again).  max_radial_neighbors / max_angular_neighbors (host, may be NULL) receive the
+ * largest per-atom counts seen.  Not graph-capturable. */
+int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors);
+/* Neighbour search used by compute(): 0 = automatic, 1 = all-pairs scan (the reference's
+ * algorithm, O(N^2)), 2 = cell list (O(N); periodic boxes must be at least 3 cells wide per axis). */
+int nnpops_ani_set_neighbor_algorithm(nnpops_ani_t h, int algorithm);
+
+/* ------------------------------------------------------------------------------------------
+ * SchNet continuous-filter convolution (replaces CFConvNeighbors / CFConv and their Cuda* subclasses)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nnpops_cfconv_neighbors* nnpops_cfconv_neighbors_t;
+typedef struct nnpops_cfconv* nnpops_cfconv_t;
+
+int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t* out, int num_atoms, float cutoff, int periodic, int device);
+int nnpops_cfconv_neighbors_destroy(nnpops_cfconv_neighbors_t h);
+int nnpops_cfconv_neighbors_set_stream(nnpops_cfconv_neighbors_t h, void* stream);
+/* positions: device [num_atoms][3]; box: device [3][3] or NULL.  Builds the half list
+ * {(i,j): j>i, r_ij^2 < cutoff^2} with stored distances (CFConv.h:57, CpuCFConv.cpp:104-115). */
+int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t h, const float* positions, const float* box);
+/* Blocks; num_pairs (host) receives the number of half pairs of the last build;
+ * NNPOPS_ERR_CAPACITY if that build overflowed (buffers already grown: build again). */
+int nnpops_cfconv_neighbors_check(nnpops_cfconv_neighbors_t h, int* num_pairs);
+/* Blocks; copies the half list of the last build to host arrays (test/diagnostic use):
+ * pair_atoms [2][capacity] (row 0 = i, row 1 = j), distances [capacity]. */
+int nnpops_cfconv_neighbors_export(nnpops_cfconv_neighbors_t h, int capacity, int32_t* pair_atoms, float* distances);
+
+/* activation: 0 = shifted softplus, 1 = tanh (CFConv.h:114-117).
+ * w1: host [width][num_gaussians] (the layout the reference core indexes, CpuCFConv.cpp:163);
+ * b1: host [width]; w2: host [width][width] ([out][in]); b2: host [width]. */
+int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num_gaussians, float cutoff, int periodic,
+                         float gaussian_width, int activation, const float* w1, const float* b1, const float* w2,
+                         const float* b2, int device);
+int nnpops_cfconv_destroy(nnpops_cfconv_t h);
+int nnpops_cfconv_set_stream(nnpops_cfconv_t h, void* stream);
+/* input / output: device [num_atoms][width]; output fully overwritten (CFConv.h:169-171). */
+int nnpops_cfconv_compute(nnpops_cfconv_t h, nnpops_cfconv_neighbors_t neighbors, const float* positions,
+                          const float* box, const float* input, float* output);
+/* output_deriv: device [num_atoms][width]; input_deriv: device [num_atoms][width];
+ * position_deriv: device [num_atoms][3]; both fully overwritten (CFConv.h:186-189). */
+int nnpops_cfconv_backprop(nnpops_cfconv_t h, nnpops_cfconv_neighbors_t neighbors, const float* positions,
+                           const float* box, const float* input, const float* output_deriv, float* input_deriv,
+                           float* position_deriv);
+
+/* ------------------------------------------------------------------------------------------
+ * getNeighborPairs (replaces the neighbors::getNeighborPairs CUDA kernels)
+ * ------------------------------------------------------------------------------------------ */
+/* dtype: 0 = float32, 1 = float64 (positions, box, deltas, distances share it).
+ * positions: device [num_atoms][3]; box: device [3][3] or NULL (no periodic wrap);
+ * max_num_pairs: -1 = one slot per lower-triangle pair, k -> (row, col<row) as tril_indices;
+ *                >0 = compacted list of that many slots.
+ * neighbors: device int32 [2][P]; deltas: device [P][3]; distances: device [P]; num_pairs: device int32[1]
+ * with P = num_atoms*(num_atoms-1)/2 or max_num_pairs.  All four are fully written:
+ * unused slots hold -1 / NaN / NaN (getNeighborPairsCUDA.cu:137-139); num_pairs receives the number
+ * of pairs within the cutoff, which may exceed P in compacted mode (surplus pairs are dropped).
+ * In compacted mode the list is emitted in ascending pair order (deterministic, unlike the reference).
+ * workspace: device scratch of at least nnpops_neighbor_pairs_workspace_bytes(num_atoms) bytes. */
+int64_t nnpops_neighbor_pairs_workspace_bytes(int num_atoms);
+int nnpops_neighbor_pairs_forward(int dtype, int num_atoms, const void* positions, const void* box, double cutoff,
+                                  int64_t max_num_pairs, int32_t* neighbors, void* deltas, void* distances,
+                                  int32_t* num_pairs, void* workspace, void* stream);
+/* grad_positions: device [num_atoms][3], fully overwritten
+ * (getNeighborPairsCUDA.cu:80-101: +g on neighbors[0], -g on neighbors[1], g = grad_deltas + deltas/distance*grad_distances). */
+int nnpops_neighbor_pairs_backward(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors,
+                                   const void* deltas, const void* distances, const void* grad_deltas,
+                                   const void* grad_distances, void* grad_positions, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNPOPS_HIP_H */

@@ -1,0 +1,63 @@
+"""Build libnnpops_hip.so (the C-ABI HIP library) in-tree for gfx950.
+
+    python -m nnpops_amd.build            # incremental: rebuilds only when a source is newer
+    python -m nnpops_amd.build --force
+
+hipcc cross-compiles without a GPU present; the resulting .so sits next to this file so that it
+travels with the repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnnpops_hip.so")
+ARCH = "gfx950"
+
+# translation units of the C-ABI library (the torch binding is built separately, see torch_binding.py)
+UNITS = ["capi_common.hip", "ani.hip", "cfconv.hip", "neighbor_pairs.hip"]
+
+
+def _sources():
+    return [os.path.join(CSRC, u) for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + \
+        [os.path.join(HERE, "..", "include", "nnpops_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    objdir = os.path.join(HERE, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,189 @@
+"""ctypes view of ``libnnpops_hip.so`` -- the C ABI declared in ``include/nnpops_hip.h``.
+
+This is the thinnest possible host layer: it loads the in-tree library, declares every exported
+symbol's signature, and offers small classes that hand PyTorch device tensors (used purely as
+device-memory owners) to the C ABI by raw pointer.  There is no CPU fallback: if the library is
+missing or there is no HIP device the calls raise.
+
+Reference interfaces mirrored (file:line relative to /root/reference/src):
+    AniSymmetryFunctions   -> ani/ANISymmetryFunctions.h:41-154   (computeSymmetryFunctions / backprop)
+    CFConvNeighbors, CFConv -> schnet/CFConv.h:37-217             (build / compute / backprop)
+    neighbor_pairs          -> pytorch/neighbors/getNeighborPairsCUDA.cu:103-196
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnnpops_hip.so")
+
+OK = 0
+ERR_CAPACITY = -4
+
+# name -> (restype, argtypes); the single source the symbol-export test checks against the header
+SIGNATURES = {
+    "nnpops_last_error": (C.c_char_p, []),
+    "nnpops_version": (C.c_char_p, []),
+    "nnpops_device_count": (C.c_int, []),
+    "nnpops_ani_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "nnpops_ani_destroy": (C.c_int, [C.c_void_p]),
+    "nnpops_ani_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nnpops_ani_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_ani_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_ani_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nnpops_ani_set_neighbor_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
+    "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
+    "nnpops_cfconv_neighbors_destroy": (C.c_int, [C.c_void_p]),
+    "nnpops_cfconv_neighbors_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nnpops_cfconv_neighbors_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_cfconv_neighbors_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "nnpops_cfconv_neighbors_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "nnpops_cfconv_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "nnpops_cfconv_destroy": (C.c_int, [C.c_void_p]),
+    "nnpops_cfconv_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nnpops_cfconv_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_cfconv_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "nnpops_neighbor_pairs_workspace_bytes": (C.c_int64, [C.c_int]),
+    "nnpops_neighbor_pairs_forward": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int64,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_neighbor_pairs_backward": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class NNPOpsHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[nnpops_hip {code}] {message}")
+        self.code = code
+
+
+def lib():
+    """Load libnnpops_hip.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m nnpops_amd.build` "
+                          "(hipcc --offload-arch=gfx950). nnpops_amd has no CPU fallback.")
+    handle = C.CDLL(LIB_PATH)
+    missing = [name for name in SIGNATURES if not hasattr(handle, name)]
+    if missing:                             # header/library mismatch: fail loudly
+        raise ImportError(f"{LIB_PATH} does not export {missing}; rebuild with `python -m nnpops_amd.build --force`")
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def _check(code):
+    if code != OK:
+        raise NNPOpsHipError(code, lib().nnpops_last_error().decode())
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, name, shape=None):
+    if not t.is_cuda:
+        raise ValueError(f'"{name}" must live on the HIP device (nnpops_amd has no CPU path)')
+    if t.dtype != torch.float32:
+        raise ValueError(f'"{name}" must be float32')
+    if not t.is_contiguous():
+        raise ValueError(f'"{name}" must be contiguous')
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f'"{name}" has shape {tuple(t.shape)}, expected {tuple(shape)}')
+    return t
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class AniSymmetryFunctions:
+    """One molecule / frame's ANI symmetry-function evaluator on one GPU.
+
+    Mirrors the reference object: construct once with the frozen parameters, ``compute`` then
+    ``backprop`` (which relies on state left by the last ``compute``)."""
+
+    def __init__(self, num_species, radial_cutoff, angular_cutoff, atom_species, radial_functions, angular_functions,
+                 periodic=False, torchani=True, device=0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        species = np.ascontiguousarray(atom_species, dtype=np.int32)
+        rf = np.ascontiguousarray(radial_functions, dtype=np.float32).reshape(-1, 2)
+        af = np.ascontiguousarray(angular_functions, dtype=np.float32).reshape(-1, 4)
+        self.num_atoms, self.num_species = int(species.shape[0]), int(num_species)
+        self.num_radial, self.num_angular = int(rf.shape[0]), int(af.shape[0])
+        self.periodic = bool(periodic)
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        _check(self._lib.nnpops_ani_create(C.byref(self._h), self.num_atoms, self.num_species, radial_cutoff,
+                                           angular_cutoff, int(self.periodic), species.ctypes.data_as(C.c_void_p),
+                                           self.num_radial, rf.ctypes.data_as(C.c_void_p), self.num_angular,
+                                           af.ctypes.data_as(C.c_void_p), int(bool(torchani)), self.device.index))
+        self.radial_width = self.num_species * self.num_radial
+        self.angular_width = self.num_species * (self.num_species + 1) // 2 * self.num_angular
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.nnpops_ani_destroy(h)
+            self._h = None
+
+    def set_neighbor_algorithm(self, algorithm):
+        _check(self._lib.nnpops_ani_set_neighbor_algorithm(self._h, int(algorithm)))
+
+    def compute(self, positions, box=None, radial=None, angular=None, check=True):
+        """positions [N,3] (device fp32), box [3,3] or None -> (radial [N,S*nR], angular [N,NB*nA]).
+
+        ``check=True`` blocks once on the stream to see whether a neighbour row overflowed and, if
+        so, repeats the computation with the grown buffers (the C ABI reports, never truncates)."""
+        _dev_f32(positions, "positions", (self.num_atoms, 3))
+        if self.periodic:
+            if box is None:
+                raise ValueError("periodic evaluator needs box vectors")
+            _dev_f32(box, "box", (3, 3))
+        if radial is None:
+            radial = torch.empty((self.num_atoms, self.radial_width), dtype=torch.float32, device=positions.device)
+        if angular is None:
+            angular = torch.empty((self.num_atoms, self.angular_width), dtype=torch.float32, device=positions.device)
+        _check(self._lib.nnpops_ani_set_stream(self._h, _stream_ptr(positions.device)))
+        for _ in range(8):
+            _check(self._lib.nnpops_ani_compute(self._h, _ptr(positions), _ptr(box if self.periodic else None),
+                                                _ptr(radial), _ptr(angular)))
+            if not check:
+                break
+            code = self._lib.nnpops_ani_check(self._h, None, None)
+            if code == OK:
+                break
+            if code != ERR_CAPACITY:
+                _check(code)
+        else:
+            raise NNPOpsHipError(ERR_CAPACITY, "neighbour buffers kept overflowing")
+        return radial, angular
+
+    def backprop(self, radial_grad, angular_grad, position_grad=None):
+        _dev_f32(radial_grad, "radial_grad", (self.num_atoms, self.radial_width))
+        _dev_f32(angular_grad, "angular_grad", (self.num_atoms, self.angular_width))
+        if position_grad is None:
+            position_grad = torch.empty((self.num_atoms, 3), dtype=torch.float32, device=radial_grad.device)
+        _check(self._lib.nnpops_ani_set_stream(self._h, _stream_ptr(radial_grad.device)))
+        _check(self._lib.nnpops_ani_backprop(self._h, _ptr(radial_grad), _ptr(angular_grad), _ptr(position_grad)))
+        return position_grad
+
+    def neighbor_stats(self):
+        """(max neighbours within Rcr, max neighbours within Rca) of the last compute; blocks."""
+        a, b = C.c_int(0), C.c_int(0)
+        code = self._lib.nnpops_ani_check(self._h, C.byref(a), C.byref(b))
+        if code not in (OK, ERR_CAPACITY):
+            _check(code)
+        return a.value, b.value

@@ -1,0 +1,304 @@
+// ani.hip -- C-ABI entry points for the ANI symmetry functions (see include/nnpops_hip.h).
+//
+// Host-side counterpart of the reference's ANISymmetryFunctions object
+// (src/ani/ANISymmetryFunctions.h:41-154): construction parameters are frozen in the handle,
+// compute() leaves positions / box / neighbour rows behind for backprop().
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ani_kernels.h"
+#include "host_common.h"
+
+using namespace nnpops;
+
+struct nnpops_ani {
+    AniParams hp{};                 // host copy of the parameter block
+    AniParams* d_params = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nfrp = 0, nfzp = 0;         // padded factor counts selecting the kernel instantiation
+    int algorithm = 0;              // 0 auto, 1 all-pairs, 2 cell list
+    // device state
+    int32_t* d_species = nullptr;
+    float* d_pos = nullptr;         // [N][3] positions of the last compute()
+    float* d_box = nullptr;         // [9]
+    int* d_nbr = nullptr;           // [N][cap]
+    int* d_cnt_a = nullptr;         // [N]
+    int* d_cnt_ro = nullptr;        // [N]
+    int* d_status = nullptr;        // [kStatWords]
+    int cap = 0;                    // row capacity (angular + radial-only neighbours)
+    int cap_angular = 0;            // LDS capacity of the angular kernels
+    bool computed = false;
+};
+
+namespace {
+
+int pad_pow2(int n, int lo) {
+    int p = lo;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// Split the angular set into {(eta,rs)} x {(zeta,thetas)}; fills hp.fr_*, hp.fz_*, hp.m_of.
+int factor_angular(AniParams& hp, const float* af, int nA) {
+    std::vector<std::pair<float, float>> fr, fz;
+    std::vector<int> ia(nA), iz(nA);
+    for (int m = 0; m < nA; m++) {
+        const std::pair<float, float> r{af[4 * m], af[4 * m + 1]}, z{af[4 * m + 2], af[4 * m + 3]};
+        size_t a = 0, q = 0;
+        while (a < fr.size() && fr[a] != r) a++;
+        if (a == fr.size()) fr.push_back(r);
+        while (q < fz.size() && fz[q] != z) q++;
+        if (q == fz.size()) fz.push_back(z);
+        ia[m] = (int)a;
+        iz[m] = (int)q;
+    }
+    const int nFR = (int)fr.size(), nFZ = (int)fz.size();
+    if (nFR * nFZ != nA || nFR > kMaxFactor || nFZ > kMaxFactor)
+        return fail(NNPOPS_ERR_UNSUPPORTED,
+                    "angular functions must factor as {(eta,rs)} x {(zeta,thetas)} with at most %d factors each "
+                    "(got %d x %d for %d functions)", kMaxFactor, nFR, nFZ, nA);
+    std::vector<int> seen(nA, -1);
+    for (int m = 0; m < nA; m++) {
+        const int c = ia[m] * nFZ + iz[m];
+        if (seen[c] >= 0) return fail(NNPOPS_ERR_UNSUPPORTED, "duplicate angular function %d", m);
+        seen[c] = m;
+        hp.m_of[c] = m;
+    }
+    hp.nFR = nFR;
+    hp.nFZ = nFZ;
+    for (int a = 0; a < nFR; a++) {
+        hp.fr_eta[a] = fr[a].first;
+        hp.fr_rs[a] = fr[a].second;
+        hp.fr_c[a] = -fr[a].first * kLog2e;
+    }
+    for (int z = 0; z < nFZ; z++) {
+        hp.fz_zeta[z] = fz[z].first;
+        hp.fz_cos[z] = (float)std::cos((double)fz[z].second);
+        hp.fz_sin[z] = (float)std::sin((double)fz[z].second);
+        hp.fz_scale[z] = powf(2.0f, 1.0f - fz[z].first);
+    }
+    return NNPOPS_OK;
+}
+
+int alloc_rows(nnpops_ani* h) {
+    dev_free(h->d_nbr);
+    return dev_alloc(&h->d_nbr, (size_t)h->hp.N * h->cap);
+}
+
+// ---- kernel dispatch over (PERIODIC, TORCHANI, NFRP, NFZP) ----
+template <bool PER, bool TA, int NFRP, int NFZP>
+int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float* out) {
+    const int N = h->hp.N;
+    const size_t lds = ang_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, forward);
+    if (lds > 160 * 1024)
+        return fail(NNPOPS_ERR_UNSUPPORTED, "angular kernel needs %zu bytes of LDS (> 160 KiB)", lds);
+    if (forward) {
+        auto k = ani_angular_forward<PER, TA, NFRP, NFZP>;
+        if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->d_pos, h->d_box, h->d_species, h->d_nbr,
+                           h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, out);
+    } else {
+        auto k = ani_angular_backward<PER, TA, NFRP, NFZP>;
+        if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->d_pos, h->d_box, h->d_species, h->d_nbr,
+                           h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, grad_or_null, out);
+    }
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+template <bool PER, bool TA>
+int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out) {
+    const int key = h->nfrp * 100 + h->nfzp;
+    switch (key) {
+        case 404:  return launch_angular<PER, TA, 4, 4>(h, forward, g, out);
+        case 408:  return launch_angular<PER, TA, 4, 8>(h, forward, g, out);
+        case 804:  return launch_angular<PER, TA, 8, 4>(h, forward, g, out);
+        case 808:  return launch_angular<PER, TA, 8, 8>(h, forward, g, out);
+        case 1604: return launch_angular<PER, TA, 16, 4>(h, forward, g, out);
+        case 1608: return launch_angular<PER, TA, 16, 8>(h, forward, g, out);
+        default:
+            return fail(NNPOPS_ERR_UNSUPPORTED, "no angular kernel for %d x %d factors", h->hp.nFR, h->hp.nFZ);
+    }
+}
+
+int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out) {
+    if (h->hp.periodic)
+        return h->hp.torchani ? dispatch_factors<true, true>(h, forward, g, out) : dispatch_factors<true, false>(h, forward, g, out);
+    return h->hp.torchani ? dispatch_factors<false, true>(h, forward, g, out) : dispatch_factors<false, false>(h, forward, g, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float radial_cutoff, float angular_cutoff,
+                      int periodic, const int32_t* atom_species, int num_radial, const float* radial_eta_rs,
+                      int num_angular, const float* angular_eta_rs_zeta_ths, int torchani, int device) {
+    NNPOPS_REQUIRE(out != nullptr, "out handle pointer is NULL");
+    *out = nullptr;
+    NNPOPS_REQUIRE(num_atoms > 0, "num_atoms must be positive (got %d)", num_atoms);
+    NNPOPS_REQUIRE(num_species > 0 && num_species <= kMaxSpecies, "num_species must be in [1, %d] (got %d)", kMaxSpecies, num_species);
+    NNPOPS_REQUIRE(radial_cutoff > 0 && angular_cutoff > 0, "cutoffs must be positive");
+    NNPOPS_REQUIRE(angular_cutoff <= radial_cutoff,
+                   "angular cutoff (%g) must not exceed the radial cutoff (%g): angular neighbours are drawn from the radial scan "
+                   "(reference CpuANISymmetryFunctions.cpp:129-135)", angular_cutoff, radial_cutoff);
+    NNPOPS_REQUIRE(num_radial > 0 && num_radial <= kMaxRadialFns, "num_radial must be in [1, %d]", kMaxRadialFns);
+    NNPOPS_REQUIRE(num_angular > 0 && num_angular <= kMaxAngularFns, "num_angular must be in [1, %d]", kMaxAngularFns);
+    NNPOPS_REQUIRE(atom_species && radial_eta_rs && angular_eta_rs_zeta_ths, "NULL parameter array");
+    for (int i = 0; i < num_atoms; i++)
+        NNPOPS_REQUIRE(atom_species[i] >= 0 && atom_species[i] < num_species, "atom_species[%d] = %d is outside [0, %d)", i,
+                       atom_species[i], num_species);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(NNPOPS_ERR_NO_DEVICE, "no HIP device available");
+    NNPOPS_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+
+    nnpops_ani* h = new nnpops_ani();
+    AniParams& hp = h->hp;
+    hp.N = num_atoms; hp.S = num_species; hp.nR = num_radial; hp.nA = num_angular;
+    hp.NB = num_species * (num_species + 1) / 2;
+    hp.periodic = periodic != 0; hp.torchani = torchani != 0;
+    hp.rcr = radial_cutoff; hp.rca = angular_cutoff;
+    hp.rcr2 = radial_cutoff * radial_cutoff; hp.rca2 = angular_cutoff * angular_cutoff;
+    hp.radial_scale = torchani ? 0.25f : 1.0f;
+    hp.angle_damp = torchani ? 0.95f : 1.0f;
+    for (int k = 0; k < num_radial; k++) {
+        hp.rad_eta[k] = radial_eta_rs[2 * k];
+        hp.rad_rs[k] = radial_eta_rs[2 * k + 1];
+        hp.rad_c[k] = -radial_eta_rs[2 * k] * kLog2e;
+    }
+    int rc = factor_angular(hp, angular_eta_rs_zeta_ths, num_angular);
+    if (rc != NNPOPS_OK) { delete h; return rc; }
+    h->nfrp = pad_pow2(hp.nFR, 4);
+    h->nfzp = pad_pow2(hp.nFZ, 4);
+    if (h->nfzp > 8) { delete h; return fail(NNPOPS_ERR_UNSUPPORTED, "more than 8 (zeta,thetas) factors (%d) not built", hp.nFZ); }
+    h->device = device;
+    h->cap = 128;
+    h->cap_angular = 64;
+
+    DeviceGuard guard(device);
+    if (!guard.ok) { delete h; return fail(NNPOPS_ERR_HIP, "cannot select device %d", device); }
+    auto cleanup = [&](int code) { nnpops_ani_destroy(h); return code; };
+    if ((rc = dev_alloc(&h->d_params, 1))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_species, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_pos, (size_t)num_atoms * 3))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_box, 9))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cnt_a, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cnt_ro, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_status, (size_t)kStatWords))) return cleanup(rc);
+    if ((rc = alloc_rows(h))) return cleanup(rc);
+    if (hipMemcpy(h->d_params, &hp, sizeof(AniParams), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess)
+        return cleanup(fail(NNPOPS_ERR_HIP, "parameter upload failed: %s", hipGetErrorString(hipGetLastError())));
+    *out = h;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_destroy(nnpops_ani_t h) {
+    if (!h) return NNPOPS_OK;
+    DeviceGuard guard(h->device);
+    dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_pos); dev_free(h->d_box);
+    dev_free(h->d_nbr); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
+    delete h;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_set_stream(nnpops_ani_t h, void* stream) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    h->stream = (hipStream_t)stream;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_set_neighbor_algorithm(nnpops_ani_t h, int algorithm) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    NNPOPS_REQUIRE(algorithm >= 0 && algorithm <= 2, "algorithm must be 0 (auto), 1 (all pairs) or 2 (cell list)");
+    h->algorithm = algorithm;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box, float* radial, float* angular) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    NNPOPS_REQUIRE(positions && radial && angular, "NULL device pointer");
+    NNPOPS_REQUIRE(!h->hp.periodic || box, "periodic handle needs box vectors");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
+    const int N = h->hp.N;
+    const bool per = h->hp.periodic;
+    // retain inputs for backprop (ANISymmetryFunctions.h:83-84)
+    NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_pos, positions, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, h->stream));
+    if (per) NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_box, box, sizeof(float) * 9, hipMemcpyDeviceToDevice, h->stream));
+    NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));
+
+    if (per)
+        hipLaunchKernelGGL(ani_neighbors_allpairs<true>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, h->d_status);
+    else
+        hipLaunchKernelGGL(ani_neighbors_allpairs<false>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, h->d_status);
+    NNPOPS_HIP_TRY(hipGetLastError());
+
+    const size_t lds_r = ((size_t)h->hp.S * h->hp.nR + 3 * (size_t)h->cap) * sizeof(float);
+    if (per)
+        hipLaunchKernelGGL(ani_radial_forward<true>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
+    else
+        hipLaunchKernelGGL(ani_radial_forward<false>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
+    NNPOPS_HIP_TRY(hipGetLastError());
+
+    int rc = dispatch_angular(h, true, nullptr, angular);
+    if (rc != NNPOPS_OK) return rc;
+    h->computed = true;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* angular_deriv, float* position_deriv) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    NNPOPS_REQUIRE(radial_deriv && angular_deriv && position_deriv, "NULL device pointer");
+    NNPOPS_REQUIRE(h->computed, "backprop() must follow compute() (ANISymmetryFunctions.h:83-84)");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
+    const int N = h->hp.N;
+    const size_t lds_r = ((size_t)h->hp.S * h->hp.nR + 8 * (size_t)h->cap) * sizeof(float);
+    if (lds_r > 64 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "radial backward needs %zu bytes of LDS", lds_r);
+    // radial backward owns position_deriv[i] (plain store) ...
+    if (h->hp.periodic)
+        hipLaunchKernelGGL(ani_radial_backward<true>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv,
+                           position_deriv);
+    else
+        hipLaunchKernelGGL(ani_radial_backward<false>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv,
+                           position_deriv);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    // ... and angular backward accumulates on top of it
+    return dispatch_angular(h, false, angular_deriv, position_deriv);
+}
+
+int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
+    int st[kStatWords] = {0, 0, 0, 0};
+    NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
+    if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
+    if (st[kStatOverflow]) {
+        const int old_cap = h->cap, old_ca = h->cap_angular;
+        while (h->cap < st[kStatMaxRow]) h->cap *= 2;
+        while (h->cap_angular < st[kStatMaxAngular]) h->cap_angular *= 2;
+        int rc = alloc_rows(h);
+        if (rc != NNPOPS_OK) return rc;
+        h->computed = false;
+        return fail(NNPOPS_ERR_CAPACITY,
+                    "neighbour rows overflowed (max row %d > %d or max angular %d > %d); capacities grown to %d / %d, "
+                    "call compute() again", st[kStatMaxRow], old_cap, st[kStatMaxAngular], old_ca, h->cap, h->cap_angular);
+    }
+    return NNPOPS_OK;
+}
+
+}  // extern "C"

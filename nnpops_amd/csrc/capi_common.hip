@@ -1,0 +1,24 @@
+// capi_common.hip -- library-wide pieces of the C ABI: error slot, version, device probe.
+#include "host_common.h"
+
+namespace nnpops {
+std::string& last_error_slot() {
+    static thread_local std::string slot;
+    return slot;
+}
+}  // namespace nnpops
+
+extern "C" {
+
+const char* nnpops_last_error(void) { return nnpops::last_error_slot().c_str(); }
+
+const char* nnpops_version(void) { return "nnpops_hip 0.1.0 gfx950"; }
+
+int nnpops_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return nnpops::fail(NNPOPS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+}  // extern "C"

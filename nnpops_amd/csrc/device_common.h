@@ -1,0 +1,84 @@
+// device_common.h -- helpers shared by the gfx950 kernels of libnnpops_hip.so.
+//
+// Written for CDNA4 only: 64-lane wavefronts are assumed everywhere (no warp-32 idioms, no
+// portability macros).  Single-wave workgroups are used by the per-atom kernels, so
+// __syncthreads() there is a wave-local LDS fence.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NNPOPS_WAVE 64
+
+namespace nnpops {
+
+// ---------------------------------------------------------------------------------------------
+// Periodic box, loaded once per wave from device memory (9 floats, rows = box vectors).
+// Mirrors the reference's minimum-image rule: one round() per axis, applied z, y, x, using the
+// diagonal element of each vector (reference src/ani/CpuANISymmetryFunctions.cpp:355-379).
+// ---------------------------------------------------------------------------------------------
+struct Box {
+    float ax, bx, by, cx, cy, cz;     // lower-triangular entries actually used by the wrap
+    float inv_x, inv_y, inv_z;
+    bool triclinic;
+};
+
+__device__ __forceinline__ Box load_box(const float* __restrict__ box) {
+    Box b;
+    // uniform address -> scalar loads
+    const float b00 = box[0], b01 = box[1], b02 = box[2];
+    const float b10 = box[3], b11 = box[4], b12 = box[5];
+    const float b20 = box[6], b21 = box[7], b22 = box[8];
+    b.ax = b00; b.bx = b10; b.by = b11; b.cx = b20; b.cy = b21; b.cz = b22;
+    b.inv_x = 1.0f / b00; b.inv_y = 1.0f / b11; b.inv_z = 1.0f / b22;
+    b.triclinic = (b01 != 0.f) | (b02 != 0.f) | (b10 != 0.f) | (b12 != 0.f) | (b20 != 0.f) | (b21 != 0.f);
+    return b;
+}
+
+template <bool PERIODIC>
+__device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const Box& b) {
+    if (PERIODIC) {
+        if (b.triclinic) {   // wave-uniform branch
+            const float s3 = roundf(dz * b.inv_z);
+            dx -= s3 * b.cx; dy -= s3 * b.cy; dz -= s3 * b.cz;
+            const float s2 = roundf(dy * b.inv_y);
+            dx -= s2 * b.bx; dy -= s2 * b.by;
+            const float s1 = roundf(dx * b.inv_x);
+            dx -= s1 * b.ax;
+        } else {
+            dx -= roundf(dx * b.inv_x) * b.ax;
+            dy -= roundf(dy * b.inv_y) * b.by;
+            dz -= roundf(dz * b.inv_z) * b.cz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-level primitives (64 lanes).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (NNPOPS_WAVE - 1); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int prefix_popc(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, NNPOPS_WAVE);
+    return v;
+}
+
+// Fast single-instruction transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32 /
+// v_rsq_f32, ~1 ulp).  Used only in the per-triple / per-pair inner loops; per-neighbour
+// quantities (cutoff function, distances) use the correctly-rounded library calls.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kPi = 3.14159265358979323846f;
+
+}  // namespace nnpops
