@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X NNPOps hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms 10000] [--no-cpu-baseline]
+
+Workload (BASELINE.json metric: "AEV+forces (energy+grad evals/sec) per GPU, 10k-atom box"):
+one *step* = one full ANI-2x symmetry-function evaluation of a 10 000-atom periodic box --
+neighbour search + radial/angular forward (the 1008-wide AEV of every atom) + backward
+(dE/dpositions for a fixed dense upstream gradient dE/dAEV) -- with positions, species, box and
+the upstream gradient already resident in HBM.  Everything goes through the C ABI
+(include/nnpops_hip.h) on the current HIP stream; there is no host synchronisation inside the
+timed region.  Neighbour-buffer capacity is verified before and after the timed region.
+
+Multi-GPU (--gpus N under torch.distributed.run): the path shards over independent frames, so
+every rank evaluates its own 10k-atom frame (different seed) with no data-path collective
+("scaling": "weak"); value = total evaluations of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nnpops_amd import workloads  # noqa: E402
+from nnpops_amd.capi import AniSymmetryFunctions  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(pos, species, box, rf, af, budget_s=25.0):
+    """Time the reference CPU path (oracle/_ref, the reference's own sources compiled in place) --
+    or, where that library is absent, this repository's C restatement -- on ONE host core, on a
+    bounded sample: as many fwd+bwd evaluations of the SAME 10k-atom frame as fit the budget
+    (at least one)."""
+    import oracle
+    kind = "reference" if oracle.have_ref() else "port"
+    cls = oracle.RefAni if kind == "reference" else oracle.AniOracle
+    n = pos.shape[0]
+    obj = cls(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=True)
+    rng = np.random.default_rng(123)
+    wr = wa = None
+    evals, t_total = 0, 0.0
+    while True:
+        t0 = time.perf_counter()
+        r, a = obj.forward(pos, box)
+        if wr is None:
+            wr = rng.standard_normal(r.shape).astype(np.float32)
+            wa = rng.standard_normal(a.shape).astype(np.float32)
+        obj.backward(wr, wa)
+        dt = time.perf_counter() - t0
+        evals += 1
+        t_total += dt
+        if t_total + dt > budget_s:
+            break
+    return {"value": evals / t_total, "unit": "evals/s", "cores": 1, "kind": kind,
+            "sample": f"{evals} fwd+bwd evaluation(s) of the same {n}-atom ANI-2x periodic frame, single thread "
+                      f"({t_total:.1f} s; host has {os.cpu_count()} cores, the reference CPU path is serial)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--atoms", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--neighbor-algorithm", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- synthetic frame of this rank ----
+    n = args.atoms
+    pos, species, box = workloads.random_box(n, density=0.1, seed=100 + rank, n_species=7)
+    rf, af = workloads.ani2x_functions()
+    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=True,
+                               device=local_rank)
+    if args.neighbor_algorithm:
+        sym.set_neighbor_algorithm(args.neighbor_algorithm)
+    tpos = torch.tensor(pos, device=dev)
+    tbox = torch.tensor(box, device=dev)
+    radial = torch.empty((n, sym.radial_width), device=dev)
+    angular = torch.empty((n, sym.angular_width), device=dev)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    g_rad = torch.randn(radial.shape, device=dev, generator=gen)
+    g_ang = torch.randn(angular.shape, device=dev, generator=gen)
+    grad = torch.empty((n, 3), device=dev)
+
+    def step():
+        sym.compute(tpos, tbox, radial, angular, check=False)
+        sym.backprop(g_rad, g_ang, grad)
+
+    sym.compute(tpos, tbox, radial, angular, check=True)     # calibrates neighbour capacity (blocks)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    sym.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing = sym.get_timing()
+    sym.enable_timing(False)
+    max_row, max_ang = sym.neighbor_stats()                   # raises nothing; verify no overflow happened
+    from nnpops_amd.capi import lib, OK
+    assert lib().nnpops_ani_check(sym._h, None, None) == OK, "neighbour buffers overflowed inside the timed region"
+    assert bool(torch.isfinite(grad).all())
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.steps / elapsed
+        # roofline of the dominant kernel family: the angular kernels move one 896-float row per atom
+        # (forward: written once; backward: read once) + positions/species.  SURVEY.md s8(d):
+        # forward N*16 + N*896*4 bytes, backward N*896*4 + N*12 bytes.
+        kern = {k: (1e-3 * ms / max(c, 1)) for k, (ms, c) in timing.items()}      # seconds per launch
+        dominant = max(("angular_forward", "angular_backward"), key=lambda k: kern[k])
+        nb_na = sym.angular_width
+        alg_bytes = {"angular_forward": n * 16 + n * nb_na * 4, "angular_backward": n * nb_na * 4 + n * 12}
+        achieved = alg_bytes[dominant] / kern[dominant] / 1e9
+        out = {
+            "metric": "AEV+forces evaluations/sec (ANI-2x symmetry functions, energy+gradient), 10k-atom periodic box",
+            "value": round(value, 3), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ANI-2x AEV forward+backward, {n}-atom periodic cubic box at 0.1 atoms/A^3, "
+                                   "7 species uniform, Rcr 5.1 / Rca 3.5, 16 radial + 32 angular functions (AEV width 1008); "
+                                   "one independent frame per GPU",
+                       "atoms": n, "frames_per_gpu": 1, "max_neighbors_rcr": max_row, "max_neighbors_rca": max_ang},
+            "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes[dominant]},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pos, species, box, rf, af)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

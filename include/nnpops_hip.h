@@ -87,6 +87,21 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
  * algorithm, O(N^2)), 2 = cell list (O(N); periodic boxes must be at least 3 cells wide per axis). */
 int nnpops_ani_set_neighbor_algorithm(nnpops_ani_t h, int algorithm);
 
+/* Per-kernel timing with HIP events recorded on the handle's stream around every kernel launch
+ * (off by default; not for use during graph capture).  get_timing blocks on the stream, returns for
+ * each kernel id the summed duration in milliseconds and the number of launches since the last
+ * call / enable, and resets the counters.  Arrays have NNPOPS_ANI_NUM_KERNELS entries. */
+enum {
+    NNPOPS_ANI_K_NEIGHBORS = 0,
+    NNPOPS_ANI_K_RADIAL_FWD = 1,
+    NNPOPS_ANI_K_ANGULAR_FWD = 2,
+    NNPOPS_ANI_K_RADIAL_BWD = 3,
+    NNPOPS_ANI_K_ANGULAR_BWD = 4,
+    NNPOPS_ANI_NUM_KERNELS = 5
+};
+int nnpops_ani_enable_timing(nnpops_ani_t h, int enable);
+int nnpops_ani_get_timing(nnpops_ani_t h, double* total_ms, int* launches);
+
 /* ------------------------------------------------------------------------------------------
  * SchNet continuous-filter convolution (replaces CFConvNeighbors / CFConv and their Cuda* subclasses)
  * ------------------------------------------------------------------------------------------ */

@@ -35,6 +35,8 @@ SIGNATURES = {
     "nnpops_ani_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_ani_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nnpops_ani_set_neighbor_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
+    "nnpops_ani_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
     "nnpops_cfconv_neighbors_destroy": (C.c_int, [C.c_void_p]),
     "nnpops_cfconv_neighbors_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -179,6 +181,18 @@ class AniSymmetryFunctions:
         _check(self._lib.nnpops_ani_set_stream(self._h, _stream_ptr(radial_grad.device)))
         _check(self._lib.nnpops_ani_backprop(self._h, _ptr(radial_grad), _ptr(angular_grad), _ptr(position_grad)))
         return position_grad
+
+    KERNELS = ("neighbors", "radial_forward", "angular_forward", "radial_backward", "angular_backward")
+
+    def enable_timing(self, enable=True):
+        _check(self._lib.nnpops_ani_enable_timing(self._h, int(bool(enable))))
+
+    def get_timing(self):
+        """-> {kernel: (total_ms, launches)} since the last call; blocks on the stream."""
+        ms = (C.c_double * len(self.KERNELS))()
+        cnt = (C.c_int * len(self.KERNELS))()
+        _check(self._lib.nnpops_ani_get_timing(self._h, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS)}
 
     def neighbor_stats(self):
         """(max neighbours within Rcr, max neighbours within Rca) of the last compute; blocks."""

@@ -30,9 +30,35 @@ struct nnpops_ani {
     int cap = 0;                    // row capacity (angular + radial-only neighbours)
     int cap_angular = 0;            // LDS capacity of the angular kernels
     bool computed = false;
+    // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
+    size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {0, 0, 0, 0, 0};
 };
 
 namespace {
+
+// Brackets one kernel launch with a pair of events on the handle's stream when timing is on.
+struct KernelTimer {
+    nnpops_ani* h;
+    int id;
+    KernelTimer(nnpops_ani* h_, int id_) : h(h_), id(id_) {
+        if (!h->timing) return;
+        if (h->ev_used[id] == h->ev_start[id].size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            h->ev_start[id].push_back(a);
+            h->ev_stop[id].push_back(b);
+        }
+        (void)hipEventRecord(h->ev_start[id][h->ev_used[id]], h->stream);
+    }
+    ~KernelTimer() {
+        if (!h->timing) return;
+        (void)hipEventRecord(h->ev_stop[id][h->ev_used[id]], h->stream);
+        h->ev_used[id]++;
+    }
+};
 
 int pad_pow2(int n, int lo) {
     int p = lo;
@@ -125,6 +151,7 @@ int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out) {
 }
 
 int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out) {
+    KernelTimer timer(h, forward ? NNPOPS_ANI_K_ANGULAR_FWD : NNPOPS_ANI_K_ANGULAR_BWD);
     if (h->hp.periodic)
         return h->hp.torchani ? dispatch_factors<true, true>(h, forward, g, out) : dispatch_factors<true, false>(h, forward, g, out);
     return h->hp.torchani ? dispatch_factors<false, true>(h, forward, g, out) : dispatch_factors<false, false>(h, forward, g, out);
@@ -202,6 +229,10 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     DeviceGuard guard(h->device);
     dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_pos); dev_free(h->d_box);
     dev_free(h->d_nbr); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
+    for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
+        for (hipEvent_t e : h->ev_start[k]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ev_stop[k]) (void)hipEventDestroy(e);
+    }
     delete h;
     return NNPOPS_OK;
 }
@@ -232,21 +263,27 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     if (per) NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_box, box, sizeof(float) * 9, hipMemcpyDeviceToDevice, h->stream));
     NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));
 
+    {
+    KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
     if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_pos, h->d_box,
                            h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, h->d_status);
     else
         hipLaunchKernelGGL(ani_neighbors_allpairs<false>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_pos, h->d_box,
                            h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, h->d_status);
+    }
     NNPOPS_HIP_TRY(hipGetLastError());
 
     const size_t lds_r = ((size_t)h->hp.S * h->hp.nR + 3 * (size_t)h->cap) * sizeof(float);
+    {
+    KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_FWD);
     if (per)
         hipLaunchKernelGGL(ani_radial_forward<true>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
                            h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
     else
         hipLaunchKernelGGL(ani_radial_forward<false>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
                            h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
+    }
     NNPOPS_HIP_TRY(hipGetLastError());
 
     int rc = dispatch_angular(h, true, nullptr, angular);
@@ -265,6 +302,8 @@ int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* 
     const size_t lds_r = ((size_t)h->hp.S * h->hp.nR + 8 * (size_t)h->cap) * sizeof(float);
     if (lds_r > 64 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "radial backward needs %zu bytes of LDS", lds_r);
     // radial backward owns position_deriv[i] (plain store) ...
+    {
+    KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD);
     if (h->hp.periodic)
         hipLaunchKernelGGL(ani_radial_backward<true>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
                            h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv,
@@ -273,6 +312,7 @@ int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* 
         hipLaunchKernelGGL(ani_radial_backward<false>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
                            h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv,
                            position_deriv);
+    }
     NNPOPS_HIP_TRY(hipGetLastError());
     // ... and angular backward accumulates on top of it
     return dispatch_angular(h, false, angular_deriv, position_deriv);
@@ -297,6 +337,31 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         return fail(NNPOPS_ERR_CAPACITY,
                     "neighbour rows overflowed (max row %d > %d or max angular %d > %d); capacities grown to %d / %d, "
                     "call compute() again", st[kStatMaxRow], old_cap, st[kStatMaxAngular], old_ca, h->cap, h->cap_angular);
+    }
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_enable_timing(nnpops_ani_t h, int enable) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    h->timing = enable != 0;
+    for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) h->ev_used[k] = 0;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_get_timing(nnpops_ani_t h, double* total_ms, int* launches) {
+    NNPOPS_REQUIRE(h != nullptr && total_ms && launches, "NULL argument");
+    DeviceGuard guard(h->device);
+    NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
+        double sum = 0;
+        for (size_t q = 0; q < h->ev_used[k]; q++) {
+            float ms = 0;
+            NNPOPS_HIP_TRY(hipEventElapsedTime(&ms, h->ev_start[k][q], h->ev_stop[k][q]));
+            sum += ms;
+        }
+        total_ms[k] = sum;
+        launches[k] = (int)h->ev_used[k];
+        h->ev_used[k] = 0;
     }
     return NNPOPS_OK;
 }
