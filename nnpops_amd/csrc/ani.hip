@@ -3,6 +3,7 @@
 // Host-side counterpart of the reference's ANISymmetryFunctions object
 // (src/ani/ANISymmetryFunctions.h:41-154): construction parameters are frozen in the handle,
 // compute() leaves positions / box / neighbour rows behind for backprop().
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -27,6 +28,17 @@ struct nnpops_ani {
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
     int* d_status = nullptr;        // [kStatWords]
+    // cell grid (celllist.h)
+    CellGrid* d_grid = nullptr;
+    int* d_cell_count = nullptr;    // [max_cells]
+    int* d_cell_start = nullptr;    // [max_cells+1]
+    int* d_atom_cell = nullptr;     // [N]
+    int* d_atom_rank = nullptr;     // [N]
+    int* d_unsorted_atom = nullptr; // [N] cell segments in arrival order
+    int* d_sorted_atom = nullptr;   // [N]
+    float4* d_sorted_pos = nullptr; // [N]
+    int max_cells = 0;
+    bool cells_disabled = false;    // set when a box turned out too small for the 27-cell stencil
     int cap = 0;                    // row capacity (angular + radial-only neighbours)
     int cap_angular = 0;            // LDS capacity of the angular kernels
     bool computed = false;
@@ -216,6 +228,15 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_cnt_ro, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_status, (size_t)kStatWords))) return cleanup(rc);
     if ((rc = alloc_rows(h))) return cleanup(rc);
+    h->max_cells = num_atoms + 4096;
+    if ((rc = dev_alloc(&h->d_grid, 1))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cell_count, (size_t)h->max_cells))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cell_start, (size_t)h->max_cells + 1))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_atom_cell, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_atom_rank, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_sorted_atom, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_unsorted_atom, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
     if (hipMemcpy(h->d_params, &hp, sizeof(AniParams), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess)
@@ -229,6 +250,8 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     DeviceGuard guard(h->device);
     dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_pos); dev_free(h->d_box);
     dev_free(h->d_nbr); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
+    dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
+    dev_free(h->d_atom_rank); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
         for (hipEvent_t e : h->ev_start[k]) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ev_stop[k]) (void)hipEventDestroy(e);
@@ -263,9 +286,31 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     if (per) NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_box, box, sizeof(float) * 9, hipMemcpyDeviceToDevice, h->stream));
     NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));
 
+    // neighbour search: cell grid for large systems, the reference's all-pairs scan for small ones
+    // (or when a previous compute found the box too small for the 27-cell stencil)
+    const bool use_cells = h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled);
     {
     KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
-    if (per)
+    if (use_cells) {
+        const int tb = 256;
+        hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, h->stream, N, h->d_pos, h->d_box, (int)per, h->hp.rcr,
+                           h->max_cells, h->d_grid, h->d_cell_count);
+        hipLaunchKernelGGL(assign_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid,
+                           h->d_cell_count, h->d_atom_cell, h->d_atom_rank);
+        hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, h->stream, h->d_grid, h->d_cell_count, h->d_cell_start);
+        hipLaunchKernelGGL(fill_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_grid, h->d_cell_start,
+                           h->d_atom_cell, h->d_atom_rank, h->d_unsorted_atom);
+        hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid,
+                           h->d_cell_start, h->d_atom_cell, h->d_unsorted_atom, h->d_sorted_atom, h->d_sorted_pos);
+        if (per)
+            hipLaunchKernelGGL(ani_neighbors_cells<true>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_box, h->d_grid,
+                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular,
+                               h->d_cnt_a, h->d_cnt_ro, h->d_status);
+        else
+            hipLaunchKernelGGL(ani_neighbors_cells<false>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_box, h->d_grid,
+                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular,
+                               h->d_cnt_a, h->d_cnt_ro, h->d_status);
+    } else if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_pos, h->d_box,
                            h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, h->d_status);
     else
@@ -323,10 +368,21 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
     int st[kStatWords] = {0, 0, 0, 0};
+    hipLaunchKernelGGL(ani_row_stats, dim3(std::min(64, div_up(h->hp.N, 256))), dim3(256), 0, h->stream, h->hp.N, h->d_cnt_a,
+                       h->d_cnt_ro, h->cap, h->cap_angular, h->d_status);
+    NNPOPS_HIP_TRY(hipGetLastError());
     NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
+    if (st[kStatOverflow] & 2) {
+        if (h->algorithm == 2)
+            return fail(NNPOPS_ERR_UNSUPPORTED, "cell list forced but the periodic box is fewer than 3 cells wide on some axis");
+        h->cells_disabled = true;
+        h->computed = false;
+        return fail(NNPOPS_ERR_CAPACITY, "periodic box is fewer than 3 cells wide on some axis: switched to the all-pairs "
+                                         "neighbour search, call compute() again");
+    }
     if (st[kStatOverflow]) {
         const int old_cap = h->cap, old_ca = h->cap_angular;
         while (h->cap < st[kStatMaxRow]) h->cap *= 2;

@@ -26,6 +26,7 @@
 //     rows), so it needs no atomics and also initialises position_deriv.
 #pragma once
 
+#include "celllist.h"
 #include "device_common.h"
 
 namespace nnpops {
@@ -56,6 +57,34 @@ struct AniParams {
 
 // status words written by the neighbour builder
 enum { kStatOverflow = 0, kStatMaxRow = 1, kStatMaxAngular = 2, kStatWords = 4 };
+
+// Largest row / angular count of the last neighbour build, reduced from the per-atom counts only when
+// the host asks (nnpops_ani_check).  Doing this with per-wave atomics inside the builders serialised
+// 10k waves on one L2 word (measured ~240 us), so the builders publish nothing but their counts.
+__global__ __launch_bounds__(256) void ani_row_stats(int N, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
+                                                     int cap, int cap_angular, int* __restrict__ status) {
+    __shared__ int red[2][256];
+    int mrow = 0, mang = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        mrow = max(mrow, cnt_a[i] + cnt_ro[i]);
+        mang = max(mang, cnt_a[i]);
+    }
+    red[0][threadIdx.x] = mrow;
+    red[1][threadIdx.x] = mang;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] = max(red[0][threadIdx.x], red[0][threadIdx.x + off]);
+            red[1][threadIdx.x] = max(red[1][threadIdx.x], red[1][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(&status[kStatMaxRow], red[0][0]);
+        atomicMax(&status[kStatMaxAngular], red[1][0]);
+        if (red[0][0] > cap || red[1][0] > cap_angular) atomicOr(&status[kStatOverflow], 1);
+    }
+}
 
 // =============================================================================================
 // Neighbour rows, all-pairs scan (the reference's O(N^2) search, one wave per atom).
@@ -101,9 +130,71 @@ __global__ __launch_bounds__(64) void ani_neighbors_allpairs(const AniParams* __
     if (lane == 0) {
         cnt_a[i] = na;
         cnt_ro[i] = nro;
-        if (na + nro > cap || na > cap_angular) atomicOr(&status[kStatOverflow], 1);
-        atomicMax(&status[kStatMaxRow], na + nro);
-        atomicMax(&status[kStatMaxAngular], na);
+    }
+}
+
+// =============================================================================================
+// Neighbour rows from the cell grid (celllist.h): one wave per atom walks the 3x3x3 stencil of its
+// cell; candidates are read as coalesced float4 {x,y,z,id} runs.  Same row format as above; the
+// order inside a row is the (deterministic) stencil order.
+// =============================================================================================
+template <bool PERIODIC>
+__global__ __launch_bounds__(64) void ani_neighbors_cells(const AniParams* __restrict__ P,
+                                                          const float* __restrict__ box,
+                                                          const CellGrid* __restrict__ grid,
+                                                          const int* __restrict__ cell_start,
+                                                          const int* __restrict__ atom_cell,
+                                                          const float4* __restrict__ sorted_pos, int* __restrict__ nbr,
+                                                          int cap, int cap_angular, int* __restrict__ cnt_a,
+                                                          int* __restrict__ cnt_ro, int* __restrict__ status) {
+    const int lane = lane_id();
+    const CellGrid g = *grid;
+    if (!g.ok) {                                           // box too small for the stencil: tell the host
+        if (blockIdx.x == 0 && lane == 0) atomicOr(&status[kStatOverflow], 2);
+        return;
+    }
+    const float rcr2 = P->rcr2, rca2 = P->rca2;
+    Box b{};
+    if (PERIODIC) b = load_box(box);
+    const float4 me = sorted_pos[blockIdx.x];
+    const int i = __float_as_int(me.w);
+    const int c = atom_cell[i];
+    const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+    int* row = nbr + (size_t)i * cap;
+    int na = 0, nro = 0;
+    for_each_stencil_range(g, cell_start, cx, cy, cz, [&](int begin, int end) {
+        for (int base = begin; base < end; base += 64) {
+            const int k = base + lane;
+            bool in_r = false, in_a = false;
+            int j = -1;
+            if (k < end) {
+                const float4 pj = sorted_pos[k];
+                j = __float_as_int(pj.w);
+                if (j != i) {
+                    float dx = pj.x - me.x, dy = pj.y - me.y, dz = pj.z - me.z;
+                    min_image<PERIODIC>(dx, dy, dz, b);
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    in_r = r2 < rcr2;
+                    in_a = in_r && (r2 < rca2);
+                }
+            }
+            const bool in_ro = in_r && !in_a;
+            const unsigned long long ma = __ballot(in_a), mro = __ballot(in_ro);
+            if (in_a) {
+                const int slot = na + prefix_popc(ma);
+                if (slot < cap) row[slot] = j;
+            }
+            if (in_ro) {
+                const int slot = nro + prefix_popc(mro);
+                if (slot < cap) row[cap - 1 - slot] = j;
+            }
+            na += __popcll(ma);
+            nro += __popcll(mro);
+        }
+    });
+    if (lane == 0) {
+        cnt_a[i] = na;
+        cnt_ro[i] = nro;
     }
 }
 
@@ -143,7 +234,6 @@ __global__ __launch_bounds__(64) void ani_radial_forward(const AniParams* __rest
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
     const float rcr = P->rcr;
 
-    for (int q = lane; q < width; q += 64) acc[q] = 0.f;
     for (int e = lane; e < total; e += 64) {
         const int j = e < na ? row[e] : row[cap - 1 - (e - na)];
         float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
@@ -155,22 +245,34 @@ __global__ __launch_bounds__(64) void ani_radial_forward(const AniParams* __rest
     }
     __syncthreads();
 
-    // lanes = (stream, k): KP = smallest power of two >= nR
+    // lanes = (stream, k): KP = smallest power of two >= nR.  Each lane keeps one partial sum per
+    // species in registers (select-accumulate; LDS float atomics cost ~3 cycles per lane on gfx950,
+    // see tools/ubench/lds_atomic.hip), streams are folded with xor-shuffles at the end.
     int KP = 1;
     while (KP < nR) KP <<= 1;
     const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
-    if (k < nR) {
-        const float ck = P->rad_c[k], rs = P->rad_rs[k];
+    const float ck = P->rad_c[min(k, nR - 1)], rs = P->rad_rs[min(k, nR - 1)];
+    const float scale = P->radial_scale;
+    float* out = radial + (size_t)i * width;
+    constexpr int SCHUNK = 8;
+    for (int s0 = 0; s0 < S; s0 += SCHUNK) {           // one pass per group of 8 species (one pass for ANI)
+        float part[SCHUNK];
+#pragma unroll
+        for (int s = 0; s < SCHUNK; s++) part[s] = 0.f;
         for (int e = stream; e < total; e += nstreams) {
             const float sh = nb_r[e] - rs;
             const float v = nb_fc[e] * fast_exp2(ck * sh * sh);
-            atomicAdd(&acc[nb_sp[e] * nR + k], v);
+            const int sp = nb_sp[e] - s0;
+#pragma unroll
+            for (int s = 0; s < SCHUNK; s++) part[s] += (sp == s) ? v : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < SCHUNK; s++) {
+            float v = part[s];
+            for (int off = KP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (stream == 0 && k < nR && s0 + s < S) out[(s0 + s) * nR + k] = v * scale;
         }
     }
-    __syncthreads();
-    const float scale = P->radial_scale;
-    float* out = radial + (size_t)i * width;
-    for (int q = lane; q < width; q += 64) out[q] = acc[q] * scale;
 }
 
 // =============================================================================================

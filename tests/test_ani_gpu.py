@@ -18,7 +18,7 @@ FORCE_RTOL = 1e-4      # relative to the largest force component of the system
 AEV_ATOL, AEV_RTOL = 2e-6, 2e-5
 
 
-def _run_case(n_species, rcr, rca, species, rf, af, pos, box, torchani=True, seed=0):
+def _run_case(n_species, rcr, rca, species, rf, af, pos, box, torchani=True, seed=0, algorithm=0):
     from nnpops_amd.capi import AniSymmetryFunctions
     periodic = box is not None
     oracle = AniOracle(n_species, rcr, rca, species, rf, af, periodic=periodic, torchani=torchani)
@@ -30,6 +30,7 @@ def _run_case(n_species, rcr, rca, species, rf, af, pos, box, torchani=True, see
 
     dev = torch.device("cuda:0")
     sym = AniSymmetryFunctions(n_species, rcr, rca, species, rf, af, periodic=periodic, torchani=torchani)
+    sym.set_neighbor_algorithm(algorithm)
     tpos = torch.tensor(pos, device=dev)
     tbox = torch.tensor(box, device=dev) if periodic else None
     radial, angular = sym.compute(tpos, tbox)
@@ -86,6 +87,31 @@ def test_ani2x_water_box():
 def test_ani2x_triclinic_box():
     pos, species, box = workloads.triclinic_box(500, seed=4)
     rf, af = workloads.ani2x_functions()
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
+
+
+@pytest.mark.parametrize("algorithm", [1, 2])
+@pytest.mark.parametrize("kind", ["cubic", "triclinic", "vacuum"])
+def test_neighbor_algorithms_agree_with_oracle(algorithm, kind):
+    """All-pairs scan (the reference's search) and the cell grid must give the same physics."""
+    rf, af = workloads.ani2x_functions()
+    if kind == "cubic":
+        pos, species, box = workloads.random_box(700, seed=8)
+        pos = pos + np.float32(40.0)          # atoms far outside the primary cell: wrapping must cope
+    elif kind == "triclinic":
+        pos, species, box = workloads.triclinic_box(650, seed=9)
+    else:
+        pos, species = workloads.conformer(300, seed=10)
+        box = None
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, box, algorithm=algorithm)
+
+
+def test_cell_grid_falls_back_when_box_too_small():
+    """N >= 1024 selects the cell grid, but a 14.6 A box has < 3 cells per axis at Rcr 5.1: the
+    handle must notice on the device, switch to the all-pairs search and still be right (also grows the rows)."""
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1100, density=0.35, seed=12, min_dist=0.5)
+    assert box[0, 0] < 3 * 5.1
     _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
 
 

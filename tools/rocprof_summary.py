@@ -23,7 +23,7 @@ def main():
     total = sum(r[2] for r in rows) or 1
     pmc = []
     try:
-        pmc = c.execute("select k.name, p.counter_name, count(*), avg(p.value) from pmc_events p "
+        pmc = c.execute("select k.name, p.counter_name, count(*), avg(p.counter_value) from pmc_events p "
                         "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
     except sqlite3.Error:
         pass
