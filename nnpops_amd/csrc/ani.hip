@@ -5,6 +5,7 @@
 // compute() leaves positions / box / neighbour rows behind for backprop().
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -24,7 +25,10 @@ struct nnpops_ani {
     int32_t* d_species = nullptr;
     float* d_pos = nullptr;         // [N][3] positions of the last compute()
     float* d_box = nullptr;         // [9]
-    int* d_nbr = nullptr;           // [N][cap]
+    float4* d_nbr = nullptr;        // [N][cap] records {dx, dy, dz, (species<<24)|atom}
+    float4* d_recA = nullptr;       // [N][cap_angular] sorted angular records {dx,dy,dz,r}
+    float4* d_recB = nullptr;       // [N][cap_angular]                        {fc,dfc,1/r,word}
+    int* d_tri = nullptr;           // [N][cap_angular*(cap_angular-1)/2] bucket-major triple words
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
     int* d_status = nullptr;        // [kStatWords]
@@ -41,7 +45,9 @@ struct nnpops_ani {
     bool cells_disabled = false;    // set when a box turned out too small for the 27-cell stencil
     int cap = 0;                    // row capacity (angular + radial-only neighbours)
     int cap_angular = 0;            // LDS capacity of the angular kernels
+    int tile = 32;                  // pair-matrix edge of the angular backward kernel (<= 32, sized in check())
     bool computed = false;
+    int debug = 0;                  // kernel ablation bits from $NNPOPS_ANI_DEBUG (timing experiments only)
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
     bool timing = false;
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
@@ -98,11 +104,13 @@ int factor_angular(AniParams& hp, const float* af, int nA) {
                     "angular functions must factor as {(eta,rs)} x {(zeta,thetas)} with at most %d factors each "
                     "(got %d x %d for %d functions)", kMaxFactor, nFR, nFZ, nA);
     std::vector<int> seen(nA, -1);
+    const int nfzp = pad_pow2(nFZ, 4);
     for (int m = 0; m < nA; m++) {
         const int c = ia[m] * nFZ + iz[m];
         if (seen[c] >= 0) return fail(NNPOPS_ERR_UNSUPPORTED, "duplicate angular function %d", m);
         seen[c] = m;
-        hp.m_of[c] = m;
+        hp.c_of_m[m] = ia[m] * nfzp + iz[m];
+        hp.scale_m[m] = powf(2.0f, 1.0f - af[4 * m + 2]);
     }
     hp.nFR = nFR;
     hp.nFZ = nFZ;
@@ -115,48 +123,52 @@ int factor_angular(AniParams& hp, const float* af, int nA) {
         hp.fz_zeta[z] = fz[z].first;
         hp.fz_cos[z] = (float)std::cos((double)fz[z].second);
         hp.fz_sin[z] = (float)std::sin((double)fz[z].second);
-        hp.fz_scale[z] = powf(2.0f, 1.0f - fz[z].first);
     }
     return NNPOPS_OK;
 }
 
 int alloc_rows(nnpops_ani* h) {
-    dev_free(h->d_nbr);
-    return dev_alloc(&h->d_nbr, (size_t)h->hp.N * h->cap);
+    dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri);
+    int rc;
+    if ((rc = dev_alloc(&h->d_nbr, (size_t)h->hp.N * h->cap))) return rc;
+    if ((rc = dev_alloc(&h->d_recA, (size_t)h->hp.N * h->cap_angular))) return rc;
+    if ((rc = dev_alloc(&h->d_recB, (size_t)h->hp.N * h->cap_angular))) return rc;
+    return dev_alloc(&h->d_tri, (size_t)h->hp.N * triples_capacity(h->cap_angular));
 }
 
-// ---- kernel dispatch over (PERIODIC, TORCHANI, NFRP, NFZP) ----
-template <bool PER, bool TA, int NFRP, int NFZP>
+// ---- kernel dispatch over (TORCHANI, NFRP, NFZP) ----
+template <bool TA, int NFRP, int NFZP>
 int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float* out) {
     const int N = h->hp.N;
-    const size_t lds = ang_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, forward);
+    const size_t lds = forward ? ang_fwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB)
+                               : ang_bwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, h->tile);
     if (lds > 160 * 1024)
         return fail(NNPOPS_ERR_UNSUPPORTED, "angular kernel needs %zu bytes of LDS (> 160 KiB)", lds);
     if (forward) {
-        auto k = ani_angular_forward<PER, TA, NFRP, NFZP>;
+        auto k = ani_angular_forward<TA, NFRP, NFZP>;
         if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->d_pos, h->d_box, h->d_species, h->d_nbr,
-                           h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, out);
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB,
+                           h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->debug);
     } else {
-        auto k = ani_angular_backward<PER, TA, NFRP, NFZP>;
+        auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->d_pos, h->d_box, h->d_species, h->d_nbr,
-                           h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, grad_or_null, out);
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->cap, h->cap_angular, h->tile, h->d_recA,
+                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, out, h->debug);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
 
-template <bool PER, bool TA>
+template <bool TA>
 int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out) {
     const int key = h->nfrp * 100 + h->nfzp;
     switch (key) {
-        case 404:  return launch_angular<PER, TA, 4, 4>(h, forward, g, out);
-        case 408:  return launch_angular<PER, TA, 4, 8>(h, forward, g, out);
-        case 804:  return launch_angular<PER, TA, 8, 4>(h, forward, g, out);
-        case 808:  return launch_angular<PER, TA, 8, 8>(h, forward, g, out);
-        case 1604: return launch_angular<PER, TA, 16, 4>(h, forward, g, out);
-        case 1608: return launch_angular<PER, TA, 16, 8>(h, forward, g, out);
+        case 404:  return launch_angular<TA, 4, 4>(h, forward, g, out);
+        case 408:  return launch_angular<TA, 4, 8>(h, forward, g, out);
+        case 804:  return launch_angular<TA, 8, 4>(h, forward, g, out);
+        case 808:  return launch_angular<TA, 8, 8>(h, forward, g, out);
+        case 1604: return launch_angular<TA, 16, 4>(h, forward, g, out);
+        case 1608: return launch_angular<TA, 16, 8>(h, forward, g, out);
         default:
             return fail(NNPOPS_ERR_UNSUPPORTED, "no angular kernel for %d x %d factors", h->hp.nFR, h->hp.nFZ);
     }
@@ -164,9 +176,7 @@ int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out) {
 
 int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out) {
     KernelTimer timer(h, forward ? NNPOPS_ANI_K_ANGULAR_FWD : NNPOPS_ANI_K_ANGULAR_BWD);
-    if (h->hp.periodic)
-        return h->hp.torchani ? dispatch_factors<true, true>(h, forward, g, out) : dispatch_factors<true, false>(h, forward, g, out);
-    return h->hp.torchani ? dispatch_factors<false, true>(h, forward, g, out) : dispatch_factors<false, false>(h, forward, g, out);
+    return h->hp.torchani ? dispatch_factors<true>(h, forward, g, out) : dispatch_factors<false>(h, forward, g, out);
 }
 
 }  // namespace
@@ -178,7 +188,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
                       int num_angular, const float* angular_eta_rs_zeta_ths, int torchani, int device) {
     NNPOPS_REQUIRE(out != nullptr, "out handle pointer is NULL");
     *out = nullptr;
-    NNPOPS_REQUIRE(num_atoms > 0, "num_atoms must be positive (got %d)", num_atoms);
+    NNPOPS_REQUIRE(num_atoms > 0 && num_atoms <= kIdMask, "num_atoms must be in [1, %d] (got %d)", kIdMask, num_atoms);
     NNPOPS_REQUIRE(num_species > 0 && num_species <= kMaxSpecies, "num_species must be in [1, %d] (got %d)", kMaxSpecies, num_species);
     NNPOPS_REQUIRE(radial_cutoff > 0 && angular_cutoff > 0, "cutoffs must be positive");
     NNPOPS_REQUIRE(angular_cutoff <= radial_cutoff,
@@ -208,14 +218,17 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         hp.rad_rs[k] = radial_eta_rs[2 * k + 1];
         hp.rad_c[k] = -radial_eta_rs[2 * k] * kLog2e;
     }
+    for (int a = 0, bk = 0; a < num_species; a++)
+        for (int b = a; b < num_species; b++, bk++) { hp.bkt_a[bk] = a; hp.bkt_b[bk] = b; }
     int rc = factor_angular(hp, angular_eta_rs_zeta_ths, num_angular);
     if (rc != NNPOPS_OK) { delete h; return rc; }
     h->nfrp = pad_pow2(hp.nFR, 4);
     h->nfzp = pad_pow2(hp.nFZ, 4);
     if (h->nfzp > 8) { delete h; return fail(NNPOPS_ERR_UNSUPPORTED, "more than 8 (zeta,thetas) factors (%d) not built", hp.nFZ); }
     h->device = device;
+    if (const char* e = std::getenv("NNPOPS_ANI_DEBUG")) h->debug = std::atoi(e);
     h->cap = 128;
-    h->cap_angular = 64;
+    h->cap_angular = 32;
 
     DeviceGuard guard(device);
     if (!guard.ok) { delete h; return fail(NNPOPS_ERR_HIP, "cannot select device %d", device); }
@@ -239,7 +252,9 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
     if (hipMemcpy(h->d_params, &hp, sizeof(AniParams), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess)
+        hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess ||
+        hipMemset(h->d_cnt_a, 0, sizeof(int) * num_atoms) != hipSuccess ||
+        hipMemset(h->d_cnt_ro, 0, sizeof(int) * num_atoms) != hipSuccess)
         return cleanup(fail(NNPOPS_ERR_HIP, "parameter upload failed: %s", hipGetErrorString(hipGetLastError())));
     *out = h;
     return NNPOPS_OK;
@@ -249,7 +264,7 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     if (!h) return NNPOPS_OK;
     DeviceGuard guard(h->device);
     dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_pos); dev_free(h->d_box);
-    dev_free(h->d_nbr); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
+    dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
     dev_free(h->d_atom_rank); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
@@ -288,6 +303,7 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
 
     // neighbour search: cell grid for large systems, the reference's all-pairs scan for small ones
     // (or when a previous compute found the box too small for the 27-cell stencil)
+    const size_t lds_b = builder_lds_bytes(h->cap_angular, h->hp.S, h->hp.NB);
     const bool use_cells = h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled);
     {
     KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
@@ -301,33 +317,32 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
         hipLaunchKernelGGL(fill_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_grid, h->d_cell_start,
                            h->d_atom_cell, h->d_atom_rank, h->d_unsorted_atom);
         hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid,
-                           h->d_cell_start, h->d_atom_cell, h->d_unsorted_atom, h->d_sorted_atom, h->d_sorted_pos);
+                           h->d_cell_start, h->d_atom_cell, h->d_unsorted_atom, h->d_species, h->d_sorted_atom,
+                           h->d_sorted_pos);
         if (per)
-            hipLaunchKernelGGL(ani_neighbors_cells<true>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_box, h->d_grid,
-                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular,
-                               h->d_cnt_a, h->d_cnt_ro, h->d_status);
+            hipLaunchKernelGGL(ani_neighbors_cells<true>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_box, h->d_grid,
+                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status);
         else
-            hipLaunchKernelGGL(ani_neighbors_cells<false>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_box, h->d_grid,
-                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular,
-                               h->d_cnt_a, h->d_cnt_ro, h->d_status);
+            hipLaunchKernelGGL(ani_neighbors_cells<false>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_box, h->d_grid,
+                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status);
     } else if (per)
-        hipLaunchKernelGGL(ani_neighbors_allpairs<true>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_pos, h->d_box,
-                           h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, h->d_status);
+        hipLaunchKernelGGL(ani_neighbors_allpairs<true>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri, h->d_cnt_a,
+                           h->d_cnt_ro);
     else
-        hipLaunchKernelGGL(ani_neighbors_allpairs<false>, dim3(N), dim3(64), 0, h->stream, h->d_params, h->d_pos, h->d_box,
-                           h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, h->d_status);
+        hipLaunchKernelGGL(ani_neighbors_allpairs<false>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_pos, h->d_box,
+                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri, h->d_cnt_a,
+                           h->d_cnt_ro);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
 
-    const size_t lds_r = ((size_t)h->hp.S * h->hp.nR + 3 * (size_t)h->cap) * sizeof(float);
+    const size_t lds_r = 3 * (size_t)h->cap * sizeof(float);
     {
     KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_FWD);
-    if (per)
-        hipLaunchKernelGGL(ani_radial_forward<true>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
-                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
-    else
-        hipLaunchKernelGGL(ani_radial_forward<false>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
-                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
+    hipLaunchKernelGGL(ani_radial_forward, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_nbr, h->cap,
+                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
 
@@ -349,14 +364,8 @@ int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* 
     // radial backward owns position_deriv[i] (plain store) ...
     {
     KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD);
-    if (h->hp.periodic)
-        hipLaunchKernelGGL(ani_radial_backward<true>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
-                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv,
-                           position_deriv);
-    else
-        hipLaunchKernelGGL(ani_radial_backward<false>, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_pos, h->d_box,
-                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv,
-                           position_deriv);
+    hipLaunchKernelGGL(ani_radial_backward, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_species, h->d_nbr, h->cap,
+                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, position_deriv);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     // ... and angular backward accumulates on top of it
@@ -373,6 +382,8 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     NNPOPS_HIP_TRY(hipGetLastError());
     NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+    // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
+    h->tile = std::min(32, std::max(8, (st[kStatMaxAngular] + 3) / 4 * 4));
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
     if (st[kStatOverflow] & 2) {
@@ -387,6 +398,9 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         const int old_cap = h->cap, old_ca = h->cap_angular;
         while (h->cap < st[kStatMaxRow]) h->cap *= 2;
         while (h->cap_angular < st[kStatMaxAngular]) h->cap_angular *= 2;
+        if (h->cap_angular > kMaxAngularCap)
+            return fail(NNPOPS_ERR_UNSUPPORTED, "an atom has %d neighbours inside the angular cutoff (limit %d)",
+                        st[kStatMaxAngular], kMaxAngularCap);
         int rc = alloc_rows(h);
         if (rc != NNPOPS_OK) return rc;
         h->computed = false;

@@ -6,22 +6,26 @@
 //                         (1+cos(theta-ths_m))^zeta_m exp(-eta_m((r_ij+r_ik)/2-Rs_m)^2) fc(r_ij)fc(r_ik)       (ref :153-194)
 //   and the analytic position gradients of both                                                              (ref :196-353)
 //
-// How it is laid out for CDNA4 (this is a new design, not the reference's CUDA launch shapes):
+// How it is laid out for CDNA4 (a new design, not the reference's CUDA launch shapes):
 //   * one single-wave workgroup (64 lanes) per centre atom; everything an atom needs lives in that
-//     wave's LDS slice, so the only HBM traffic is: positions/species gathers (L2 resident), the
-//     neighbour row, and ONE coalesced write (forward) or read (backward) of the atom's AEV row.
-//   * neighbour rows [N][cap]: angular neighbours (r < Rca) packed from the front, radial-only
-//     neighbours (Rca <= r < Rcr) packed from the back; both in ascending atom order.
+//     wave's LDS slice.
+//   * the NEIGHBOUR BUILD does all the geometry and all the integer bookkeeping, once per
+//     evaluation, and leaves behind streaming-friendly arrays; the forward and backward kernels
+//     that follow are pure load + arithmetic:
+//       rows  [N][cap]     16-byte records {dx, dy, dz, (species<<24)|atom} of every neighbour within
+//                          Rcr: angular ones (r < Rca) packed from the front, radial-only from the back;
+//       recA  [N][capA]    {dx, dy, dz, r}                    angular neighbours SORTED BY SPECIES
+//       recB  [N][capA]    {fc, dfc/dr, 1/r, (species<<24)|atom}
+//       tri   [N][capT]    the atom's n(n-1)/2 neighbour pairs in bucket-major order, one word
+//                          p | q<<8 | bucket<<16 (bucket = species-pair block of the output row)
 //   * the angular functions factor as R_a(rbar) x Z_z(theta) (8 x 4 for ANI-2x): a triple costs
 //     nFR exp2 + nFZ (log2+exp2) instead of nA (powf+cosf+expf).
-//   * forward, two phases per batch of 64 triples:
-//       phase 1  lane = triple:           geometry, R_a, fc*fc*Z_z  -> LDS (no cross-lane traffic)
-//       phase 2  lane = (stream, a):      acc[z] += R_a * Z_z over the stream's triples; triples are
-//                                         sorted by species pair so a stream flushes its 4 partial sums
-//                                         into the LDS output row only when the pair bucket changes.
-//   * backward: lane = triple; the atom's upstream-gradient row sits in LDS in canonical
-//     [bucket][a][z] order and is contracted with R, dR, Z, dZ in registers; forces on the two leg
-//     atoms go to per-neighbour LDS accumulators, then one global atomic per neighbour component.
+//   * no LDS float atomics anywhere: ds_add_f32 costs ~3 cycles per active lane on gfx950
+//     (tools/ubench/lds_atomic.hip); every LDS accumulation below has exactly one owner.
+//   * forward, per batch of 64 triples: phase 1 lane = triple computes the 12 factors into LDS;
+//     phase 2 lane = (stream, a) contracts them into the atom's LDS output row.
+//   * backward: lane = triple; leg-atom forces go to an LDS pair matrix (one writer per entry), row
+//     sums give per-slot forces, then one global atomic per neighbour component.
 //   * radial backward is owner-computes (each atom walks its full row, reading both gradient
 //     rows), so it needs no atomics and also initialises position_deriv.
 #pragma once
@@ -34,7 +38,9 @@ namespace nnpops {
 constexpr int kMaxRadialFns = 64;
 constexpr int kMaxFactor = 16;       // max distinct (eta,rs) or (zeta,thetas) factors of the angular set
 constexpr int kMaxAngularFns = 256;
-constexpr int kMaxSpecies = 32;
+constexpr int kMaxSpecies = 16;
+constexpr int kMaxBuckets = kMaxSpecies * (kMaxSpecies + 1) / 2;
+constexpr int kMaxAngularCap = 256;  // p and q of a triple word are 8 bits each
 
 struct AniParams {
     int N, S, nR, nA, NB, nFR, nFZ;
@@ -51,12 +57,16 @@ struct AniParams {
     float fz_zeta[kMaxFactor];
     float fz_cos[kMaxFactor];        // cos(thetas_z)
     float fz_sin[kMaxFactor];        // sin(thetas_z)
-    float fz_scale[kMaxFactor];      // 2^(1-zeta_z)                  ref :104-109
-    int m_of[kMaxAngularFns];        // canonical (a*nFZ+z) -> position m inside a species-pair block
+    float scale_m[kMaxAngularFns];   // 2^(1-zeta_m) of angular function m                       ref :104-109
+    int c_of_m[kMaxAngularFns];      // function m -> slot a*NFZP+z inside a padded canonical bucket block
+    int bkt_a[kMaxBuckets];          // bucket b -> its species pair (A <= B), upper-triangular row-major
+    int bkt_b[kMaxBuckets];          //                                                          ref :39-43
 };
 
-// status words written by the neighbour builder
+// status words reported by nnpops_ani_check
 enum { kStatOverflow = 0, kStatMaxRow = 1, kStatMaxAngular = 2, kStatWords = 4 };
+
+__host__ __device__ inline int triples_capacity(int capA) { return capA * (capA - 1) / 2; }
 
 // Largest row / angular count of the last neighbour build, reduced from the per-atom counts only when
 // the host asks (nnpops_ani_check).  Doing this with per-wave atomics inside the builders serialised
@@ -86,15 +96,190 @@ __global__ __launch_bounds__(256) void ani_row_stats(int N, const int* __restric
     }
 }
 
+// Clamp the per-atom counts so that nobody indexes outside a row even after an overflow (results of
+// an overflowed compute are garbage and reported through nnpops_ani_check).  Builders and consumers
+// use the same clamp.
+__device__ __forceinline__ void clamp_counts(int raw_a, int raw_ro, int cap, int cap_angular, int& na, int& nro) {
+    na = max(0, min(raw_a, min(cap, cap_angular)));
+    nro = max(0, min(raw_ro, cap - na));
+}
+
 // =============================================================================================
-// Neighbour rows, all-pairs scan (the reference's O(N^2) search, one wave per atom).
+// Triple enumeration helpers (used by the builders; the consumers just read the word lists).
 // =============================================================================================
+// (p, q) with p < q of the t-th pair in row-major order of the strict upper triangle of an n x n grid
+__device__ __forceinline__ void decode_pair(int t, int n, int& p, int& q) {
+    const float w = (float)(2 * n - 1);
+    int pp = (int)((w - fast_sqrt(fmaxf(w * w - 8.0f * (float)t, 0.f))) * 0.5f);
+    pp = max(0, min(pp, n - 2));
+    // offset(p) = p*(2n-p-1)/2 ; one fix-up step each way covers the rounding of the fast sqrt
+    if (((pp + 1) * (2 * n - pp - 2)) / 2 <= t) pp++;
+    if ((pp * (2 * n - pp - 1)) / 2 > t) pp--;
+    p = pp;
+    q = t - (pp * (2 * n - pp - 1)) / 2 + pp + 1;
+}
+
+// Per-atom species bookkeeping in LDS (ints), sized by the actual species / bucket counts.
+struct AtomGroups {
+    int* gs;      // [S]  first sorted slot of species s
+    int* gn;      // [S]  number of neighbours of species s
+    int* run;     // [S]  scratch for the stable sort
+    int* boff;    // [NB + 1] exclusive offsets of the species-pair buckets in bucket-major triple order
+    int* ba;      // [NB] first species of bucket b   (LDS copy of AniParams::bkt_a)
+    int* bb;      // [NB] second species of bucket b
+};
+__host__ __device__ inline size_t group_ints(int S, int NB) { return (size_t)3 * S + 3 * NB + 1; }
+
+__device__ __forceinline__ AtomGroups carve_groups(int* base, int S, int NB) {
+    AtomGroups G;
+    G.gs = base; G.gn = G.gs + S; G.run = G.gn + S; G.boff = G.run + S;
+    G.ba = G.boff + NB + 1; G.bb = G.ba + NB;
+    return G;
+}
+
+// Bucket-major triple order: bucket b = (A <= B) holds gn[A]*gn[B] pairs (A < B, row-major over
+// (ia, ib)) or gn[A](gn[A]-1)/2 pairs (A == B, strict upper triangle).  Returns the triple count.
+__device__ __forceinline__ int build_bucket_offsets(int NB, const AtomGroups& G) {
+    const int lane = lane_id();
+    int carry = 0;
+    for (int base = 0; base < NB; base += 64) {
+        const int bk = base + lane;
+        int c = 0;
+        if (bk < NB) {
+            const int A = G.ba[bk], B = G.bb[bk];
+            const int ga = G.gn[A], gb = G.gn[B];
+            c = (A == B) ? (ga * (ga - 1)) / 2 : ga * gb;
+        }
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (bk < NB) G.boff[bk] = carry + incl - c;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) G.boff[NB] = carry;
+    __syncthreads();
+    return carry;
+}
+
+// t-th triple in bucket-major order -> sorted slots (p < q) and its bucket.
+__device__ __forceinline__ void decode_triple(int NB, const AtomGroups& G, int t, int steps, int& p, int& q, int& bucket) {
+    int lo = 0, hi = NB;
+    for (int it = 0; it < steps; it++) {                  // uniform trip count = ceil(log2(NB))
+        const int mid = (lo + hi) >> 1;
+        const bool ge = G.boff[mid] <= t;
+        lo = ge ? mid : lo;
+        hi = ge ? hi : mid;
+    }
+    bucket = lo;
+    const int A = G.ba[lo], B = G.bb[lo];
+    const int local = t - G.boff[lo];
+    if (A == B) {
+        int ia, ib;
+        decode_pair(local, G.gn[A], ia, ib);
+        p = G.gs[A] + ia;
+        q = G.gs[A] + ib;
+    } else {
+        const int nb = G.gn[B];
+        const int ia = (int)(((float)local + 0.5f) * fast_rcp((float)nb));
+        p = G.gs[A] + ia;
+        q = G.gs[B] + (local - ia * nb);
+    }
+}
+
+// =============================================================================================
+// Neighbour build.
+// =============================================================================================
+// Appends the lanes flagged in_a / in_ro to the two ends of a row (ballot compaction keeps scan
+// order); angular ones are also staged in LDS for the sort that follows the scan.
+__device__ __forceinline__ void append_to_row(float4* __restrict__ row, int cap, float4* stage, int capA, bool in_a,
+                                              bool in_ro, float dx, float dy, float dz, int word, int& na, int& nro) {
+    const unsigned long long ma = __ballot(in_a), mro = __ballot(in_ro);
+    const float4 rec = make_float4(dx, dy, dz, __int_as_float(word));
+    if (in_a) {
+        const int slot = na + prefix_popc(ma);
+        if (slot < cap) row[slot] = rec;
+        if (slot < capA) stage[slot] = rec;
+    }
+    if (in_ro) {
+        const int slot = nro + prefix_popc(mro);
+        if (slot < cap) row[cap - 1 - slot] = rec;
+    }
+    na += __popcll(ma);
+    nro += __popcll(mro);
+}
+
+// After the scan: sort the staged angular neighbours by species (stable), evaluate everything that
+// depends on one neighbour only (r, cutoff function and derivative, 1/r), write the sorted records
+// and the bucket-major triple list.  Runs once per atom per evaluation; forward and backward reuse it.
+__device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P, const float4* stage, int n,
+                                                 float4* __restrict__ recA, float4* __restrict__ recB,
+                                                 int* __restrict__ tri, const AtomGroups& G) {
+    const int lane = lane_id();
+    const int S = P->S, NB = P->NB;
+    const float rca = P->rca;
+    for (int s = lane; s < S; s += 64) { G.gn[s] = 0; G.run[s] = 0; }
+    for (int bk = lane; bk < NB; bk += 64) { G.ba[bk] = P->bkt_a[bk]; G.bb[bk] = P->bkt_b[bk]; }
+    __syncthreads();
+    for (int e = lane; e < n; e += 64) atomicAdd(&G.gn[__float_as_int(stage[e].w) >> kTagShift], 1);   // int LDS atomics
+    __syncthreads();
+    if (lane == 0) {
+        int accum = 0;
+        for (int s = 0; s < S; s++) { G.gs[s] = accum; accum += G.gn[s]; }
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+        const int e = base + lane;
+        const bool valid = e < n;
+        const float4 r4 = valid ? stage[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int word = __float_as_int(r4.w);
+        const int sp = valid ? (word >> kTagShift) : -1;
+        int rank = 0;
+        for (int s = 0; s < S; s++) {
+            const unsigned long long m = __ballot(valid && sp == s);
+            if (m == 0) continue;                         // wave-uniform
+            if (sp == s) rank = G.gs[s] + G.run[s] + prefix_popc(m);
+            __syncthreads();
+            if (lane == 0) G.run[s] += __popcll(m);
+            __syncthreads();
+        }
+        if (valid) {
+            const float r = sqrtf(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);
+            float sn, cs;
+            sincospif(r / rca, &sn, &cs);                  // fc = (cos(pi r/Rc)+1)/2, ref :381-387
+            recA[rank] = make_float4(r4.x, r4.y, r4.z, r);
+            recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi / rca) * sn, 1.0f / r, r4.w);
+        }
+    }
+    const int T = build_bucket_offsets(NB, G);
+    int steps = 0;
+    while ((1 << steps) < NB) steps++;
+    for (int t = lane; t < T; t += 64) {
+        int p, q, bucket;
+        decode_triple(NB, G, t, steps, p, q, bucket);
+        tri[t] = p | (q << 8) | (bucket << 16);
+    }
+}
+
+__host__ __device__ inline size_t builder_lds_bytes(int capA, int S, int NB) {
+    return (size_t)capA * sizeof(float4) + group_ints(S, NB) * sizeof(int);
+}
+
+// All-pairs scan (the reference's O(N^2) search, one wave per atom; used for small systems and for
+// boxes too small for the cell stencil).  Row order = ascending atom id.
 template <bool PERIODIC>
 __global__ __launch_bounds__(64) void ani_neighbors_allpairs(const AniParams* __restrict__ P,
                                                              const float* __restrict__ pos,
-                                                             const float* __restrict__ box, int* __restrict__ nbr,
-                                                             int cap, int cap_angular, int* __restrict__ cnt_a,
-                                                             int* __restrict__ cnt_ro, int* __restrict__ status) {
+                                                             const float* __restrict__ box,
+                                                             const int* __restrict__ species, float4* __restrict__ nbr,
+                                                             int cap, int capA, float4* __restrict__ recA,
+                                                             float4* __restrict__ recB, int* __restrict__ tri,
+                                                             int* __restrict__ cnt_a, int* __restrict__ cnt_ro) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float4* stage = (float4*)lds_raw;
+    const AtomGroups G = carve_groups((int*)(stage + capA), P->S, P->NB);
     const int i = blockIdx.x;
     const int lane = lane_id();
     const int N = P->N;
@@ -102,152 +287,125 @@ __global__ __launch_bounds__(64) void ani_neighbors_allpairs(const AniParams* __
     Box b{};
     if (PERIODIC) b = load_box(box);
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-    int* row = nbr + (size_t)i * cap;
+    float4* row = nbr + (size_t)i * cap;
     int na = 0, nro = 0;
     for (int base = 0; base < N; base += 64) {
         const int j = base + lane;
         bool in_r = false, in_a = false;
+        int word = 0;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
         if (j < N && j != i) {
-            float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
+            word = j | (species[j] << kTagShift);
+            dx = pos[3 * j] - xi; dy = pos[3 * j + 1] - yi; dz = pos[3 * j + 2] - zi;
             min_image<PERIODIC>(dx, dy, dz, b);
             const float r2 = dx * dx + dy * dy + dz * dz;
             in_r = r2 < rcr2;
             in_a = in_r && (r2 < rca2);
         }
-        const bool in_ro = in_r && !in_a;
-        const unsigned long long ma = __ballot(in_a), mro = __ballot(in_ro);
-        if (in_a) {
-            const int slot = na + prefix_popc(ma);
-            if (slot < cap) row[slot] = j;
-        }
-        if (in_ro) {
-            const int slot = nro + prefix_popc(mro);
-            if (slot < cap) row[cap - 1 - slot] = j;
-        }
-        na += __popcll(ma);
-        nro += __popcll(mro);
+        append_to_row(row, cap, stage, capA, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
     }
-    if (lane == 0) {
-        cnt_a[i] = na;
-        cnt_ro[i] = nro;
-    }
+    if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
+    int n, nro_c;
+    clamp_counts(na, nro, cap, capA, n, nro_c);
+    __syncthreads();
+    finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
+                     tri + (size_t)i * triples_capacity(capA), G);
 }
 
-// =============================================================================================
-// Neighbour rows from the cell grid (celllist.h): one wave per atom walks the 3x3x3 stencil of its
-// cell; candidates are read as coalesced float4 {x,y,z,id} runs.  Same row format as above; the
-// order inside a row is the (deterministic) stencil order.
-// =============================================================================================
+// Cell-grid search (celllist.h): one wave per atom walks the 3x3x3 stencil of its cell; candidates
+// are read as coalesced float4 {x,y,z,(species<<24)|id} runs.  Row order = stencil order.
 template <bool PERIODIC>
 __global__ __launch_bounds__(64) void ani_neighbors_cells(const AniParams* __restrict__ P,
                                                           const float* __restrict__ box,
                                                           const CellGrid* __restrict__ grid,
                                                           const int* __restrict__ cell_start,
                                                           const int* __restrict__ atom_cell,
-                                                          const float4* __restrict__ sorted_pos, int* __restrict__ nbr,
-                                                          int cap, int cap_angular, int* __restrict__ cnt_a,
-                                                          int* __restrict__ cnt_ro, int* __restrict__ status) {
+                                                          const float4* __restrict__ sorted_pos, float4* __restrict__ nbr,
+                                                          int cap, int capA, float4* __restrict__ recA,
+                                                          float4* __restrict__ recB, int* __restrict__ tri,
+                                                          int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
+                                                          int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float4* stage = (float4*)lds_raw;
+    const AtomGroups G = carve_groups((int*)(stage + capA), P->S, P->NB);
     const int lane = lane_id();
     const CellGrid g = *grid;
     if (!g.ok) {                                           // box too small for the stencil: tell the host
-        if (blockIdx.x == 0 && lane == 0) atomicOr(&status[kStatOverflow], 2);
+        if (lane == 0) {
+            if (blockIdx.x == 0) atomicOr(&status[kStatOverflow], 2);
+            cnt_a[blockIdx.x] = 0;                         // keep the consumers of this (void) build harmless
+            cnt_ro[blockIdx.x] = 0;
+        }
         return;
     }
     const float rcr2 = P->rcr2, rca2 = P->rca2;
     Box b{};
     if (PERIODIC) b = load_box(box);
     const float4 me = sorted_pos[blockIdx.x];
-    const int i = __float_as_int(me.w);
+    const int i = __float_as_int(me.w) & kIdMask;
     const int c = atom_cell[i];
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
-    int* row = nbr + (size_t)i * cap;
+    float4* row = nbr + (size_t)i * cap;
     int na = 0, nro = 0;
     for_each_stencil_range(g, cell_start, cx, cy, cz, [&](int begin, int end) {
         for (int base = begin; base < end; base += 64) {
             const int k = base + lane;
             bool in_r = false, in_a = false;
-            int j = -1;
+            int word = 0;
+            float dx = 0.f, dy = 0.f, dz = 0.f;
             if (k < end) {
                 const float4 pj = sorted_pos[k];
-                j = __float_as_int(pj.w);
-                if (j != i) {
-                    float dx = pj.x - me.x, dy = pj.y - me.y, dz = pj.z - me.z;
+                word = __float_as_int(pj.w);
+                if ((word & kIdMask) != i) {
+                    dx = pj.x - me.x; dy = pj.y - me.y; dz = pj.z - me.z;
                     min_image<PERIODIC>(dx, dy, dz, b);
                     const float r2 = dx * dx + dy * dy + dz * dz;
                     in_r = r2 < rcr2;
                     in_a = in_r && (r2 < rca2);
                 }
             }
-            const bool in_ro = in_r && !in_a;
-            const unsigned long long ma = __ballot(in_a), mro = __ballot(in_ro);
-            if (in_a) {
-                const int slot = na + prefix_popc(ma);
-                if (slot < cap) row[slot] = j;
-            }
-            if (in_ro) {
-                const int slot = nro + prefix_popc(mro);
-                if (slot < cap) row[cap - 1 - slot] = j;
-            }
-            na += __popcll(ma);
-            nro += __popcll(mro);
+            append_to_row(row, cap, stage, capA, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
         }
     });
-    if (lane == 0) {
-        cnt_a[i] = na;
-        cnt_ro[i] = nro;
-    }
-}
-
-// Clamp the per-atom counts so that consumers never index outside a row even after an overflow
-// (results of an overflowed compute are garbage and reported through nnpops_ani_check).
-__device__ __forceinline__ void clamped_counts(const int* cnt_a, const int* cnt_ro, int i, int cap, int cap_angular,
-                                               int& na, int& nro) {
-    na = min(cnt_a[i], min(cap, cap_angular));
-    nro = min(cnt_ro[i], cap - na);
+    if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
+    int n, nro_c;
+    clamp_counts(na, nro, cap, capA, n, nro_c);
+    __syncthreads();
+    finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
+                     tri + (size_t)i * triples_capacity(capA), G);
 }
 
 // =============================================================================================
-// Radial forward.  LDS: per-neighbour {r, fc, species} + the [S][nR] accumulator row.
+// Radial forward.  LDS: per-neighbour {r, fc, species}.
 // =============================================================================================
-template <bool PERIODIC>
 __global__ __launch_bounds__(64) void ani_radial_forward(const AniParams* __restrict__ P,
-                                                         const float* __restrict__ pos,
-                                                         const float* __restrict__ box,
-                                                         const int* __restrict__ species,
-                                                         const int* __restrict__ nbr, int cap, int cap_angular,
+                                                         const float4* __restrict__ nbr, int cap, int cap_angular,
                                                          const int* __restrict__ cnt_a,
                                                          const int* __restrict__ cnt_ro, float* __restrict__ radial) {
     extern __shared__ float lds[];
     const int i = blockIdx.x, lane = lane_id();
     const int S = P->S, nR = P->nR, width = S * nR;
-    float* acc = lds;                        // [S*nR]
-    float* nb_r = acc + width;               // [cap]
+    float* nb_r = lds;                       // [cap]
     float* nb_fc = nb_r + cap;               // [cap]
     int* nb_sp = (int*)(nb_fc + cap);        // [cap]
 
     int na, nro;
-    clamped_counts(cnt_a, cnt_ro, i, cap, cap_angular, na, nro);
+    clamp_counts(cnt_a[i], cnt_ro[i], cap, cap_angular, na, nro);
     const int total = na + nro;
-    const int* row = nbr + (size_t)i * cap;
-    Box b{};
-    if (PERIODIC) b = load_box(box);
-    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    const float4* row = nbr + (size_t)i * cap;
     const float rcr = P->rcr;
 
     for (int e = lane; e < total; e += 64) {
-        const int j = e < na ? row[e] : row[cap - 1 - (e - na)];
-        float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
-        min_image<PERIODIC>(dx, dy, dz, b);
-        const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float4 rec = e < na ? row[e] : row[cap - 1 - (e - na)];
+        const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         nb_r[e] = r;
-        nb_fc[e] = 0.5f * cosf(kPi * r / rcr) + 0.5f;
-        nb_sp[e] = species[j];
+        nb_fc[e] = 0.5f * cospif(r / rcr) + 0.5f;
+        nb_sp[e] = __float_as_int(rec.w) >> kTagShift;
     }
     __syncthreads();
 
     // lanes = (stream, k): KP = smallest power of two >= nR.  Each lane keeps one partial sum per
-    // species in registers (select-accumulate; LDS float atomics cost ~3 cycles per lane on gfx950,
-    // see tools/ubench/lds_atomic.hip), streams are folded with xor-shuffles at the end.
+    // species in registers (select-accumulate), streams are folded with xor-shuffles at the end.
     int KP = 1;
     while (KP < nR) KP <<= 1;
     const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
@@ -278,12 +436,9 @@ __global__ __launch_bounds__(64) void ani_radial_forward(const AniParams* __rest
 // =============================================================================================
 // Radial backward (owner computes; writes position_deriv[i], no atomics).      ref :228-263
 // =============================================================================================
-template <bool PERIODIC>
 __global__ __launch_bounds__(64) void ani_radial_backward(const AniParams* __restrict__ P,
-                                                          const float* __restrict__ pos,
-                                                          const float* __restrict__ box,
                                                           const int* __restrict__ species,
-                                                          const int* __restrict__ nbr, int cap, int cap_angular,
+                                                          const float4* __restrict__ nbr, int cap, int cap_angular,
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
                                                           const float* __restrict__ radial_grad,
@@ -302,30 +457,27 @@ __global__ __launch_bounds__(64) void ani_radial_backward(const AniParams* __res
     int* nb_j = nb_sp + cap;
 
     int na, nro;
-    clamped_counts(cnt_a, cnt_ro, i, cap, cap_angular, na, nro);
+    clamp_counts(cnt_a[i], cnt_ro[i], cap, cap_angular, na, nro);
     const int total = na + nro;
-    const int* row = nbr + (size_t)i * cap;
-    Box b{};
-    if (PERIODIC) b = load_box(box);
-    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    const float4* row = nbr + (size_t)i * cap;
     const float rcr = P->rcr;
     const int si = species[i];
 
     const float* gi = radial_grad + (size_t)i * width;
     for (int q = lane; q < width; q += 64) g_own[q] = gi[q];
     for (int e = lane; e < total; e += 64) {
-        const int j = e < na ? row[e] : row[cap - 1 - (e - na)];
-        float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
-        min_image<PERIODIC>(dx, dy, dz, b);
-        const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float4 rec = e < na ? row[e] : row[cap - 1 - (e - na)];
+        const int word = __float_as_int(rec.w);
+        const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         const float rinv = 1.0f / r;
-        const float arg = kPi * r / rcr;
+        float sn, cs;
+        sincospif(r / rcr, &sn, &cs);
         nb_r[e] = r;
-        nb_fc[e] = 0.5f * cosf(arg) + 0.5f;
-        nb_dfc[e] = -(0.5f * kPi / rcr) * sinf(arg);
-        nb_ux[e] = dx * rinv; nb_uy[e] = dy * rinv; nb_uz[e] = dz * rinv;
-        nb_sp[e] = species[j];
-        nb_j[e] = j;
+        nb_fc[e] = 0.5f * cs + 0.5f;
+        nb_dfc[e] = -(0.5f * kPi / rcr) * sn;
+        nb_ux[e] = rec.x * rinv; nb_uy[e] = rec.y * rinv; nb_uz[e] = rec.z * rinv;
+        nb_sp[e] = word >> kTagShift;
+        nb_j[e] = word & kIdMask;
     }
     __syncthreads();
 
@@ -356,136 +508,18 @@ __global__ __launch_bounds__(64) void ani_radial_backward(const AniParams* __res
 // =============================================================================================
 // Angular kernels.
 // =============================================================================================
-// Per-neighbour record kept in LDS, sorted by species so that triples come out grouped by bucket.
-struct AngRec {
-    float dx, dy, dz, r;       // displacement i -> j and its length
-};
-struct AngRec2 {
-    float fc, dfc, rinv;
-    int sp;
-};
-
-// (p, q) with p < q of the t-th pair in row-major order of the strict upper triangle of an n x n grid
-__device__ __forceinline__ void decode_pair(int t, int n, int& p, int& q) {
-    const float w = (float)(2 * n - 1);
-    int pp = (int)((w - fast_sqrt(w * w - 8.0f * (float)t)) * 0.5f);
-    pp = max(0, min(pp, n - 2));
-    // offset(p) = p*(2n-p-1)/2 ; one fix-up step each way covers the rounding of the fast sqrt
-    if (((pp + 1) * (2 * n - pp - 2)) / 2 <= t) pp++;
-    if ((pp * (2 * n - pp - 1)) / 2 > t) pp--;
-    p = pp;
-    q = t - (pp * (2 * n - pp - 1)) / 2 + pp + 1;
-}
-
-// Load the angular neighbours of atom i into LDS, stably sorted by species.  Returns n.
-// scratch: int[2*kMaxSpecies] in LDS.
-template <bool PERIODIC>
-__device__ __forceinline__ int load_sorted_angular_neighbors(const AniParams* __restrict__ P,
-                                                             const float* __restrict__ pos, const Box& b,
-                                                             const int* __restrict__ species,
-                                                             const int* __restrict__ row, int n, int i,
-                                                             AngRec* rec, AngRec2* rec2, int* rec_j, int* scratch) {
-    const int lane = lane_id();
-    const int S = P->S;
-    int* tot = scratch;              // [S] species totals, then exclusive prefix
-    int* run = scratch + kMaxSpecies;  // [S] running within-species offsets
-    for (int s = lane; s < S; s += 64) { tot[s] = 0; run[s] = 0; }
-    __syncthreads();
-    for (int e = lane; e < n; e += 64) atomicAdd(&tot[species[row[e]]], 1);
-    __syncthreads();
-    if (lane == 0) {
-        int accum = 0;
-        for (int s = 0; s < S; s++) { const int c = tot[s]; tot[s] = accum; accum += c; }
-    }
-    __syncthreads();
-    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-    const float rca = P->rca;
-    for (int base = 0; base < n; base += 64) {
-        const int e = base + lane;
-        const bool valid = e < n;
-        int j = 0, sp = -1;
-        float dx = 0, dy = 0, dz = 0;
-        if (valid) {
-            j = row[e];
-            sp = species[j];
-            dx = pos[3 * j] - xi; dy = pos[3 * j + 1] - yi; dz = pos[3 * j + 2] - zi;
-            min_image<PERIODIC>(dx, dy, dz, b);
-        }
-        int rank = 0;
-        for (int s = 0; s < S; s++) {
-            const unsigned long long m = __ballot(valid && sp == s);
-            if (sp == s) rank = tot[s] + run[s] + prefix_popc(m);
-            __syncthreads();
-            if (lane == 0) run[s] += __popcll(m);
-            __syncthreads();
-        }
-        if (valid) {
-            const float r = sqrtf(dx * dx + dy * dy + dz * dz);
-            const float arg = kPi * r / rca;
-            rec[rank] = AngRec{dx, dy, dz, r};
-            rec2[rank] = AngRec2{0.5f * cosf(arg) + 0.5f, -(0.5f * kPi / rca) * sinf(arg), 1.0f / r, sp};
-            if (rec_j) rec_j[rank] = j;
-        }
-    }
-    __syncthreads();
-    return n;
-}
-
-// LDS carve-up shared by the two angular kernels (all offsets multiples of 16 bytes).
-struct AngLds {
-    AngRec* rec;      // [capA]
-    AngRec2* rec2;    // [capA]
-    int* rec_j;       // [capA]
-    float* row;       // [NB][NFRP][NFZP] canonical accumulator (fwd) / scaled upstream gradient (bwd)
-    float* facR;      // fwd: [64][NFRP]        bwd: per-neighbour force accumulators [capA][4]
-    float* facZ;      // fwd: [64][NFZP]
-    int* facB;        // fwd: [64]
-    int* scratch;     // [2*kMaxSpecies]
-};
-
-template <int NFRP, int NFZP>
-__host__ __device__ inline size_t ang_lds_bytes(int capA, int NB, bool forward) {
-    size_t b = (size_t)capA * (sizeof(AngRec) + sizeof(AngRec2) + sizeof(int));
-    b += (size_t)NB * NFRP * NFZP * sizeof(float);
-    b += forward ? (size_t)64 * (NFRP + NFZP + 1) * sizeof(float) : (size_t)capA * 4 * sizeof(float);
-    b += 2 * kMaxSpecies * sizeof(int);
-    return b;
-}
-
-template <int NFRP, int NFZP>
-__device__ __forceinline__ AngLds carve_lds(char* base, int capA, int NB, bool forward) {
-    AngLds L;
-    L.rec = (AngRec*)base;            base += (size_t)capA * sizeof(AngRec);
-    L.rec2 = (AngRec2*)base;          base += (size_t)capA * sizeof(AngRec2);
-    L.row = (float*)base;             base += (size_t)NB * NFRP * NFZP * sizeof(float);
-    if (forward) {
-        L.facR = (float*)base;        base += (size_t)64 * NFRP * sizeof(float);
-        L.facZ = (float*)base;        base += (size_t)64 * NFZP * sizeof(float);
-        L.facB = (int*)base;          base += (size_t)64 * sizeof(int);
-    } else {
-        L.facR = (float*)base;        base += (size_t)capA * 4 * sizeof(float);
-        L.facZ = nullptr;
-        L.facB = nullptr;
-    }
-    L.rec_j = (int*)base;             base += (size_t)capA * sizeof(int);
-    L.scratch = (int*)base;
-    return L;
-}
-
-// Geometry of one triple, shared by forward and backward.
+// Geometry of one triple, shared by forward and backward.  A = {dx,dy,dz,r}, A2 = {fc,dfc,1/r,word}.
 struct TripleGeom {
     float c, s;        // cos / sin of the (damped) angle
     float rbar;        // (r_ij + r_ik)/2
     float fcfc;
-    int bucket;
 };
 
 template <bool TORCHANI>
-__device__ __forceinline__ TripleGeom triple_geometry(const AngRec& A, const AngRec2& A2, const AngRec& B,
-                                                      const AngRec2& B2, int S) {
+__device__ __forceinline__ TripleGeom triple_geometry(const float4& A, const float4& A2, const float4& B, const float4& B2) {
     TripleGeom g;
-    const float dot = A.dx * B.dx + A.dy * B.dy + A.dz * B.dz;
-    const float iprod = A2.rinv * B2.rinv;
+    const float dot = A.x * B.x + A.y * B.y + A.z * B.z;
+    const float iprod = A2.z * B2.z;
     if (TORCHANI) {
         g.c = 0.95f * dot * iprod;                       // ref :391-393
         g.s = fast_sqrt(1.0f - g.c * g.c);               // |c| <= 0.95: no cancellation
@@ -493,42 +527,98 @@ __device__ __forceinline__ TripleGeom triple_geometry(const AngRec& A, const Ang
         g.c = fminf(fmaxf(dot * iprod, -1.0f), 1.0f);
         // sin from the cross product: accurate next to 0 and pi, which is what the reference's
         // asin branch (ref :396-404) is there for
-        const float cx = A.dy * B.dz - A.dz * B.dy, cy = A.dz * B.dx - A.dx * B.dz, cz = A.dx * B.dy - A.dy * B.dx;
+        const float cx = A.y * B.z - A.z * B.y, cy = A.z * B.x - A.x * B.z, cz = A.x * B.y - A.y * B.x;
         g.s = fminf(fast_sqrt(cx * cx + cy * cy + cz * cz) * iprod, 1.0f);
     }
-    g.rbar = 0.5f * (A.r + B.r);
-    g.fcfc = A2.fc * B2.fc;
-    const int sa = A2.sp, sb = B2.sp;                    // sorted: sa <= sb
-    g.bucket = sa * S - (sa * (sa - 1)) / 2 + (sb - sa); // upper-triangular row-major, ref :39-43
+    g.rbar = 0.5f * (A.w + B.w);
+    g.fcfc = A2.x * B2.x;
     return g;
+}
+
+// Copy the atom's sorted angular records into LDS (one coalesced access per array).
+__device__ __forceinline__ void load_angular_records(const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
+                                                     int n, float4* recA, float4* recB) {
+    for (int e = lane_id(); e < n; e += 64) {
+        const float4 a = recA_g[e], b = recB_g[e];
+        recA[e] = a;
+        recB[e] = b;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Angular forward.
+//
+// LDS per wave: sorted neighbour records, the atom's output row in canonical padded order
+// [bucket][a][z], and the per-batch factor staging area.
+//
+// phase 2 ownership rules (triples of a batch are in bucket-major order, so every bucket is one
+// contiguous run): stream s = lanes [s*NFRP, (s+1)*NFRP) owns the CH = NFRP consecutive triples
+// [s*CH, (s+1)*CH) of the batch and lane (s, a) accumulates acc[z] += R_a * Z_z.  A run that starts
+// and ends strictly inside a stream's chunk belongs to that stream alone and is added to the LDS
+// row with a plain read-modify-write.  The first and the last run of each chunk may continue in a
+// neighbouring stream; see "edge runs" below.  Batches whose 64 triples share one bucket (the common
+// case for few-species systems) skip all of that: accumulate, fold the streams with xor-shuffles,
+// one read-modify-write.
 // ---------------------------------------------------------------------------------------------
-template <bool PERIODIC, bool TORCHANI, int NFRP, int NFZP>
-__global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __restrict__ P,
-                                                          const float* __restrict__ pos,
-                                                          const float* __restrict__ box,
-                                                          const int* __restrict__ species,
-                                                          const int* __restrict__ nbr, int cap, int capA,
+template <int NFRP, int NFZP>
+struct FwdLayout {
+    static constexpr int CH = NFRP;                       // triples per stream per batch
+    static constexpr int NSTREAM = 64 / NFRP;
+    static constexpr int SR = NFRP * (CH + 1);            // stream stride of facR in floats (bank-conflict free)
+    static constexpr int BLK = NFRP * NFZP;               // padded canonical block of one bucket
+};
+
+template <int NFRP, int NFZP>
+__host__ __device__ inline size_t ang_fwd_lds_bytes(int capA, int NB) {
+    using L = FwdLayout<NFRP, NFZP>;
+    size_t b = (size_t)capA * 2 * sizeof(float4);
+    b += (size_t)NB * L::BLK * sizeof(float);
+    b += (size_t)L::NSTREAM * L::SR * sizeof(float) + (size_t)64 * NFZP * sizeof(float) + 64 * sizeof(int);
+    return b;
+}
+
+template <int NFZP>
+__device__ __forceinline__ void row_add(float* dst, const float (&v)[NFZP]) {
+#pragma unroll
+    for (int z = 0; z < NFZP; z += 4) {
+        float4 cur = *reinterpret_cast<float4*>(dst + z);
+        cur.x += v[z]; cur.y += v[z + 1]; cur.z += v[z + 2]; cur.w += v[z + 3];
+        *reinterpret_cast<float4*>(dst + z) = cur;
+    }
+}
+
+template <bool TORCHANI, int NFRP, int NFZP>
+__global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __restrict__ P, int cap, int capA,
+                                                          const float4* __restrict__ recA_g,
+                                                          const float4* __restrict__ recB_g,
+                                                          const int* __restrict__ tri_g,
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
-                                                          float* __restrict__ angular) {
+                                                          float* __restrict__ angular, int dbg) {
+    using L = FwdLayout<NFRP, NFZP>;
+    constexpr int CH = L::CH, NSTREAM = L::NSTREAM, SR = L::SR, BLK = L::BLK;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int i = blockIdx.x, lane = lane_id();
-    const int S = P->S, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
-    AngLds L = carve_lds<NFRP, NFZP>(lds_raw, capA, NB, true);
-    constexpr int BLK = NFRP * NFZP;                      // padded canonical block
-    const int rowlen = NB * BLK;
+    const int NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
+    if (dbg & 32) return;                                  // ablation: launch + dispatch floor
+
+    char* cursor = lds_raw;
+    float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float* row = (float*)cursor;          cursor += (size_t)NB * BLK * sizeof(float);
+    float* facR = (float*)cursor;         cursor += (size_t)NSTREAM * SR * sizeof(float);
+    float* facZ = (float*)cursor;         cursor += (size_t)64 * NFZP * sizeof(float);
+    int* facB = (int*)cursor;
 
     int n, nro;
-    clamped_counts(cnt_a, cnt_ro, i, cap, capA, n, nro);
-    Box b{};
-    if (PERIODIC) b = load_box(box);
-    for (int q = lane; q < rowlen; q += 64) L.row[q] = 0.f;
-    load_sorted_angular_neighbors<PERIODIC>(P, pos, b, species, nbr + (size_t)i * cap, n, i, L.rec, L.rec2, nullptr,
-                                            L.scratch);
+    clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+    const int T = (n * (n - 1)) / 2;
+    const int* tri = tri_g + (size_t)i * triples_capacity(capA);
+    int word = lane < T ? tri[lane] : 0;                   // first batch of triple words, in flight early
+    load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
+    const int rowlen = NB * BLK;
+    for (int q = lane; q < rowlen; q += 64) row[q] = 0.f;
+    if (dbg & 16) return;                                  // ablation: prologue only
 
     // per-lane constants of the two factor families
     float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP];
@@ -540,113 +630,296 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
         zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
         zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
     }
+    __syncthreads();
 
-    constexpr int NSTREAM = 64 / NFRP;                    // phase-2 streams; each owns every NSTREAM-th triple
     const int a2 = lane & (NFRP - 1), stream = lane / NFRP;
-    const int T = (n * (n - 1)) / 2;
     for (int base = 0; base < T; base += 64) {
         // ---------------- phase 1: lane = triple ----------------
         const int t = base + lane;
-        if (t < T) {
-            int p, q;
-            decode_pair(t, n, p, q);
-            const AngRec A = L.rec[p], B = L.rec[q];
-            const AngRec2 A2 = L.rec2[p], B2 = L.rec2[q];
-            const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2, S);
+        const int next_word = (t + 64 < T) ? tri[t + 64] : 0;     // prefetch the next batch
+        int bucket = -1;
+        if (t < T && !(dbg & 1)) {
+            const int p = word & 0xff, q = (word >> 8) & 0xff;
+            bucket = word >> 16;
+            const float4 A = recA[p], B = recA[q];
+            const float4 A2 = recB[p], B2 = recB[q];
+            const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
+            float* dstR = facR + (lane / CH) * SR + (lane % CH) * NFRP;
 #pragma unroll
-            for (int a = 0; a < NFRP; a++) {
-                const float sh = g.rbar - frs[a];
-                L.facR[lane * NFRP + a] = fast_exp2(frc[a] * sh * sh);
+            for (int a = 0; a < NFRP; a += 4) {
+                float4 v;
+                float sh;
+                sh = g.rbar - frs[a];     v.x = fast_exp2(frc[a] * sh * sh);
+                sh = g.rbar - frs[a + 1]; v.y = fast_exp2(frc[a + 1] * sh * sh);
+                sh = g.rbar - frs[a + 2]; v.z = fast_exp2(frc[a + 2] * sh * sh);
+                sh = g.rbar - frs[a + 3]; v.w = fast_exp2(frc[a + 3] * sh * sh);
+                *reinterpret_cast<float4*>(dstR + a) = v;
             }
+            float zv[NFZP];
 #pragma unroll
             for (int z = 0; z < NFZP; z++) {
                 const float x = fmaxf(1.0f + (g.c * zc[z] + g.s * zs[z]), 1e-30f);   // 1 + cos(theta - ths)
-                L.facZ[lane * NFZP + z] = g.fcfc * fast_exp2(zz[z] * fast_log2(x));
+                zv[z] = g.fcfc * fast_exp2(zz[z] * fast_log2(x));
             }
-            L.facB[lane] = g.bucket;
+#pragma unroll
+            for (int z = 0; z < NFZP; z += 4)
+                *reinterpret_cast<float4*>(facZ + lane * NFZP + z) = make_float4(zv[z], zv[z + 1], zv[z + 2], zv[z + 3]);
+            facB[lane] = bucket;
         }
+        word = next_word;
+        const int b0 = __shfl(bucket, 0, 64);
+        const bool uniform = __all(bucket == b0);          // implies all 64 lanes hold a triple
         __syncthreads();
         // ---------------- phase 2: lane = (stream, a) ----------------
-        {
-            const int count = min(64, T - base);
+        const float* srcR = facR + stream * SR + a2;
+        if (dbg & 2) {
+        } else if (uniform) {
             float acc[NFZP];
 #pragma unroll
             for (int z = 0; z < NFZP; z++) acc[z] = 0.f;
-            int cur = -1;
-            for (int u = stream; u < count; u += NSTREAM) {
-                const int bkt = L.facB[u];
-                if (bkt != cur) {
-                    if (cur >= 0) {
 #pragma unroll
-                        for (int z = 0; z < NFZP; z++) atomicAdd(&L.row[cur * BLK + a2 * NFZP + z], acc[z]);
-                    }
+            for (int u = 0; u < CH; u++) {
+                const float R = srcR[u * NFRP];
+                const float* Z = facZ + (stream * CH + u) * NFZP;
 #pragma unroll
-                    for (int z = 0; z < NFZP; z++) acc[z] = 0.f;
-                    cur = bkt;
-                }
-                const float R = L.facR[u * NFRP + a2];
-#pragma unroll
-                for (int z = 0; z < NFZP; z++) acc[z] += R * L.facZ[u * NFZP + z];
+                for (int z = 0; z < NFZP; z++) acc[z] += R * Z[z];
             }
-            if (cur >= 0) {
 #pragma unroll
-                for (int z = 0; z < NFZP; z++) atomicAdd(&L.row[cur * BLK + a2 * NFZP + z], acc[z]);
+            for (int off = NFRP; off < 64; off <<= 1) {
+#pragma unroll
+                for (int z = 0; z < NFZP; z++) acc[z] += __shfl_xor(acc[z], off, 64);
+            }
+            if (stream == 0) row_add<NFZP>(row + b0 * BLK + a2 * NFZP, acc);
+        } else {
+            const int count = min(64, T - base);
+            float acc[NFZP], head[NFZP];
+#pragma unroll
+            for (int z = 0; z < NFZP; z++) { acc[z] = 0.f; head[z] = 0.f; }
+            int cur = -1, hb = -1;
+            bool first = true;
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int tl = stream * CH + u;
+                if (tl < count) {
+                    const int bkt = facB[tl];
+                    if (bkt != cur) {
+                        if (cur >= 0) {
+                            if (first) {
+                                hb = cur;
+#pragma unroll
+                                for (int z = 0; z < NFZP; z++) head[z] = acc[z];
+                                first = false;
+                            } else {
+                                row_add<NFZP>(row + cur * BLK + a2 * NFZP, acc);   // interior run: sole owner
+                            }
+                        }
+#pragma unroll
+                        for (int z = 0; z < NFZP; z++) acc[z] = 0.f;
+                        cur = bkt;
+                    }
+                    const float R = srcR[u * NFRP];
+                    const float* Z = facZ + tl * NFZP;
+#pragma unroll
+                    for (int z = 0; z < NFZP; z++) acc[z] += R * Z[z];
+                }
+            }
+            int tb = -1;
+            if (cur >= 0) {
+                if (first) {
+                    hb = cur;
+#pragma unroll
+                    for (int z = 0; z < NFZP; z++) head[z] = acc[z];
+                } else {
+                    tb = cur;
+                }
+            }
+            // edge runs.  A head can only be shared with the previous stream's last run, a tail only with
+            // the next stream's head (runs are contiguous), so two bucket-id shuffles tell which edge runs
+            // have a single owner: those are added in one step; the (rare) shared ones go stream by stream
+            // (LDS operations of a wave execute in order).
+            const int lastb = tb >= 0 ? tb : hb;
+            int prev_last = __shfl_up(lastb, NFRP, 64);
+            int next_head = __shfl_down(hb, NFRP, 64);
+            if (stream == 0) prev_last = -2;
+            if (stream == NSTREAM - 1) next_head = -2;
+            const bool head_free = hb >= 0 && hb != prev_last && !(tb < 0 && hb == next_head);
+            const bool tail_free = tb >= 0 && tb != next_head;
+            if (head_free) row_add<NFZP>(row + hb * BLK + a2 * NFZP, head);
+            if (tail_free) row_add<NFZP>(row + tb * BLK + a2 * NFZP, acc);
+            const bool head_left = hb >= 0 && !head_free, tail_left = tb >= 0 && !tail_free;
+            if (__any(head_left || tail_left)) {
+                for (int s2 = 0; s2 < NSTREAM; s2++) {
+                    if (stream == s2) {
+                        if (head_left) row_add<NFZP>(row + hb * BLK + a2 * NFZP, head);
+                        if (tail_left) row_add<NFZP>(row + tb * BLK + a2 * NFZP, acc);
+                    }
+                }
             }
         }
         __syncthreads();
     }
 
-    // ---------------- epilogue: canonical LDS row -> reference column order, one coalesced write ----------------
+    // ---------------- epilogue: canonical LDS row -> reference column order, coalesced rows ----------------
     float* out = angular + (size_t)i * NB * nA;
-    const int per_block = nFR * nFZ;                       // == nA
-    for (int q = lane; q < NB * per_block; q += 64) {
-        const int bkt = q / per_block, c = q - bkt * per_block;
-        const int a = c / nFZ, z = c - a * nFZ;
-        out[bkt * nA + P->m_of[c]] = L.row[bkt * BLK + a * NFZP + z] * P->fz_scale[z];
+    if (dbg & 4) return;
+    if (nA <= 32) {                                        // two buckets per pass
+        const int m = lane & 31, half = lane >> 5;
+        const bool live = m < nA;
+        const int c = live ? P->c_of_m[m] : 0;             // canonical slot a*NFZP+z of function m
+        const float sc = live ? P->scale_m[m] : 0.f;
+        for (int bk = half; bk < NB; bk += 2)
+            if (live) out[bk * nA + m] = row[bk * BLK + c] * sc;
+    } else {
+        for (int bk = 0; bk < NB; bk++)
+            for (int m = lane; m < nA; m += 64) out[bk * nA + m] = row[bk * BLK + P->c_of_m[m]] * P->scale_m[m];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Angular backward.                                                              ref :265-353
+//
+// lane = triple (p < q sorted neighbour slots).  The force a triple puts on its two leg atoms is
+// written to an LDS "pair matrix" M[p][q] (force on p) / M[q][p] (force on q): every entry has
+// exactly one writer, so there are no atomics and no reductions across lanes; afterwards lane e sums
+// row e.  The centre atom receives minus the total.  The host sizes `tile` (<= 32, the matrix edge)
+// from the largest angular neighbour count it has seen, so an atom is normally one tile and takes
+// its triples straight from the builder's word list; an atom that outgrows the tile is processed
+// tile pair by tile pair (enumerating pairs itself, off-diagonal tiles in two passes).
 // ---------------------------------------------------------------------------------------------
-template <bool PERIODIC, bool TORCHANI, int NFRP, int NFZP>
-__global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __restrict__ P,
-                                                           const float* __restrict__ pos,
-                                                           const float* __restrict__ box,
-                                                           const int* __restrict__ species,
-                                                           const int* __restrict__ nbr, int cap, int capA,
+template <int NFRP, int NFZP>
+__host__ __device__ inline size_t ang_bwd_lds_bytes(int capA, int NB, int tile) {
+    size_t b = (size_t)capA * (2 * sizeof(float4) + 4 * sizeof(float));
+    b += (size_t)NB * NFRP * NFZP * sizeof(float);
+    b += (size_t)3 * tile * (tile + 1) * sizeof(float);
+    return b;
+}
+
+// Forces of one triple on its two leg atoms (Fp, Fq), given the scaled upstream-gradient block.
+template <bool TORCHANI, int NFRP, int NFZP>
+__device__ __forceinline__ void triple_forces(const float4& A, const float4& A2, const float4& B, const float4& B2,
+                                              const float* Gb, const float (&frc)[NFRP], const float (&frs)[NFRP],
+                                              const float (&fre)[NFRP], const float (&zz)[NFZP], const float (&zc)[NFZP],
+                                              const float (&zs)[NFZP], float (&Fp)[3], float (&Fq)[3]) {
+    const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
+    float R[NFRP], dR[NFRP];
+#pragma unroll
+    for (int a = 0; a < NFRP; a++) {
+        const float sh = g.rbar - frs[a];
+        R[a] = fast_exp2(frc[a] * sh * sh);
+        dR[a] = -fre[a] * sh * R[a];       // d/dr_ij of exp(-eta (rbar-Rs)^2): rbar carries 1/2 (ref :306)
+    }
+    // contract the gradient block with R and dR:  U_z = sum_a G[a][z] R_a,  V_z = sum_a G[a][z] dR_a
+    float U[NFZP], V[NFZP];
+#pragma unroll
+    for (int z = 0; z < NFZP; z++) { U[z] = 0.f; V[z] = 0.f; }
+#pragma unroll
+    for (int a = 0; a < NFRP; a++) {
+#pragma unroll
+        for (int z = 0; z < NFZP; z += 4) {
+            const float4 gv = *reinterpret_cast<const float4*>(Gb + a * NFZP + z);
+            U[z] += gv.x * R[a];     V[z] += gv.x * dR[a];
+            U[z + 1] += gv.y * R[a]; V[z + 1] += gv.y * dR[a];
+            U[z + 2] += gv.z * R[a]; V[z + 2] += gv.z * dR[a];
+            U[z + 3] += gv.w * R[a]; V[z + 3] += gv.w * dR[a];
+        }
+    }
+    float S0 = 0.f, Sr = 0.f, Sth = 0.f;
+#pragma unroll
+    for (int z = 0; z < NFZP; z++) {
+        const float cz = g.c * zc[z] + g.s * zs[z];    // cos(theta - ths)
+        const float sz = g.s * zc[z] - g.c * zs[z];    // sin(theta - ths)
+        const float x = fmaxf(1.0f + cz, 1e-30f);      // keeps 0 * -inf out of the zeta == 1 corner
+        const float lg = fast_log2(x);
+        const float Z = fast_exp2(zz[z] * lg);                          // (1+cos)^zeta
+        const float dZ = -zz[z] * fast_exp2((zz[z] - 1.0f) * lg) * sz;   // d/dtheta           ref :337
+        S0 += U[z] * Z;
+        Sr += V[z] * Z;
+        Sth += U[z] * dZ;
+    }
+    // three routes of the chain rule (ref :311-348), already summed over the functions m
+    const float t1 = A2.y * B2.x * S0 + g.fcfc * Sr;   // through r_ij   (A2.y = dfc_ij, B2.x = fc_ik)
+    const float t2 = A2.x * B2.y * S0 + g.fcfc * Sr;   // through r_ik
+    const float t3 = g.fcfc * Sth;                     // through theta
+    // angle gradients (ref :410-433): dtheta/d(dot') = -damp / sin(theta)
+    const float dot = A.x * B.x + A.y * B.y + A.z * B.z;
+    const float iprod = A2.z * B2.z;
+    const float damp = TORCHANI ? 0.95f : 1.0f;
+    const float dadd = -damp * fast_rcp(g.s) * iprod * t3;
+    const float ka = dot * A2.z * A2.z, kb = dot * B2.z * B2.z;
+    const float s1 = t1 * A2.z, s2 = t2 * B2.z;
+    Fp[0] = s1 * A.x + dadd * (B.x - ka * A.x);
+    Fp[1] = s1 * A.y + dadd * (B.y - ka * A.y);
+    Fp[2] = s1 * A.z + dadd * (B.z - ka * A.z);
+    Fq[0] = s2 * B.x + dadd * (A.x - kb * B.x);
+    Fq[1] = s2 * B.y + dadd * (A.y - kb * B.y);
+    Fq[2] = s2 * B.z + dadd * (A.z - kb * B.z);
+}
+
+template <bool TORCHANI, int NFRP, int NFZP>
+__global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __restrict__ P, int cap, int capA, int tile,
+                                                           const float4* __restrict__ recA_g,
+                                                           const float4* __restrict__ recB_g,
+                                                           const int* __restrict__ tri_g,
                                                            const int* __restrict__ cnt_a,
                                                            const int* __restrict__ cnt_ro,
                                                            const float* __restrict__ angular_grad,
-                                                           float* __restrict__ pos_grad) {
+                                                           float* __restrict__ pos_grad, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int i = blockIdx.x, lane = lane_id();
     const int S = P->S, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
-    AngLds L = carve_lds<NFRP, NFZP>(lds_raw, capA, NB, false);
     constexpr int BLK = NFRP * NFZP;
-    float* facc = L.facR;                                  // [capA][4] leg-atom force accumulators
+    const int tstride = tile + 1;
+
+    char* cursor = lds_raw;
+    float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float* facc = (float*)cursor;         cursor += (size_t)capA * 4 * sizeof(float);   // per-slot force accumulators
+    float* grow = (float*)cursor;         cursor += (size_t)NB * BLK * sizeof(float);   // scaled upstream gradient row
+    float* Mx = (float*)cursor;           cursor += (size_t)tile * tstride * sizeof(float);
+    float* My = (float*)cursor;           cursor += (size_t)tile * tstride * sizeof(float);
+    float* Mz = (float*)cursor;
 
     int n, nro;
-    clamped_counts(cnt_a, cnt_ro, i, cap, capA, n, nro);
-    if (n < 2) return;                                     // no triples: nothing to add (wave-uniform)
-    Box b{};
-    if (PERIODIC) b = load_box(box);
+    clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+    if (n < 2 || (dbg & 32)) return;                       // no triples: nothing to add (wave-uniform)
+    const int T = (n * (n - 1)) / 2;
+    const int* tri = tri_g + (size_t)i * triples_capacity(capA);
+    int word = lane < T ? tri[lane] : 0;
 
-    // upstream gradient row -> canonical [bucket][a][z] order, pre-multiplied by 2^(1-zeta)
-    for (int q = lane; q < NB * BLK; q += 64) L.row[q] = 0.f;
-    __syncthreads();
+    // upstream gradient row -> canonical [bucket][a][z] order, pre-multiplied by 2^(1-zeta).
+    // All global loads of a group are issued before LDS is touched (a load-store-load loop waits every trip).
     {
         const float* g = angular_grad + (size_t)i * NB * nA;
-        const int per_block = nFR * nFZ;
-        for (int q = lane; q < NB * per_block; q += 64) {
-            const int bkt = q / per_block, c = q - bkt * per_block;
-            const int a = c / nFZ, z = c - a * nFZ;
-            L.row[bkt * BLK + a * NFZP + z] = g[bkt * nA + P->m_of[c]] * P->fz_scale[z];
+        if (nA <= 32) {
+            const int m = lane & 31, half = lane >> 5;
+            const bool live = m < nA;
+            const int c = live ? P->c_of_m[m] : 0;
+            const float sc = live ? P->scale_m[m] : 0.f;
+            if (BLK != nA)
+                for (int q = lane; q < NB * BLK; q += 64) grow[q] = 0.f;      // padded slots must read as zero
+            for (int bk0 = half; bk0 < NB; bk0 += 16) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int bk = bk0 + 2 * k;
+                    v[k] = (live && bk < NB) ? g[bk * nA + m] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int bk = bk0 + 2 * k;
+                    if (live && bk < NB) grow[bk * BLK + c] = v[k] * sc;
+                }
+            }
+        } else {
+            for (int q = lane; q < NB * BLK; q += 64) grow[q] = 0.f;
+            __syncthreads();
+            for (int bk = 0; bk < NB; bk++)
+                for (int m = lane; m < nA; m += 64) grow[bk * BLK + P->c_of_m[m]] = g[bk * nA + m] * P->scale_m[m];
         }
     }
     for (int q = lane; q < n * 4; q += 64) facc[q] = 0.f;
-    load_sorted_angular_neighbors<PERIODIC>(P, pos, b, species, nbr + (size_t)i * cap, n, i, L.rec, L.rec2, L.rec_j,
-                                            L.scratch);
+    load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
+    if (dbg & 16) return;                                  // ablation: prologue only
 
     float frc[NFRP], frs[NFRP], fre[NFRP], zz[NFZP], zc[NFZP], zs[NFZP];
 #pragma unroll
@@ -661,75 +934,100 @@ __global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __re
         zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
         zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
     }
+    __syncthreads();
 
-    const int T = (n * (n - 1)) / 2;
-    for (int t = lane; t < T; t += 64) {
-        int p, q;
-        decode_pair(t, n, p, q);
-        const AngRec A = L.rec[p], B = L.rec[q];
-        const AngRec2 A2 = L.rec2[p], B2 = L.rec2[q];
-        const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2, S);
-
-        float R[NFRP], dR[NFRP];
-#pragma unroll
-        for (int a = 0; a < NFRP; a++) {
-            const float sh = g.rbar - frs[a];
-            R[a] = fast_exp2(frc[a] * sh * sh);
-            dR[a] = -fre[a] * sh * R[a];                   // d/dr_ij of exp(-eta (rbar-Rs)^2): rbar carries 1/2 (ref :306)
+    if (n <= tile) {
+        // ---------------- common case: one tile, triples from the builder's list ----------------
+        for (int base = 0; base < T && !(dbg & 1); base += 64) {
+            const int t = base + lane;
+            const int next_word = (t + 64 < T) ? tri[t + 64] : 0;
+            if (t < T) {
+                const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;
+                float Fp[3], Fq[3];
+                triple_forces<TORCHANI, NFRP, NFZP>(recA[p], recB[p], recA[q], recB[q], grow + bucket * BLK, frc, frs, fre,
+                                                    zz, zc, zs, Fp, Fq);
+                Mx[p * tstride + q] = Fp[0]; My[p * tstride + q] = Fp[1]; Mz[p * tstride + q] = Fp[2];
+                Mx[q * tstride + p] = Fq[0]; My[q * tstride + p] = Fq[1]; Mz[q * tstride + p] = Fq[2];
+            }
+            word = next_word;
         }
-        // contract the gradient block with R and dR:  U_z = sum_a G[a][z] R_a,  V_z = sum_a G[a][z] dR_a
-        float U[NFZP], V[NFZP];
-#pragma unroll
-        for (int z = 0; z < NFZP; z++) { U[z] = 0.f; V[z] = 0.f; }
-        const float* G = &L.row[g.bucket * BLK];
-#pragma unroll
-        for (int a = 0; a < NFRP; a++) {
-#pragma unroll
-            for (int z = 0; z < NFZP; z++) {
-                const float gv = G[a * NFZP + z];
-                U[z] += gv * R[a];
-                V[z] += gv * dR[a];
+        __syncthreads();
+        // row sums: lane (e, half) adds up to 16 columns of row e; halves folded by one shuffle
+        const int e = lane & 31, half = lane >> 5;
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        if (e < n && !(dbg & 2)) {
+            const int x0 = half * 16, x1 = min(n, x0 + 16);
+            const float* mx = Mx + e * tstride;
+            const float* my = My + e * tstride;
+            const float* mz = Mz + e * tstride;
+#pragma unroll 4
+            for (int x = x0; x < x1; x++) {
+                const bool use = x != e;
+                fx += use ? mx[x] : 0.f;
+                fy += use ? my[x] : 0.f;
+                fz += use ? mz[x] : 0.f;
             }
         }
-        float S0 = 0.f, Sr = 0.f, Sth = 0.f;
-#pragma unroll
-        for (int z = 0; z < NFZP; z++) {
-            const float cz = g.c * zc[z] + g.s * zs[z];    // cos(theta - ths)
-            const float sz = g.s * zc[z] - g.c * zs[z];    // sin(theta - ths)
-            const float x = fmaxf(1.0f + cz, 1e-30f);      // keeps 0 * -inf out of the zeta == 1 corner
-            const float lg = fast_log2(x);
-            const float Z = fast_exp2(zz[z] * lg);                         // (1+cos)^zeta
-            const float dZ = -zz[z] * fast_exp2((zz[z] - 1.0f) * lg) * sz;  // d/dtheta            ref :337
-            S0 += U[z] * Z;
-            Sr += V[z] * Z;
-            Sth += U[z] * dZ;
+        fx += __shfl_xor(fx, 32, 64); fy += __shfl_xor(fy, 32, 64); fz += __shfl_xor(fz, 32, 64);
+        if (half == 0 && e < n) { facc[e * 4] = fx; facc[e * 4 + 1] = fy; facc[e * 4 + 2] = fz; }
+        __syncthreads();
+    } else {
+        // ---------------- an atom larger than the pair matrix: tile pairs ----------------
+        const int nblk = (n + tile - 1) / tile;
+        for (int PB = 0; PB < nblk; PB++) {
+            for (int QB = PB; QB < nblk; QB++) {
+                const int p0 = PB * tile, q0 = QB * tile;
+                const int np = min(tile, n - p0), nq = min(tile, n - q0);
+                const bool diag = PB == QB;
+                const int Tt = diag ? (np * (np - 1)) / 2 : np * nq;
+                const int npass = diag ? 1 : 2;           // off-diagonal: forces on the p block, then on the q block
+                for (int pass = 0; pass < npass; pass++) {
+                    for (int t = lane; t < Tt; t += 64) {
+                        int pl, ql;
+                        if (diag) decode_pair(t, np, pl, ql);
+                        else { pl = t / nq; ql = t - pl * nq; }
+                        const int p = p0 + pl, q = q0 + ql;
+                        const float4 A2 = recB[p], B2 = recB[q];
+                        const int sa = __float_as_int(A2.w) >> kTagShift, sb = __float_as_int(B2.w) >> kTagShift;
+                        const int bucket = sa * S - (sa * (sa - 1)) / 2 + (sb - sa);      // sorted: sa <= sb, ref :39-43
+                        float Fp[3], Fq[3];
+                        triple_forces<TORCHANI, NFRP, NFZP>(recA[p], A2, recA[q], B2, grow + bucket * BLK, frc, frs, fre, zz,
+                                                            zc, zs, Fp, Fq);
+                        if (pass == 0) {
+                            Mx[pl * tstride + ql] = Fp[0]; My[pl * tstride + ql] = Fp[1]; Mz[pl * tstride + ql] = Fp[2];
+                        }
+                        if (diag || pass == 1) {
+                            Mx[ql * tstride + pl] = Fq[0]; My[ql * tstride + pl] = Fq[1]; Mz[ql * tstride + pl] = Fq[2];
+                        }
+                    }
+                    __syncthreads();
+                    const int e = lane & 31, half = lane >> 5;
+                    const int rows = (diag || pass == 0) ? np : nq;
+                    const int cols = diag ? np : (pass == 0 ? nq : np);
+                    float fx = 0.f, fy = 0.f, fz = 0.f;
+                    if (e < rows) {
+                        const int x0 = half * 16, x1 = min(cols, x0 + 16);
+                        for (int x = x0; x < x1; x++) {
+                            if (diag && x == e) continue;
+                            fx += Mx[e * tstride + x]; fy += My[e * tstride + x]; fz += Mz[e * tstride + x];
+                        }
+                    }
+                    fx += __shfl_xor(fx, 32, 64); fy += __shfl_xor(fy, 32, 64); fz += __shfl_xor(fz, 32, 64);
+                    if (half == 0 && e < rows) {
+                        const int slot = ((diag || pass == 0) ? p0 : q0) + e;
+                        facc[slot * 4] += fx; facc[slot * 4 + 1] += fy; facc[slot * 4 + 2] += fz;
+                    }
+                    __syncthreads();
+                }
+            }
         }
-        // three routes of the chain rule (ref :311-348), already summed over the functions m
-        const float t1 = A2.dfc * B2.fc * S0 + g.fcfc * Sr;   // through r_ij
-        const float t2 = A2.fc * B2.dfc * S0 + g.fcfc * Sr;   // through r_ik
-        const float t3 = g.fcfc * Sth;                        // through theta
-        // angle gradients (ref :410-433): dtheta/d(dot') = -damp / sin(theta)
-        const float dot = A.dx * B.dx + A.dy * B.dy + A.dz * B.dz;
-        const float iprod = A2.rinv * B2.rinv;
-        const float damp = TORCHANI ? 0.95f : 1.0f;
-        const float dadd = -damp * fast_rcp(g.s) * iprod * t3;
-        const float ka = dot * A2.rinv * A2.rinv, kb = dot * B2.rinv * B2.rinv;
-        const float s1 = t1 * A2.rinv, s2 = t2 * B2.rinv;
-        const float fjx = s1 * A.dx + dadd * (B.dx - ka * A.dx);
-        const float fjy = s1 * A.dy + dadd * (B.dy - ka * A.dy);
-        const float fjz = s1 * A.dz + dadd * (B.dz - ka * A.dz);
-        const float fkx = s2 * B.dx + dadd * (A.dx - kb * B.dx);
-        const float fky = s2 * B.dy + dadd * (A.dy - kb * B.dy);
-        const float fkz = s2 * B.dz + dadd * (A.dz - kb * B.dz);
-        atomicAdd(&facc[p * 4 + 0], fjx); atomicAdd(&facc[p * 4 + 1], fjy); atomicAdd(&facc[p * 4 + 2], fjz);
-        atomicAdd(&facc[q * 4 + 0], fkx); atomicAdd(&facc[q * 4 + 1], fky); atomicAdd(&facc[q * 4 + 2], fkz);
     }
-    __syncthreads();
     // scatter: +F on each leg atom, -(sum) on the centre
+    if (dbg & 4) return;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     for (int e = lane; e < n; e += 64) {
         const float fx = facc[e * 4], fy = facc[e * 4 + 1], fz = facc[e * 4 + 2];
-        const int j = L.rec_j[e];
+        const int j = __float_as_int(recB[e].w) & kIdMask;
         atomicAdd(&pos_grad[3 * j], fx); atomicAdd(&pos_grad[3 * j + 1], fy); atomicAdd(&pos_grad[3 * j + 2], fz);
         cx -= fx; cy -= fy; cz -= fz;
     }

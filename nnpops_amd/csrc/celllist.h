@@ -20,6 +20,9 @@
 
 namespace nnpops {
 
+constexpr int kTagShift = 24;                 // packed neighbour word: (tag << 24) | atom id
+constexpr int kIdMask = (1 << kTagShift) - 1;
+
 struct CellGrid {
     int nx, ny, nz, ncells;
     int periodic;
@@ -169,8 +172,8 @@ __global__ void fill_cells(int N, const CellGrid* __restrict__ grid, const int* 
 // same thread publishes {x,y,z,id} in cell order.
 __global__ void order_cells(int N, const float* __restrict__ pos, const CellGrid* __restrict__ grid,
                             const int* __restrict__ cell_start, const int* __restrict__ atom_cell,
-                            const int* __restrict__ unsorted_atom, int* __restrict__ sorted_atom,
-                            float4* __restrict__ sorted_pos) {
+                            const int* __restrict__ unsorted_atom, const int* __restrict__ tag,
+                            int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N || !grid->ok) return;
     const int c = atom_cell[i];
@@ -178,7 +181,9 @@ __global__ void order_cells(int N, const float* __restrict__ pos, const CellGrid
     int rank = 0;
     for (int a = lo; a < hi; a++) rank += unsorted_atom[a] < i;
     sorted_atom[lo + rank] = i;
-    sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(i));
+    // .w carries the atom id in its low 24 bits and an optional 8-bit tag (e.g. the species) above them
+    const int packed = i | (tag ? (tag[i] << kTagShift) : 0);
+    sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
 }
 
 // Iterate the candidate ranges of the 3x3x3 stencil around cell (cx,cy,cz).  For every (dy,dz)
