@@ -572,7 +572,7 @@ template <int NFRP, int NFZP>
 __host__ __device__ inline size_t ang_fwd_lds_bytes(int capA, int NB) {
     using L = FwdLayout<NFRP, NFZP>;
     size_t b = (size_t)capA * 2 * sizeof(float4);
-    b += (size_t)NB * L::BLK * sizeof(float);
+    b += (size_t)(NB + 1) * L::BLK * sizeof(float);       // + one dummy block that swallows masked-off stores
     b += (size_t)L::NSTREAM * L::SR * sizeof(float) + (size_t)64 * NFZP * sizeof(float) + 64 * sizeof(int);
     return b;
 }
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
     char* cursor = lds_raw;
     float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
-    float* row = (float*)cursor;          cursor += (size_t)NB * BLK * sizeof(float);
+    float* row = (float*)cursor;          cursor += (size_t)(NB + 1) * BLK * sizeof(float);
     float* facR = (float*)cursor;         cursor += (size_t)NSTREAM * SR * sizeof(float);
     float* facZ = (float*)cursor;         cursor += (size_t)64 * NFZP * sizeof(float);
     int* facB = (int*)cursor;
@@ -691,7 +691,31 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
             }
             if (stream == 0) row_add<NFZP>(row + b0 * BLK + a2 * NFZP, acc);
         } else {
+            // general path: pull the stream's whole chunk into registers first (one LDS wait), then find
+            // the runs with register compares only.  An interior run (neither first nor last of the
+            // chunk) is the ONLY contribution its bucket ever receives -- buckets are contiguous in the
+            // atom's triple order -- so it is stored, not accumulated.
             const int count = min(64, T - base);
+            int bk[CH];
+            float Rv[CH];
+            float Zv[CH][NFZP];
+#pragma unroll
+            for (int u = 0; u < CH; u += 4) {
+                const int4 b4 = *reinterpret_cast<const int4*>(facB + stream * CH + u);
+                bk[u] = b4.x; bk[u + 1] = b4.y; bk[u + 2] = b4.z; bk[u + 3] = b4.w;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                Rv[u] = srcR[u * NFRP];
+#pragma unroll
+                for (int z = 0; z < NFZP; z += 4) {
+                    const float4 z4 = *reinterpret_cast<const float4*>(facZ + (stream * CH + u) * NFZP + z);
+                    Zv[u][z] = z4.x; Zv[u][z + 1] = z4.y; Zv[u][z + 2] = z4.z; Zv[u][z + 3] = z4.w;
+                }
+            }
+            // Everything below is straight-line, select-based code: the streams diverge at almost every
+            // step for many-species systems, and exec-mask juggling was costing more than the arithmetic.
+            // Stores that must not happen go to a dummy block behind the row (bucket index NB).
             float acc[NFZP], head[NFZP];
 #pragma unroll
             for (int z = 0; z < NFZP; z++) { acc[z] = 0.f; head[z] = 0.f; }
@@ -699,62 +723,71 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
             bool first = true;
 #pragma unroll
             for (int u = 0; u < CH; u++) {
-                const int tl = stream * CH + u;
-                if (tl < count) {
-                    const int bkt = facB[tl];
-                    if (bkt != cur) {
-                        if (cur >= 0) {
-                            if (first) {
-                                hb = cur;
+                const bool valid = stream * CH + u < count;
+                const int bkt = valid ? bk[u] : cur;
+                const bool change = bkt != cur;
+                const bool closes = change && cur >= 0;          // a run ends here
+                const bool interior = closes && !first;
+                const bool is_head = closes && first;
+                float* dst = row + (interior ? cur : NB) * BLK + a2 * NFZP;
 #pragma unroll
-                                for (int z = 0; z < NFZP; z++) head[z] = acc[z];
-                                first = false;
-                            } else {
-                                row_add<NFZP>(row + cur * BLK + a2 * NFZP, acc);   // interior run: sole owner
-                            }
-                        }
+                for (int z = 0; z < NFZP; z += 4)
+                    *reinterpret_cast<float4*>(dst + z) = make_float4(acc[z], acc[z + 1], acc[z + 2], acc[z + 3]);
+                hb = is_head ? cur : hb;
+                first = first && !closes;
+                const float r = valid ? Rv[u] : 0.f;
 #pragma unroll
-                        for (int z = 0; z < NFZP; z++) acc[z] = 0.f;
-                        cur = bkt;
-                    }
-                    const float R = srcR[u * NFRP];
-                    const float* Z = facZ + tl * NFZP;
-#pragma unroll
-                    for (int z = 0; z < NFZP; z++) acc[z] += R * Z[z];
+                for (int z = 0; z < NFZP; z++) {
+                    head[z] = is_head ? acc[z] : head[z];
+                    acc[z] = (change ? 0.f : acc[z]) + r * Zv[u][z];
                 }
+                cur = bkt;
             }
-            int tb = -1;
-            if (cur >= 0) {
-                if (first) {
-                    hb = cur;
+            // after the chunk: the open run is the head if it is the only one, else the tail
+            const bool only = first;                               // chunk holds a single run (or nothing)
+            hb = (only && cur >= 0) ? cur : hb;
+            const int tb = (!only && cur >= 0) ? cur : -1;
 #pragma unroll
-                    for (int z = 0; z < NFZP; z++) head[z] = acc[z];
-                } else {
-                    tb = cur;
-                }
-            }
-            // edge runs.  A head can only be shared with the previous stream's last run, a tail only with
-            // the next stream's head (runs are contiguous), so two bucket-id shuffles tell which edge runs
-            // have a single owner: those are added in one step; the (rare) shared ones go stream by stream
-            // (LDS operations of a wave execute in order).
-            const int lastb = tb >= 0 ? tb : hb;
+            for (int z = 0; z < NFZP; z++) head[z] = only ? acc[z] : head[z];
+            // edge runs.  The head run of a chunk may continue the previous stream's last run, and the last
+            // run may continue into the next stream (runs are contiguous), possibly through several
+            // single-run streams.  Each stream hands OUT_s forward: its tail if it has one, else its head plus
+            // what it received -- a first-order recurrence OUT_s = a_s + c_s * OUT_{s-1} (c_s in {0,1}) that a
+            // log-step scan over the streams resolves with shuffles.  The piece of a run that ends it adds
+            // the run's total to the row; every run is therefore added exactly once, by one owner.
+            const bool has_tail = tb >= 0;
+            const int lastb = has_tail ? tb : hb;
             int prev_last = __shfl_up(lastb, NFRP, 64);
             int next_head = __shfl_down(hb, NFRP, 64);
-            if (stream == 0) prev_last = -2;
-            if (stream == NSTREAM - 1) next_head = -2;
-            const bool head_free = hb >= 0 && hb != prev_last && !(tb < 0 && hb == next_head);
-            const bool tail_free = tb >= 0 && tb != next_head;
-            if (head_free) row_add<NFZP>(row + hb * BLK + a2 * NFZP, head);
-            if (tail_free) row_add<NFZP>(row + tb * BLK + a2 * NFZP, acc);
-            const bool head_left = hb >= 0 && !head_free, tail_left = tb >= 0 && !tail_free;
-            if (__any(head_left || tail_left)) {
-                for (int s2 = 0; s2 < NSTREAM; s2++) {
-                    if (stream == s2) {
-                        if (head_left) row_add<NFZP>(row + hb * BLK + a2 * NFZP, head);
-                        if (tail_left) row_add<NFZP>(row + tb * BLK + a2 * NFZP, acc);
-                    }
+            prev_last = stream == 0 ? -2 : prev_last;
+            next_head = stream == NSTREAM - 1 ? -2 : next_head;
+            const bool link = hb >= 0 && hb == prev_last;           // my head continues the previous stream
+            float av[NFZP];
+#pragma unroll
+            for (int z = 0; z < NFZP; z++) av[z] = has_tail ? acc[z] : head[z];
+            int cv = (!has_tail && link) ? 1 : 0;
+#pragma unroll
+            for (int off = NFRP; off < 64; off <<= 1) {
+                const int cup = __shfl_up(cv, off, 64);
+                const bool take = lane >= off && cv != 0;
+#pragma unroll
+                for (int z = 0; z < NFZP; z++) {
+                    const float up = __shfl_up(av[z], off, 64);
+                    av[z] += take ? up : 0.f;
                 }
+                cv = (lane >= off) ? (cv & cup) : cv;
             }
+            // av is now OUT_s; what I receive is OUT_{s-1} when linked
+            float total[NFZP];
+#pragma unroll
+            for (int z = 0; z < NFZP; z++) {
+                const float in = __shfl_up(av[z], NFRP, 64);
+                total[z] = head[z] + (link ? in : 0.f);
+            }
+            const bool head_ends_here = hb >= 0 && (has_tail || next_head != hb);
+            const bool tail_ends_here = has_tail && next_head != tb;
+            row_add<NFZP>(row + (head_ends_here ? hb : NB) * BLK + a2 * NFZP, total);
+            row_add<NFZP>(row + (tail_ends_here ? tb : NB) * BLK + a2 * NFZP, acc);
         }
         __syncthreads();
     }
@@ -767,8 +800,19 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
         const bool live = m < nA;
         const int c = live ? P->c_of_m[m] : 0;             // canonical slot a*NFZP+z of function m
         const float sc = live ? P->scale_m[m] : 0.f;
-        for (int bk = half; bk < NB; bk += 2)
-            if (live) out[bk * nA + m] = row[bk * BLK + c] * sc;
+        for (int bk0 = half; bk0 < NB; bk0 += 16) {        // 8 LDS reads in flight, then 8 coalesced stores
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int bk = bk0 + 2 * k;
+                v[k] = (live && bk < NB) ? row[bk * BLK + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int bk = bk0 + 2 * k;
+                if (live && bk < NB) out[bk * nA + m] = v[k] * sc;
+            }
+        }
     } else {
         for (int bk = 0; bk < NB; bk++)
             for (int m = lane; m < nA; m += 64) out[bk * nA + m] = row[bk * BLK + P->c_of_m[m]] * P->scale_m[m];
