@@ -201,3 +201,55 @@ class AniSymmetryFunctions:
         if code not in (OK, ERR_CAPACITY):
             _check(code)
         return a.value, b.value
+
+
+# ---------------------------------------------------------------------------------------------
+# getNeighborPairs (reference src/pytorch/neighbors/getNeighborPairsCUDA.cu)
+# ---------------------------------------------------------------------------------------------
+_DTYPE_CODE = {torch.float32: 0, torch.float64: 1}
+
+
+def neighbor_pairs_forward(positions, cutoff, max_num_pairs=-1, box=None):
+    """-> (neighbors int32[2,P], deltas[P,3], distances[P], num_pairs int32[1]) on positions' device.
+
+    P = N(N-1)/2 when max_num_pairs == -1, else max_num_pairs.  No host synchronisation."""
+    if not positions.is_cuda:
+        raise ValueError('"positions" must live on the HIP device (nnpops_amd has no CPU path)')
+    if positions.dtype not in _DTYPE_CODE:
+        raise ValueError('"positions" must be float32 or float64')
+    if positions.dim() != 2 or positions.size(1) != 3 or not positions.is_contiguous():
+        raise ValueError('Expected "positions" to be a contiguous (num_atoms, 3) tensor')
+    n = positions.size(0)
+    max_num_pairs = int(max_num_pairs)
+    if not (max_num_pairs > 0 or max_num_pairs == -1):
+        raise ValueError('Expected "max_num_pairs" to be positive or equal to -1')
+    slots = n * (n - 1) // 2 if max_num_pairs == -1 else max_num_pairs
+    dev, dt = positions.device, positions.dtype
+    if box is not None and box.numel():
+        if tuple(box.shape) != (3, 3):
+            raise ValueError('Expected "box_vectors" to have shape (3, 3)')
+        box = box.to(device=dev, dtype=dt).contiguous()
+    else:
+        box = None
+    neighbors = torch.empty((2, slots), dtype=torch.int32, device=dev)
+    deltas = torch.empty((slots, 3), dtype=dt, device=dev)
+    distances = torch.empty((slots,), dtype=dt, device=dev)
+    num_pairs = torch.empty((1,), dtype=torch.int32, device=dev)
+    L = lib()
+    ws = torch.empty((int(L.nnpops_neighbor_pairs_workspace_bytes(n)),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(L.nnpops_neighbor_pairs_forward(_DTYPE_CODE[dt], n, _ptr(positions), _ptr(box), float(cutoff), max_num_pairs,
+                                               _ptr(neighbors), _ptr(deltas), _ptr(distances), _ptr(num_pairs), _ptr(ws),
+                                               _stream_ptr(dev)))
+    return neighbors, deltas, distances, num_pairs
+
+
+def neighbor_pairs_backward(num_atoms, neighbors, deltas, distances, grad_deltas, grad_distances):
+    dev, dt = deltas.device, deltas.dtype
+    grad_positions = torch.empty((num_atoms, 3), dtype=dt, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().nnpops_neighbor_pairs_backward(_DTYPE_CODE[dt], num_atoms, distances.numel(), _ptr(neighbors),
+                                                    _ptr(deltas.contiguous()), _ptr(distances.contiguous()),
+                                                    _ptr(grad_deltas.contiguous()), _ptr(grad_distances.contiguous()),
+                                                    _ptr(grad_positions), _stream_ptr(dev)))
+    return grad_positions

@@ -71,7 +71,7 @@ __host__ __device__ inline int triples_capacity(int capA) { return capA * (capA 
 // Largest row / angular count of the last neighbour build, reduced from the per-atom counts only when
 // the host asks (nnpops_ani_check).  Doing this with per-wave atomics inside the builders serialised
 // 10k waves on one L2 word (measured ~240 us), so the builders publish nothing but their counts.
-__global__ __launch_bounds__(256) void ani_row_stats(int N, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
+static __global__ __launch_bounds__(256) void ani_row_stats(int N, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
                                                      int cap, int cap_angular, int* __restrict__ status) {
     __shared__ int red[2][256];
     int mrow = 0, mang = 0;

@@ -48,7 +48,7 @@ __device__ __forceinline__ void cell_of(const CellGrid& g, float x, float y, flo
 }
 
 // One block of 256 threads.
-__global__ __launch_bounds__(256) void grid_setup(int N, const float* __restrict__ pos, const float* __restrict__ box,
+static __global__ __launch_bounds__(256) void grid_setup(int N, const float* __restrict__ pos, const float* __restrict__ box,
                                                   int periodic, float cutoff, int max_cells, CellGrid* __restrict__ grid,
                                                   int* __restrict__ cell_count) {
     __shared__ float red[6][256];
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void grid_setup(int N, const float* __restrict
     for (int c = tid; c < ncells; c += 256) cell_count[c] = 0;
 }
 
-__global__ void assign_cells(int N, const float* __restrict__ pos, const CellGrid* __restrict__ grid,
+static __global__ void assign_cells(int N, const float* __restrict__ pos, const CellGrid* __restrict__ grid,
                              int* __restrict__ cell_count, int* __restrict__ atom_cell, int* __restrict__ atom_rank) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -129,7 +129,7 @@ __global__ void assign_cells(int N, const float* __restrict__ pos, const CellGri
 }
 
 // Exclusive scan of cell_count[0..ncells) into cell_start[0..ncells]; one block of 1024 threads.
-__global__ __launch_bounds__(1024) void scan_cells(const CellGrid* __restrict__ grid, const int* __restrict__ cell_count,
+static __global__ __launch_bounds__(1024) void scan_cells(const CellGrid* __restrict__ grid, const int* __restrict__ cell_count,
                                                    int* __restrict__ cell_start) {
     __shared__ int wave_tot[16];
     __shared__ int carry;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(1024) void scan_cells(const CellGrid* __restrict__ 
     if (tid == 0) cell_start[ncells] = carry;
 }
 
-__global__ void fill_cells(int N, const CellGrid* __restrict__ grid, const int* __restrict__ cell_start,
+static __global__ void fill_cells(int N, const CellGrid* __restrict__ grid, const int* __restrict__ cell_start,
                            const int* __restrict__ atom_cell, const int* __restrict__ atom_rank,
                            int* __restrict__ sorted_atom) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,7 +170,7 @@ __global__ void fill_cells(int N, const CellGrid* __restrict__ grid, const int* 
 // One thread per atom: its final slot is the number of smaller atom ids in its cell segment (segments
 // hold ~10-30 atoms), which makes the cell order deterministic without a serial per-cell sort; the
 // same thread publishes {x,y,z,id} in cell order.
-__global__ void order_cells(int N, const float* __restrict__ pos, const CellGrid* __restrict__ grid,
+static __global__ void order_cells(int N, const float* __restrict__ pos, const CellGrid* __restrict__ grid,
                             const int* __restrict__ cell_start, const int* __restrict__ atom_cell,
                             const int* __restrict__ unsorted_atom, const int* __restrict__ tag,
                             int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos) {
