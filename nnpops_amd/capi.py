@@ -253,3 +253,107 @@ def neighbor_pairs_backward(num_atoms, neighbors, deltas, distances, grad_deltas
                                                     _ptr(grad_deltas.contiguous()), _ptr(grad_distances.contiguous()),
                                                     _ptr(grad_positions), _stream_ptr(dev)))
     return grad_positions
+
+
+# ---------------------------------------------------------------------------------------------
+# SchNet CFConv (reference src/schnet/CFConv.h)
+# ---------------------------------------------------------------------------------------------
+class CFConvNeighbors:
+    """Neighbour list of the continuous-filter convolution (reference CFConvNeighbors, CFConv.h:37-85)."""
+
+    def __init__(self, num_atoms, cutoff, periodic=False, device=0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        self.num_atoms, self.cutoff, self.periodic = int(num_atoms), float(cutoff), bool(periodic)
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        _check(self._lib.nnpops_cfconv_neighbors_create(C.byref(self._h), self.num_atoms, self.cutoff, int(self.periodic),
+                                                        self.device.index))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.nnpops_cfconv_neighbors_destroy(h)
+            self._h = None
+
+    def build(self, positions, box=None, check=True):
+        _dev_f32(positions, "positions", (self.num_atoms, 3))
+        if self.periodic:
+            if box is None:
+                raise ValueError("periodic neighbour list needs box vectors")
+            _dev_f32(box, "box", (3, 3))
+        _check(self._lib.nnpops_cfconv_neighbors_set_stream(self._h, _stream_ptr(positions.device)))
+        for _ in range(8):
+            _check(self._lib.nnpops_cfconv_neighbors_build(self._h, _ptr(positions), _ptr(box if self.periodic else None)))
+            if not check:
+                return
+            code = self._lib.nnpops_cfconv_neighbors_check(self._h, None)
+            if code == OK:
+                return
+            if code != ERR_CAPACITY:
+                _check(code)
+        raise NNPOpsHipError(ERR_CAPACITY, "neighbour buffers kept overflowing")
+
+    def num_pairs(self):
+        n = C.c_int(0)
+        _check(self._lib.nnpops_cfconv_neighbors_check(self._h, C.byref(n)))
+        return n.value
+
+    def export(self):
+        """-> (pair_atoms int32[2,P], distances f32[P]) of the half list {(i, j>i)}, i ascending, j ascending (host arrays)."""
+        P = self.num_pairs()
+        cap = max(P, 1)
+        atoms = np.empty((2, cap), np.int32)
+        dist = np.empty((cap,), np.float32)
+        _check(self._lib.nnpops_cfconv_neighbors_export(self._h, cap, atoms.ctypes.data_as(C.c_void_p),
+                                                        dist.ctypes.data_as(C.c_void_p)))
+        return atoms[:, :P], dist[:P]
+
+
+class CFConv:
+    """Continuous-filter convolution (reference CFConv, CFConv.h:109-217).  ``w1`` is the core-level
+    [width][num_gaussians] array, ``w2`` is [out][in]."""
+
+    def __init__(self, num_atoms, width, num_gaussians, cutoff, gaussian_width, activation, w1, b1, w2, b2,
+                 periodic=False, device=0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        act = {"ssp": 0, "tanh": 1, 0: 0, 1: 1}.get(activation)
+        if act is None:
+            raise ValueError('Invalid value of "activation"')
+        self.num_atoms, self.width, self.num_gaussians = int(num_atoms), int(width), int(num_gaussians)
+        w1 = np.ascontiguousarray(w1, np.float32).reshape(-1)
+        w2 = np.ascontiguousarray(w2, np.float32).reshape(-1)
+        b1 = np.ascontiguousarray(b1, np.float32).reshape(-1)
+        b2 = np.ascontiguousarray(b2, np.float32).reshape(-1)
+        assert w1.size == width * num_gaussians and w2.size == width * width and b1.size == width and b2.size == width
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        _check(self._lib.nnpops_cfconv_create(C.byref(self._h), self.num_atoms, self.width, self.num_gaussians, cutoff,
+                                              int(bool(periodic)), gaussian_width, act, w1.ctypes.data_as(C.c_void_p),
+                                              b1.ctypes.data_as(C.c_void_p), w2.ctypes.data_as(C.c_void_p),
+                                              b2.ctypes.data_as(C.c_void_p), self.device.index))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.nnpops_cfconv_destroy(h)
+            self._h = None
+
+    def compute(self, neighbors, positions, x, box=None, out=None):
+        _dev_f32(positions, "positions", (self.num_atoms, 3))
+        _dev_f32(x, "input", (self.num_atoms, self.width))
+        if out is None:
+            out = torch.empty_like(x)
+        _check(self._lib.nnpops_cfconv_set_stream(self._h, _stream_ptr(x.device)))
+        _check(self._lib.nnpops_cfconv_compute(self._h, neighbors._h, _ptr(positions), _ptr(box), _ptr(x), _ptr(out)))
+        return out
+
+    def backprop(self, neighbors, positions, x, out_grad, box=None):
+        _dev_f32(positions, "positions", (self.num_atoms, 3))
+        _dev_f32(x, "input", (self.num_atoms, self.width))
+        _dev_f32(out_grad, "output_grad", (self.num_atoms, self.width))
+        x_grad = torch.empty_like(x)
+        pos_grad = torch.empty((self.num_atoms, 3), dtype=torch.float32, device=x.device)
+        _check(self._lib.nnpops_cfconv_set_stream(self._h, _stream_ptr(x.device)))
+        _check(self._lib.nnpops_cfconv_backprop(self._h, neighbors._h, _ptr(positions), _ptr(box), _ptr(x), _ptr(out_grad),
+                                                _ptr(x_grad), _ptr(pos_grad)))
+        return x_grad, pos_grad

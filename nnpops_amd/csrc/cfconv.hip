@@ -1,17 +1,668 @@
-// cfconv.hip -- placeholder until the CFConv kernels land (same round); every entry point fails loudly.
+// cfconv.hip -- SchNet continuous-filter convolution on gfx950 (C ABI: nnpops_cfconv_*).
+//
+// What is computed (reference src/schnet/CpuCFConv.cpp, maths in SURVEY.md App. A): for every pair
+// (i, j) with r_ij < c
+//     gamma_g = exp(-((r - mu_g)/sigma)^2 / 2),  mu_g = g*c/(G-1)                           ref :121-122, :151-154
+//     y1 = act(W1 gamma + b1)      act = log((e^x + 1)/2)  or  tanh                          ref :158-166
+//     y2 = fc(r) * (W2 y1 + b2)    fc = (cos(pi r/c) + 1)/2                                  ref :170-176
+//     out[i] += y2 . x[j] ,  out[j] += y2 . x[i]           (elementwise over the W filters)  ref :180-183
+// and the analytic derivatives with respect to x and to the positions                        ref :190-299
+//
+// How it is laid out for CDNA4 (new design; the reference CUDA code runs one warp per half pair and
+// scatters 2W float atomics per pair):
+//   * OWNER COMPUTES over a FULL neighbour list: atom i walks all its neighbours j and accumulates
+//     out[i] (and, backward, dE/dx[i] and dE/dpos[i]) in registers -- no atomics, no scatter,
+//     deterministic.  Every pair is therefore evaluated from both ends; the filter network is the
+//     same function of r on either side, so this doubles its flops in exchange for removing
+//     2W atomics per pair and all cross-wave traffic.  (An MFMA pair-tile version with a half list is
+//     the planned next step; see DESIGN.md.)
+//   * one wave per atom, lane = filter channel(s) (W <= 128: up to two per lane); 8 waves per
+//     workgroup share the transposed weight matrices in LDS (W2^T is 64 KB at W = 128), loaded once
+//     per persistent workgroup.
+//   * pairs are processed 8 at a time: every weight read from LDS feeds 8 (x2 channels) FMAs, which
+//     moves the kernel from LDS-bound to VALU-bound.
+//   * the neighbour list (rows of {dx, dy, dz, j}) comes from the shared cell grid (celllist.h), or
+//     from an all-pairs scan for small systems.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "celllist.h"
 #include "host_common.h"
+
 using namespace nnpops;
-#define NOT_YET return fail(NNPOPS_ERR_UNSUPPORTED, "%s: not built yet", __func__)
-extern "C" {
-int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t*, int, float, int, int) { NOT_YET; }
-int nnpops_cfconv_neighbors_destroy(nnpops_cfconv_neighbors_t) { NOT_YET; }
-int nnpops_cfconv_neighbors_set_stream(nnpops_cfconv_neighbors_t, void*) { NOT_YET; }
-int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t, const float*, const float*) { NOT_YET; }
-int nnpops_cfconv_neighbors_check(nnpops_cfconv_neighbors_t, int*) { NOT_YET; }
-int nnpops_cfconv_neighbors_export(nnpops_cfconv_neighbors_t, int, int32_t*, float*) { NOT_YET; }
-int nnpops_cfconv_create(nnpops_cfconv_t*, int, int, int, float, int, float, int, const float*, const float*, const float*, const float*, int) { NOT_YET; }
-int nnpops_cfconv_destroy(nnpops_cfconv_t) { NOT_YET; }
-int nnpops_cfconv_set_stream(nnpops_cfconv_t, void*) { NOT_YET; }
-int nnpops_cfconv_compute(nnpops_cfconv_t, nnpops_cfconv_neighbors_t, const float*, const float*, const float*, float*) { NOT_YET; }
-int nnpops_cfconv_backprop(nnpops_cfconv_t, nnpops_cfconv_neighbors_t, const float*, const float*, const float*, const float*, float*, float*) { NOT_YET; }
+
+namespace {
+
+constexpr int kPairTile = 8;
+constexpr int kMaxWavesPerBlock = 8;
+constexpr int kMaxWidth = 128;
+constexpr int kMaxGauss = 128;
+enum { kStOverflow = 0, kStMaxRow = 1, kStPairs = 2, kStWordsN = 4 };
+
+// ---------------------------------------------------------------------------------------------
+// neighbour rows (full list): one wave per atom
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void append(float4* __restrict__ row, int cap, bool keep, float dx, float dy, float dz, int j,
+                                       int& n) {
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+        const int slot = n + prefix_popc(m);
+        if (slot < cap) row[slot] = make_float4(dx, dy, dz, __int_as_float(j));
+    }
+    n += __popcll(m);
 }
+
+template <bool PERIODIC>
+__global__ __launch_bounds__(64) void rows_allpairs(int N, const float* __restrict__ pos, const float* __restrict__ box,
+                                                    float cutoff2, float4* __restrict__ rows, int cap,
+                                                    int* __restrict__ cnt) {
+    const int i = blockIdx.x, lane = lane_id();
+    Box b{};
+    if (PERIODIC) b = load_box(box);
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    float4* row = rows + (size_t)i * cap;
+    int n = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int j = base + lane;
+        bool keep = false;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (j < N && j != i) {
+            dx = pos[3 * j] - xi; dy = pos[3 * j + 1] - yi; dz = pos[3 * j + 2] - zi;
+            min_image<PERIODIC>(dx, dy, dz, b);
+            keep = dx * dx + dy * dy + dz * dz < cutoff2;          // strict, on r^2 (ref :110)
+        }
+        append(row, cap, keep, dx, dy, dz, j, n);
+    }
+    if (lane == 0) cnt[i] = n;
+}
+
+template <bool PERIODIC>
+__global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, float cutoff2,
+                                                 const CellGrid* __restrict__ grid, const int* __restrict__ cell_start,
+                                                 const int* __restrict__ atom_cell, const float4* __restrict__ sorted_pos,
+                                                 float4* __restrict__ rows, int cap, int* __restrict__ cnt,
+                                                 int* __restrict__ status) {
+    const int lane = lane_id();
+    const CellGrid g = *grid;
+    if (!g.ok) {
+        if (lane == 0) {
+            if (blockIdx.x == 0) atomicOr(&status[kStOverflow], 2);
+            cnt[blockIdx.x] = 0;
+        }
+        return;
+    }
+    Box b{};
+    if (PERIODIC) b = load_box(box);
+    const float4 me = sorted_pos[blockIdx.x];
+    const int i = __float_as_int(me.w) & kIdMask;
+    const int c = atom_cell[i];
+    const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+    float4* row = rows + (size_t)i * cap;
+    int n = 0;
+    for_each_stencil_range(g, cell_start, cx, cy, cz, [&](int begin, int end) {
+        for (int base = begin; base < end; base += 64) {
+            const int k = base + lane;
+            bool keep = false;
+            int j = -1;
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (k < end) {
+                const float4 pj = sorted_pos[k];
+                j = __float_as_int(pj.w) & kIdMask;
+                if (j != i) {
+                    dx = pj.x - me.x; dy = pj.y - me.y; dz = pj.z - me.z;
+                    min_image<PERIODIC>(dx, dy, dz, b);
+                    keep = dx * dx + dy * dy + dz * dz < cutoff2;
+                }
+            }
+            append(row, cap, keep, dx, dy, dz, j, n);
+        }
+    });
+    if (lane == 0) cnt[i] = n;
+}
+
+// max row length and number of half pairs (j > i) of the last build
+__global__ __launch_bounds__(256) void row_stats(int N, const int* __restrict__ cnt, const float4* __restrict__ rows, int cap,
+                                                 int* __restrict__ status) {
+    __shared__ int red[2][256];
+    int mrow = 0, half = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const int n = cnt[i];
+        mrow = max(mrow, n);
+        const int m = min(n, cap);
+        for (int e = 0; e < m; e++) half += (__float_as_int(rows[(size_t)i * cap + e].w) & kIdMask) > i;
+    }
+    red[0][threadIdx.x] = mrow;
+    red[1][threadIdx.x] = half;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] = max(red[0][threadIdx.x], red[0][threadIdx.x + off]);
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(&status[kStMaxRow], red[0][0]);
+        atomicAdd(&status[kStPairs], red[1][0]);
+        if (red[0][0] > cap) atomicOr(&status[kStOverflow], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the convolution
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+    int N, W, G;
+    float cutoff, sigma_inv;
+    int activation;          // 0 shifted softplus, 1 tanh
+};
+
+template <int ACT>
+__device__ __forceinline__ float activate(float s) {
+    if (ACT == 0) return logf(0.5f * expf(s) + 0.5f);      // ref :163
+    return tanhf(s);
+}
+// activation and its derivative in one go
+template <int ACT>
+__device__ __forceinline__ void activate_d(float s, float& y, float& dy) {
+    if (ACT == 0) {
+        const float e = expf(s);
+        y = logf(0.5f * e + 0.5f);
+        dy = e / (e + 1.0f);                               // ref :254-257
+    } else {
+        const float th = tanhf(s);
+        y = th;
+        dy = 1.0f - th * th;                               // ref :259-262
+    }
+}
+
+// LDS: W2^T [W][W] | W1^T [G][W] | per wave: gam[G][8], y1[W][8], pair scalars [8][8] (+ dgam, dy1 backward)
+__host__ __device__ inline size_t conv_weight_floats(int W, int G) {
+    return ((size_t)W * W + (size_t)G * W + 3) & ~(size_t)3;          // keeps the per-wave slices 16-byte aligned
+}
+__host__ __device__ inline size_t conv_wave_floats(int W, int G, bool backward) {
+    return (size_t)(backward ? 2 : 1) * ((size_t)G * kPairTile + (size_t)W * kPairTile) + 64;
+}
+
+// CPL = channels per lane (1: W <= 64, 2: W <= 128).  BACKWARD adds the d/dr path and the two gradients.
+template <int ACT, int CPL, bool BACKWARD>
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_kernel(
+    ConvParams P, const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
+    const float* __restrict__ b2, const float4* __restrict__ rows, const int* __restrict__ cnt, int cap,
+    const float* __restrict__ x, const float* __restrict__ gout,   // gout: upstream gradient (backward only)
+    float* __restrict__ out,                                       // forward: output ; backward: input gradient
+    float* __restrict__ pos_grad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int W = P.W, G = P.G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* s_w2t = lds;                                   // [W][W]   s_w2t[b*W + a] = w2[a][b]
+    float* s_w1t = s_w2t + (size_t)W * W;                 // [G][W]   s_w1t[g*W + a] = w1[a][g]
+    const int waves_per_block = blockDim.x >> 6;
+    float* wv = lds + conv_weight_floats(W, G) + (size_t)wave * conv_wave_floats(W, G, BACKWARD);
+    float* ps = wv;                                       // [8][8] per-pair scalars: r, fc, dfc, j, 1/r, dx, dy, dz
+    float* gam = ps + 64;                                 // [G][8]
+    float* y1b = gam + (size_t)G * kPairTile;             // [W][8]
+    float* dgam = y1b + (size_t)W * kPairTile;            // [G][8]  (backward only)
+    float* dy1b = dgam + (size_t)G * kPairTile;           // [W][8]  (backward only)
+
+    for (int q = tid; q < W * W; q += blockDim.x) s_w2t[q] = w2t[q];
+    for (int q = tid; q < G * W; q += blockDim.x) s_w1t[q] = w1t[q];
+    __syncthreads();
+
+    int ch[CPL];
+    bool live[CPL];
+    float bias1[CPL], bias2[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        ch[c] = lane + 64 * c;
+        live[c] = ch[c] < W;
+        if (!live[c]) ch[c] = 0;
+        bias1[c] = b1[ch[c]];
+        bias2[c] = b2[ch[c]];
+    }
+    const float mu_step = P.cutoff / (float)(G - 1);       // ref :121-122
+
+    for (int i = blockIdx.x * waves_per_block + wave; i < P.N; i += gridDim.x * waves_per_block) {
+        const int n = min(cnt[i], cap);
+        const float4* row = rows + (size_t)i * cap;
+        float acc[CPL];
+        float xi[CPL], gi[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            acc[c] = 0.f;
+            xi[c] = BACKWARD ? x[(size_t)i * W + ch[c]] : 0.f;
+            gi[c] = BACKWARD ? gout[(size_t)i * W + ch[c]] : 0.f;
+        }
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        for (int t0 = 0; t0 < n; t0 += kPairTile) {
+            const int np = min(kPairTile, n - t0);
+            // ---- per-pair scalars (lanes 0..7) ----
+            float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < np) rec = row[t0 + lane];
+            if (lane < kPairTile) {
+                const float r = lane < np ? sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z) : 1.0f;
+                float sn, cs;
+                sincospif(r / P.cutoff, &sn, &cs);
+                ps[0 * 8 + lane] = r;
+                ps[1 * 8 + lane] = lane < np ? 0.5f * cs + 0.5f : 0.f;                       // fc   (ref :301-303)
+                ps[2 * 8 + lane] = lane < np ? -(0.5f * kPi / P.cutoff) * sn : 0.f;           // dfc  (ref :305-307)
+                ps[3 * 8 + lane] = __int_as_float(lane < np ? (__float_as_int(rec.w) & kIdMask) : i);
+                ps[4 * 8 + lane] = 1.0f / r;
+                ps[5 * 8 + lane] = rec.x; ps[6 * 8 + lane] = rec.y; ps[7 * 8 + lane] = rec.z;
+            }
+            __builtin_amdgcn_wave_barrier();          // per-wave LDS slice: LDS ops of one wave execute in order
+            // ---- Gaussians for the 8 pairs ----
+            for (int q = lane; q < G * kPairTile; q += 64) {
+                const int g = q >> 3, p = q & 7;
+                const float xg = (ps[p] - (float)g * mu_step) * P.sigma_inv;
+                const float gm = expf(-0.5f * xg * xg);                                       // ref :152-153
+                gam[q] = gm;
+                if (BACKWARD) dgam[q] = -xg * gm * P.sigma_inv;                                // ref :242
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- dense 1 + activation ----
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                float s[kPairTile], ds[kPairTile];
+#pragma unroll
+                for (int p = 0; p < kPairTile; p++) { s[p] = bias1[c]; ds[p] = 0.f; }
+                for (int g = 0; g < G; g++) {
+                    const float w = s_w1t[g * W + ch[c]];
+                    const float4 ga = *reinterpret_cast<const float4*>(gam + g * 8), gb = *reinterpret_cast<const float4*>(gam + g * 8 + 4);
+                    s[0] += ga.x * w; s[1] += ga.y * w; s[2] += ga.z * w; s[3] += ga.w * w;
+                    s[4] += gb.x * w; s[5] += gb.y * w; s[6] += gb.z * w; s[7] += gb.w * w;
+                    if (BACKWARD) {
+                        const float4 da = *reinterpret_cast<const float4*>(dgam + g * 8), db = *reinterpret_cast<const float4*>(dgam + g * 8 + 4);
+                        ds[0] += da.x * w; ds[1] += da.y * w; ds[2] += da.z * w; ds[3] += da.w * w;
+                        ds[4] += db.x * w; ds[5] += db.y * w; ds[6] += db.z * w; ds[7] += db.w * w;
+                    }
+                }
+                float yv[kPairTile], dyv[kPairTile];
+#pragma unroll
+                for (int p = 0; p < kPairTile; p++) {
+                    if (BACKWARD) {
+                        float dact;
+                        activate_d<ACT>(s[p], yv[p], dact);
+                        dyv[p] = ds[p] * dact;
+                    } else {
+                        yv[p] = activate<ACT>(s[p]);
+                    }
+                }
+                if (live[c]) {
+                    *reinterpret_cast<float4*>(y1b + ch[c] * 8) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                    *reinterpret_cast<float4*>(y1b + ch[c] * 8 + 4) = make_float4(yv[4], yv[5], yv[6], yv[7]);
+                    if (BACKWARD) {
+                        *reinterpret_cast<float4*>(dy1b + ch[c] * 8) = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
+                        *reinterpret_cast<float4*>(dy1b + ch[c] * 8 + 4) = make_float4(dyv[4], dyv[5], dyv[6], dyv[7]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- dense 2, cutoff, accumulate ----
+            float scale_p[kPairTile];
+#pragma unroll
+            for (int p = 0; p < kPairTile; p++) scale_p[p] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                float s[kPairTile], ds[kPairTile];
+#pragma unroll
+                for (int p = 0; p < kPairTile; p++) { s[p] = bias2[c]; ds[p] = 0.f; }
+                for (int b = 0; b < W; b++) {
+                    const float w = s_w2t[b * W + ch[c]];
+                    const float4 ya = *reinterpret_cast<const float4*>(y1b + b * 8), yb = *reinterpret_cast<const float4*>(y1b + b * 8 + 4);
+                    s[0] += ya.x * w; s[1] += ya.y * w; s[2] += ya.z * w; s[3] += ya.w * w;
+                    s[4] += yb.x * w; s[5] += yb.y * w; s[6] += yb.z * w; s[7] += yb.w * w;
+                    if (BACKWARD) {
+                        const float4 da = *reinterpret_cast<const float4*>(dy1b + b * 8), db = *reinterpret_cast<const float4*>(dy1b + b * 8 + 4);
+                        ds[0] += da.x * w; ds[1] += da.y * w; ds[2] += da.z * w; ds[3] += da.w * w;
+                        ds[4] += db.x * w; ds[5] += db.y * w; ds[6] += db.z * w; ds[7] += db.w * w;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < kPairTile; p++) {
+                    const float fc = ps[1 * 8 + p];
+                    const int j = __float_as_int(ps[3 * 8 + p]);
+                    const float y2 = fc * s[p];                                               // ref :175 / :275
+                    if (!BACKWARD) {
+                        const float xj = live[c] ? x[(size_t)j * W + ch[c]] : 0.f;
+                        acc[c] += y2 * xj;                                                    // ref :181
+                    } else {
+                        const float gj = live[c] ? gout[(size_t)j * W + ch[c]] : 0.f;
+                        const float xj = live[c] ? x[(size_t)j * W + ch[c]] : 0.f;
+                        acc[c] += y2 * gj;                                                    // ref :284
+                        const float dy2 = ps[2 * 8 + p] * s[p] + fc * ds[p];                   // ref :276
+                        scale_p[p] += live[c] ? dy2 * (xj * gi[c] + xi[c] * gj) : 0.f;         // ref :286
+                    }
+                }
+            }
+            if (BACKWARD) {
+#pragma unroll
+                for (int p = 0; p < kPairTile; p++) {
+                    const float sc = wave_sum(scale_p[p]) * ps[4 * 8 + p];                    // * 1/r
+                    // position_deriv[i] -= sc * delta  (owner side of ref :287-291; delta = pos_j - pos_i)
+                    fx -= sc * ps[5 * 8 + p]; fy -= sc * ps[6 * 8 + p]; fz -= sc * ps[7 * 8 + p];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+            if (live[c]) out[(size_t)i * W + ch[c]] = acc[c];
+        if (BACKWARD && lane == 0) {
+            pos_grad[3 * i] = fx; pos_grad[3 * i + 1] = fy; pos_grad[3 * i + 2] = fz;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct nnpops_cfconv_neighbors {
+    int N = 0;
+    float cutoff = 0;
+    bool periodic = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cap = 64;
+    bool cells_disabled = false;
+    bool built = false;
+    float4* d_rows = nullptr;
+    int* d_cnt = nullptr;
+    int* d_status = nullptr;
+    float* d_pos = nullptr;
+    float* d_box = nullptr;
+    // cell grid
+    CellGrid* d_grid = nullptr;
+    int *d_cell_count = nullptr, *d_cell_start = nullptr, *d_atom_cell = nullptr, *d_atom_rank = nullptr;
+    int *d_unsorted = nullptr, *d_sorted = nullptr;
+    float4* d_sorted_pos = nullptr;
+    int max_cells = 0;
+};
+
+struct nnpops_cfconv {
+    ConvParams p{};
+    bool periodic = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float *d_w1t = nullptr, *d_b1 = nullptr, *d_w2t = nullptr, *d_b2 = nullptr;
+    int blocks = 256;
+};
+
+extern "C" {
+
+int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t* out, int num_atoms, float cutoff, int periodic, int device) {
+    NNPOPS_REQUIRE(out != nullptr, "out handle pointer is NULL");
+    *out = nullptr;
+    NNPOPS_REQUIRE(num_atoms > 0 && num_atoms <= kIdMask, "num_atoms must be in [1, %d]", kIdMask);
+    NNPOPS_REQUIRE(cutoff > 0, "cutoff must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(NNPOPS_ERR_NO_DEVICE, "no HIP device available");
+    NNPOPS_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    auto* h = new nnpops_cfconv_neighbors();
+    h->N = num_atoms; h->cutoff = cutoff; h->periodic = periodic != 0; h->device = device;
+    h->max_cells = num_atoms + 4096;
+    DeviceGuard guard(device);
+    int rc;
+    auto cleanup = [&](int code) { nnpops_cfconv_neighbors_destroy(h); return code; };
+    if ((rc = dev_alloc(&h->d_rows, (size_t)num_atoms * h->cap))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cnt, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_status, (size_t)kStWordsN))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_pos, (size_t)num_atoms * 3))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_box, 9))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_grid, 1))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cell_count, (size_t)h->max_cells))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cell_start, (size_t)h->max_cells + 1))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_atom_cell, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_atom_rank, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_unsorted, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_sorted, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
+    if (hipMemset(h->d_cnt, 0, sizeof(int) * num_atoms) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int) * kStWordsN) != hipSuccess)
+        return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
+    *out = h;
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_neighbors_destroy(nnpops_cfconv_neighbors_t h) {
+    if (!h) return NNPOPS_OK;
+    DeviceGuard guard(h->device);
+    dev_free(h->d_rows); dev_free(h->d_cnt); dev_free(h->d_status); dev_free(h->d_pos); dev_free(h->d_box);
+    dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
+    dev_free(h->d_atom_rank); dev_free(h->d_unsorted); dev_free(h->d_sorted); dev_free(h->d_sorted_pos);
+    delete h;
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_neighbors_set_stream(nnpops_cfconv_neighbors_t h, void* stream) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    h->stream = (hipStream_t)stream;
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t h, const float* positions, const float* box) {
+    NNPOPS_REQUIRE(h != nullptr && positions != nullptr, "NULL argument");
+    NNPOPS_REQUIRE(!h->periodic || box, "periodic neighbour list needs box vectors");
+    DeviceGuard guard(h->device);
+    const int N = h->N;
+    const bool per = h->periodic;
+    const float c2 = h->cutoff * h->cutoff;
+    NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_pos, positions, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, h->stream));
+    if (per) NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_box, box, sizeof(float) * 9, hipMemcpyDeviceToDevice, h->stream));
+    NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStWordsN, h->stream));
+    const bool use_cells = N >= 1024 && !h->cells_disabled;
+    if (use_cells) {
+        const int tb = 256;
+        hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, h->stream, N, h->d_pos, h->d_box, (int)per, h->cutoff, h->max_cells,
+                           h->d_grid, h->d_cell_count);
+        hipLaunchKernelGGL(assign_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid, h->d_cell_count,
+                           h->d_atom_cell, h->d_atom_rank);
+        hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, h->stream, h->d_grid, h->d_cell_count, h->d_cell_start);
+        hipLaunchKernelGGL(fill_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_grid, h->d_cell_start, h->d_atom_cell,
+                           h->d_atom_rank, h->d_unsorted);
+        hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid, h->d_cell_start,
+                           h->d_atom_cell, h->d_unsorted, (const int*)nullptr, h->d_sorted, h->d_sorted_pos);
+        if (per)
+            hipLaunchKernelGGL(rows_cells<true>, dim3(N), dim3(64), 0, h->stream, h->d_box, c2, h->d_grid, h->d_cell_start,
+                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status);
+        else
+            hipLaunchKernelGGL(rows_cells<false>, dim3(N), dim3(64), 0, h->stream, h->d_box, c2, h->d_grid, h->d_cell_start,
+                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status);
+    } else if (per) {
+        hipLaunchKernelGGL(rows_allpairs<true>, dim3(N), dim3(64), 0, h->stream, N, h->d_pos, h->d_box, c2, h->d_rows, h->cap, h->d_cnt);
+    } else {
+        hipLaunchKernelGGL(rows_allpairs<false>, dim3(N), dim3(64), 0, h->stream, N, h->d_pos, h->d_box, c2, h->d_rows, h->cap, h->d_cnt);
+    }
+    NNPOPS_HIP_TRY(hipGetLastError());
+    h->built = true;
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_neighbors_check(nnpops_cfconv_neighbors_t h, int* num_pairs) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    DeviceGuard guard(h->device);
+    int st[kStWordsN] = {0, 0, 0, 0};
+    // the statistics are recomputed on every call; the overflow word keeps the builder's "grid unusable" bit
+    NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status + kStMaxRow, 0, 2 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(row_stats, dim3(std::min(64, div_up(h->N, 256))), dim3(256), 0, h->stream, h->N, h->d_cnt, h->d_rows,
+                       h->cap, h->d_status);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (num_pairs) *num_pairs = st[kStPairs];
+    if (st[kStOverflow] & 2) {
+        h->cells_disabled = true;
+        h->built = false;
+        return fail(NNPOPS_ERR_CAPACITY, "periodic box is fewer than 3 cells wide on some axis: switched to the all-pairs "
+                                         "neighbour search, call build() again");
+    }
+    if (st[kStOverflow]) {
+        const int old = h->cap;
+        while (h->cap < st[kStMaxRow]) h->cap *= 2;
+        dev_free(h->d_rows);
+        int rc = dev_alloc(&h->d_rows, (size_t)h->N * h->cap);
+        if (rc != NNPOPS_OK) return rc;
+        h->built = false;
+        return fail(NNPOPS_ERR_CAPACITY, "neighbour rows overflowed (max %d > %d); capacity grown to %d, call build() again",
+                    st[kStMaxRow], old, h->cap);
+    }
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_neighbors_export(nnpops_cfconv_neighbors_t h, int capacity, int32_t* pair_atoms, float* distances) {
+    NNPOPS_REQUIRE(h != nullptr && pair_atoms && distances, "NULL argument");
+    NNPOPS_REQUIRE(h->built, "export() must follow build()");
+    DeviceGuard guard(h->device);
+    std::vector<float4> rows((size_t)h->N * h->cap);
+    std::vector<int> cnt(h->N);
+    NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+    NNPOPS_HIP_TRY(hipMemcpy(rows.data(), h->d_rows, rows.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    NNPOPS_HIP_TRY(hipMemcpy(cnt.data(), h->d_cnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int p = 0;
+    for (int i = 0; i < h->N; i++) {
+        std::vector<std::pair<int, float>> half;
+        for (int e = 0; e < std::min(cnt[i], h->cap); e++) {
+            const float4 r = rows[(size_t)i * h->cap + e];
+            int j;
+            std::memcpy(&j, &r.w, sizeof(int));
+            j &= kIdMask;
+            if (j > i) half.push_back({j, std::sqrt(r.x * r.x + r.y * r.y + r.z * r.z)});
+        }
+        std::sort(half.begin(), half.end());
+        for (auto& e : half) {
+            if (p >= capacity) return fail(NNPOPS_ERR_CAPACITY, "export capacity %d too small", capacity);
+            pair_atoms[p] = i;
+            pair_atoms[capacity + p] = e.first;
+            distances[p] = e.second;
+            p++;
+        }
+    }
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num_gaussians, float cutoff, int periodic,
+                         float gaussian_width, int activation, const float* w1, const float* b1, const float* w2,
+                         const float* b2, int device) {
+    NNPOPS_REQUIRE(out != nullptr, "out handle pointer is NULL");
+    *out = nullptr;
+    NNPOPS_REQUIRE(num_atoms > 0, "num_atoms must be positive");
+    NNPOPS_REQUIRE(w1 && b1 && w2 && b2, "NULL weight pointer");
+    NNPOPS_REQUIRE(activation == 0 || activation == 1, "Invalid value of \"activation\"");
+    NNPOPS_REQUIRE(cutoff > 0 && gaussian_width > 0, "cutoff and gaussian_width must be positive");
+    NNPOPS_REQUIRE(num_gaussians >= 2, "num_gaussians must be at least 2 (centres are spaced cutoff/(G-1))");
+    if (width < 1 || width > kMaxWidth || num_gaussians > kMaxGauss)
+        return fail(NNPOPS_ERR_UNSUPPORTED, "this build supports width in [1, %d] and up to %d Gaussians (got %d, %d)",
+                    kMaxWidth, kMaxGauss, width, num_gaussians);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(NNPOPS_ERR_NO_DEVICE, "no HIP device available");
+    NNPOPS_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    auto* h = new nnpops_cfconv();
+    h->p.N = num_atoms; h->p.W = width; h->p.G = num_gaussians; h->p.cutoff = cutoff;
+    h->p.sigma_inv = 1.0f / gaussian_width; h->p.activation = activation;
+    h->periodic = periodic != 0; h->device = device;
+    const int W = width, G = num_gaussians;
+    std::vector<float> w1t((size_t)G * W), w2t((size_t)W * W);
+    for (int a = 0; a < W; a++)
+        for (int g = 0; g < G; g++) w1t[(size_t)g * W + a] = w1[(size_t)a * G + g];        // core layout [W][G], CpuCFConv.cpp:163
+    for (int a = 0; a < W; a++)
+        for (int b = 0; b < W; b++) w2t[(size_t)b * W + a] = w2[(size_t)a * W + b];        // [out][in], CpuCFConv.cpp:174
+    DeviceGuard guard(device);
+    int rc;
+    auto cleanup = [&](int code) { nnpops_cfconv_destroy(h); return code; };
+    if ((rc = dev_alloc(&h->d_w1t, w1t.size()))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_w2t, w2t.size()))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_b1, (size_t)W))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_b2, (size_t)W))) return cleanup(rc);
+    if (hipMemcpy(h->d_w1t, w1t.data(), w1t.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_w2t, w2t.data(), w2t.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_b1, b1, (size_t)W * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_b2, b2, (size_t)W * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(NNPOPS_ERR_HIP, "weight upload failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->blocks = prop.multiProcessorCount;
+    *out = h;
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_destroy(nnpops_cfconv_t h) {
+    if (!h) return NNPOPS_OK;
+    DeviceGuard guard(h->device);
+    dev_free(h->d_w1t); dev_free(h->d_w2t); dev_free(h->d_b1); dev_free(h->d_b2);
+    delete h;
+    return NNPOPS_OK;
+}
+
+int nnpops_cfconv_set_stream(nnpops_cfconv_t h, void* stream) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    h->stream = (hipStream_t)stream;
+    return NNPOPS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <int ACT, int CPL, bool BWD>
+int launch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out, float* pos_grad) {
+    // as many waves per workgroup as fit next to the shared weights in 160 KiB of LDS
+    const size_t budget = 156 * 1024 / sizeof(float);
+    const size_t wfl = conv_weight_floats(h->p.W, h->p.G), per_wave = conv_wave_floats(h->p.W, h->p.G, BWD);
+    if (wfl + per_wave > budget)
+        return fail(NNPOPS_ERR_UNSUPPORTED, "CFConv weights (%zu floats) do not fit in LDS", wfl);
+    const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
+    const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
+    auto k = cfconv_kernel<ACT, CPL, BWD>;
+    if (lds > 64 * 1024)
+        NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int blocks = std::max(1, std::min(h->blocks, div_up(h->p.N, wpb)));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1t, h->d_b1, h->d_w2t, h->d_b2,
+                       nb->d_rows, nb->d_cnt, nb->cap, x, gout, out, pos_grad);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+template <bool BWD>
+int dispatch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out, float* pos_grad) {
+    const bool two = h->p.W > 64;
+    if (h->p.activation == 0)
+        return two ? launch_conv<0, 2, BWD>(h, nb, x, gout, out, pos_grad) : launch_conv<0, 1, BWD>(h, nb, x, gout, out, pos_grad);
+    return two ? launch_conv<1, 2, BWD>(h, nb, x, gout, out, pos_grad) : launch_conv<1, 1, BWD>(h, nb, x, gout, out, pos_grad);
+}
+
+int check_pair(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb) {
+    NNPOPS_REQUIRE(h != nullptr && nb != nullptr, "NULL handle");
+    NNPOPS_REQUIRE(nb->built, "the neighbour list has not been built");
+    NNPOPS_REQUIRE(nb->N == h->p.N, "neighbour list is for %d atoms, convolution for %d", nb->N, h->p.N);
+    NNPOPS_REQUIRE(nb->cutoff == h->p.cutoff, "The cutoff of \"neighbors\" has changed");
+    NNPOPS_REQUIRE(nb->device == h->device, "neighbour list and convolution live on different devices");
+    return NNPOPS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nnpops_cfconv_compute(nnpops_cfconv_t h, nnpops_cfconv_neighbors_t neighbors, const float* positions, const float* box,
+                          const float* input, float* output) {
+    (void)positions; (void)box;     // forward works from the distances stored by build() (CpuCFConv.cpp:146-147)
+    int rc = check_pair(h, neighbors);
+    if (rc != NNPOPS_OK) return rc;
+    NNPOPS_REQUIRE(input && output, "NULL device pointer");
+    DeviceGuard guard(h->device);
+    return dispatch_conv<false>(h, neighbors, input, nullptr, output, nullptr);
+}
+
+int nnpops_cfconv_backprop(nnpops_cfconv_t h, nnpops_cfconv_neighbors_t neighbors, const float* positions, const float* box,
+                           const float* input, const float* output_deriv, float* input_deriv, float* position_deriv) {
+    (void)positions; (void)box;     // displacements were stored by build() from the same positions
+    int rc = check_pair(h, neighbors);
+    if (rc != NNPOPS_OK) return rc;
+    NNPOPS_REQUIRE(input && output_deriv && input_deriv && position_deriv, "NULL device pointer");
+    DeviceGuard guard(h->device);
+    return dispatch_conv<true>(h, neighbors, input, output_deriv, input_deriv, position_deriv);
+}
+
+}  // extern "C"

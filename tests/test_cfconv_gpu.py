@@ -1,0 +1,92 @@
+"""Parity of the HIP CFConv (through the C ABI) against the oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from nnpops_amd import workloads
+from oracle import CFConvNeighborsOracle, CFConvOracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OUT_RTOL, OUT_ATOL_FRAC = 2e-5, 2e-6       # |diff| <= rtol*|ref| + atol_frac*max|ref|
+FORCE_RTOL = 1e-4                          # relative to the largest force component
+
+
+def _case(pos, box, W, G, cutoff, sigma, act, seed=0, w=None):
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    n = pos.shape[0]
+    rng = np.random.default_rng(seed)
+    if w is None:
+        w1 = (0.3 * rng.standard_normal((W, G))).astype(np.float32)
+        w2 = (0.2 * rng.standard_normal((W, W))).astype(np.float32)
+        b1 = (0.3 * rng.standard_normal(W)).astype(np.float32)
+        b2 = (0.3 * rng.standard_normal(W)).astype(np.float32)
+        x = rng.standard_normal((n, W)).astype(np.float32)
+    else:
+        w1, b1, w2, b2, x = w
+    gy = rng.standard_normal((n, W)).astype(np.float32)
+    periodic = box is not None
+    onb = CFConvNeighborsOracle(n, cutoff, periodic)
+    onb.build(pos, box)
+    ocf = CFConvOracle(n, W, G, cutoff, sigma, act, w1, b1, w2, b2, periodic=periodic)
+    y_ref = ocf.forward(onb, pos, x, box)
+    xg_ref, pg_ref = ocf.backward(onb, pos, x, gy, box)
+
+    nb = CFConvNeighbors(n, cutoff, periodic)
+    cf = CFConv(n, W, G, cutoff, sigma, act, w1, b1, w2, b2, periodic=periodic)
+    tpos = torch.tensor(pos, device=DEV)
+    tbox = torch.tensor(box, device=DEV) if periodic else None
+    tx = torch.tensor(x, device=DEV)
+    nb.build(tpos, tbox)
+    y = cf.compute(nb, tpos, tx, tbox)
+    xg, pg = cf.backprop(nb, tpos, tx, torch.tensor(gy, device=DEV), tbox)
+    torch.cuda.synchronize()
+    y, xg, pg = y.cpu().numpy(), xg.cpu().numpy(), pg.cpu().numpy()
+
+    # the half list itself: same pairs, same distances
+    start, other, dist = onb.export()
+    atoms, d = nb.export()
+    ref_i = np.repeat(np.arange(n), np.diff(start))
+    assert np.array_equal(atoms[0], ref_i) and np.array_equal(atoms[1], other)
+    np.testing.assert_allclose(d, dist, rtol=1e-6)
+
+    np.testing.assert_allclose(y, y_ref, rtol=OUT_RTOL, atol=OUT_ATOL_FRAC * np.abs(y_ref).max())
+    np.testing.assert_allclose(xg, xg_ref, rtol=OUT_RTOL, atol=OUT_ATOL_FRAC * np.abs(xg_ref).max())
+    assert np.abs(pg - pg_ref).max() <= FORCE_RTOL * np.abs(pg_ref).max()
+    e_ref = float((y_ref.astype(np.float64) * gy).sum())
+    e = float((y.astype(np.float64) * gy).sum())
+    assert abs(e - e_ref) <= 1e-5 * float(np.abs(y_ref.astype(np.float64) * gy).sum())
+    return y
+
+
+@pytest.mark.parametrize("tag", ["nonperiodic_ssp", "periodic_ssp", "triclinic_ssp", "nonperiodic_tanh"])
+def test_water18_golden(golden_dir, tag):
+    """The reference's own fixture (src/schnet/TestCFConv.h:81-247), SchNetPack-generated expectations."""
+    g = np.load(f"{golden_dir}/cfconv_water18.npz")
+    box = g[f"{tag}_box"] if f"{tag}_box" in g else None
+    act = tag.split("_")[1]
+    y = _case(g["positions"], box, 8, 5, 2.0, 0.5, act, w=(g["w1"], g["b1"], g["w2"], g["b2"], g["x"]))
+    np.testing.assert_allclose(y, g[f"{tag}_output"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("W,G", [(128, 50), (64, 25), (32, 16), (5, 3)])
+@pytest.mark.parametrize("act", ["ssp", "tanh"])
+def test_random_cluster(W, G, act):
+    pos, _ = workloads.conformer(120, seed=W + G)
+    _case(pos, None, W, G, 5.0, 0.1 if G >= 25 else 0.4, act, seed=W)
+
+
+def test_periodic_box_cells():
+    """1500 atoms in a periodic box: the cell-grid neighbour search (core-level periodic variant of config 3)."""
+    pos, _, box = workloads.random_box(1500, seed=31)
+    _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=1)
+
+
+def test_nonperiodic_box_cells():
+    pos, _, _ = workloads.random_box(1300, seed=32)
+    _case(pos, None, 64, 50, 5.0, 0.1, "tanh", seed=2)
+
+
+def test_triclinic_box():
+    pos, _, box = workloads.triclinic_box(700, seed=33)
+    _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=3)
