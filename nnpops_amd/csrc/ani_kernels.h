@@ -735,11 +735,12 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
                     *reinterpret_cast<float4*>(dst + z) = make_float4(acc[z], acc[z + 1], acc[z + 2], acc[z + 3]);
                 hb = is_head ? cur : hb;
                 first = first && !closes;
-                const float r = valid ? Rv[u] : 0.f;
+                // slots past the end of the triple list hold stale LDS (possibly NaN bit patterns): select, don't scale
 #pragma unroll
                 for (int z = 0; z < NFZP; z++) {
                     head[z] = is_head ? acc[z] : head[z];
-                    acc[z] = (change ? 0.f : acc[z]) + r * Zv[u][z];
+                    const float term = valid ? Rv[u] * Zv[u][z] : 0.f;
+                    acc[z] = (change ? 0.f : acc[z]) + term;
                 }
                 cur = bkt;
             }

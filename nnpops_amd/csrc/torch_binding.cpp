@@ -1,0 +1,581 @@
+// torch_binding.cpp -- the PyTorch operator surface of the reference, re-implemented on top of the
+// C ABI (include/nnpops_hip.h).  Plain C++ (no kernels here): every entry point hands raw device
+// pointers of contiguous tensors to libnnpops_hip.so on the current HIP stream.
+//
+// Registrations mirror the reference one-for-one so that TorchScript modules and user code written
+// against NNPOps keep working:
+//   torch.classes.NNPOpsANISymmetryFunctions.Holder / torch.ops.NNPOpsANISymmetryFunctions.operation
+//                                                         (reference src/pytorch/SymmetryFunctions.cpp:265-284)
+//   torch.classes.NNPOpsCFConvNeighbors.Holder            (reference src/pytorch/CFConvNeighbors.cpp:77-85)
+//   torch.classes.NNPOpsCFConv.Holder / torch.ops.NNPOpsCFConv.operation
+//                                                         (reference src/pytorch/CFConv.cpp:276-291)
+//   torch.ops.neighbors.getNeighborPairs                  (reference src/pytorch/neighbors/neighbors.cpp:4)
+//   torch.ops.NNPOpsBatchedNN.BatchedLinear               (reference src/pytorch/BatchedNN.cpp:48-50)
+//
+// Differences that are deliberate:
+//   * there is no CPU implementation: a CPU tensor raises (the reference's CPU path is the oracle of this
+//     repository, not part of the product);
+//   * outputs are fresh tensors on every call (the reference re-returns the same storage,
+//     SymmetryFunctions.cpp:136-138,157) -- no caller can observe the difference except by aliasing bugs;
+//   * CFConv honours the current stream (the reference leaves that commented out, CFConv.cpp:167-170).
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/script.h>
+#include <torch/serialize/archive.h>
+
+#include <cmath>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/nnpops_hip.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+
+[[noreturn]] void raise_last(const char* what) {
+    throw std::runtime_error(std::string(what) + ": " + nnpops_last_error());
+}
+
+void* current_stream(const torch::Device& device) {
+    return (void*)c10::hip::getCurrentHIPStream(device.index()).stream();
+}
+
+bool stream_is_capturing(void* stream) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &status) != hipSuccess) return false;
+    return status != hipStreamCaptureStatusNone;
+}
+
+void require_device_tensor(const Tensor& t, const char* name) {
+    if (!t.is_cuda())
+        throw std::runtime_error(std::string("Unsupported device for \"") + name + "\": " + t.device().str() +
+                                 " (this build of NNPOps runs on AMD GPUs only; there is no CPU path)");
+}
+
+}  // namespace
+
+// =============================================================================================
+// ANI symmetry functions
+// =============================================================================================
+namespace NNPOps {
+namespace ANISymmetryFunctions {
+
+class Holder;
+using HolderPtr = torch::intrusive_ptr<Holder>;
+
+class Holder : public torch::CustomClassHolder {
+public:
+    Holder(int64_t numSpecies, double Rcr, double Rca, const std::vector<double>& EtaR, const std::vector<double>& ShfR,
+           const std::vector<double>& EtaA, const std::vector<double>& Zeta, const std::vector<double>& ShfA,
+           const std::vector<double>& ShfZ, const std::vector<int64_t>& atomSpecies)
+        : numSpecies(numSpecies), Rcr(Rcr), Rca(Rca), EtaR(EtaR), ShfR(ShfR), EtaA(EtaA), Zeta(Zeta), ShfA(ShfA), ShfZ(ShfZ),
+          atomSpecies(atomSpecies) {}
+
+    ~Holder() override {
+        if (impl) nnpops_ani_destroy(impl);
+    }
+
+    tensor_list forward(const Tensor& positions, const c10::optional<Tensor>& cellOpt) {
+        // same checks, same messages as the reference (SymmetryFunctions.cpp:76-99)
+        if (positions.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"positions\" has to be float32");
+        if (positions.dim() != 2) throw std::runtime_error("The shape of \"positions\" has to have 2 dimensions");
+        if (positions.size(0) != (int64_t)atomSpecies.size())
+            throw std::runtime_error("The size of the 1nd dimension of \"positions\" has to be " + std::to_string(atomSpecies.size()));
+        if (positions.size(1) != 3) throw std::runtime_error("The size of the 2nd dimension of \"positions\" has to be 3");
+        require_device_tensor(positions, "positions");
+        Tensor cell;
+        if (cellOpt) {
+            cell = *cellOpt;
+            if (cell.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"cell\" has to be float32");
+            if (cell.dim() != 2) throw std::runtime_error("The shape of \"cell\" has to have 2 dimensions");
+            if (cell.size(0) != 3) throw std::runtime_error("The size of the 1nd dimension of \"cell\" has to be 3");
+            if (cell.size(1) != 3) throw std::runtime_error("The size of the 2nd dimension of \"cell\" has to be 3");
+            if (cell.device() != positions.device()) throw std::runtime_error("\"cell\" has to be on the same device as \"positions\"");
+            cell = cell.contiguous();
+        }
+        if (!impl) {
+            device = positions.device();
+            periodic = cellOpt.has_value();       // frozen at the first call, like the reference (:122)
+            std::vector<float> radial, angular;
+            for (double eta : EtaR)
+                for (double rs : ShfR) { radial.push_back((float)eta); radial.push_back((float)rs); }              // :110-113
+            for (double eta : EtaA)
+                for (double zeta : Zeta)
+                    for (double rs : ShfA)
+                        for (double thetas : ShfZ) {                                                              // :115-120
+                            angular.push_back((float)eta); angular.push_back((float)rs);
+                            angular.push_back((float)zeta); angular.push_back((float)thetas);
+                        }
+            std::vector<int32_t> species(atomSpecies.begin(), atomSpecies.end());
+            if (nnpops_ani_create(&impl, (int)species.size(), (int)numSpecies, (float)Rcr, (float)Rca, periodic ? 1 : 0,
+                                  species.data(), (int)(radial.size() / 2), radial.data(), (int)(angular.size() / 4),
+                                  angular.data(), /*torchani=*/1, device.index()) != NNPOPS_OK)
+                raise_last("NNPOpsANISymmetryFunctions");
+            numRadial = (int64_t)(radial.size() / 2);
+            numAngular = (int64_t)(angular.size() / 4);
+        }
+        if (positions.device() != device) throw std::runtime_error("The device of \"positions\" has changed");
+        if (periodic && !cellOpt) throw std::runtime_error("\"cell\" is required: this Holder was first used with periodic box vectors");
+
+        const Tensor pos = positions.contiguous();
+        const int64_t n = (int64_t)atomSpecies.size();
+        const auto opts = torch::TensorOptions().device(device).dtype(torch::kFloat32);
+        Tensor radial = torch::empty({n, numSpecies * numRadial}, opts);
+        Tensor angular = torch::empty({n, numSpecies * (numSpecies + 1) / 2 * numAngular}, opts);
+        void* stream = current_stream(device);
+        nnpops_ani_set_stream(impl, stream);
+        const bool capturing = stream_is_capturing(stream);
+        for (int attempt = 0;; attempt++) {
+            if (nnpops_ani_compute(impl, pos.data_ptr<float>(), periodic ? cell.data_ptr<float>() : nullptr,
+                                   radial.data_ptr<float>(), angular.data_ptr<float>()) != NNPOPS_OK)
+                raise_last("NNPOpsANISymmetryFunctions::forward");
+            if (capturing) break;                     // no host synchronisation inside a graph capture
+            const int rc = nnpops_ani_check(impl, nullptr, nullptr);
+            if (rc == NNPOPS_OK) break;
+            if (rc != NNPOPS_ERR_CAPACITY || attempt > 8) raise_last("NNPOpsANISymmetryFunctions::forward");
+        }
+        return {radial, angular};
+    }
+
+    tensor_list backward(const tensor_list& grads) {
+        if (!impl) throw std::runtime_error("backward() called before forward()");
+        const Tensor radialGrad = grads[0].contiguous();     // the reference clones to force a dense buffer (:162-163)
+        const Tensor angularGrad = grads[1].contiguous();
+        Tensor positionsGrad = torch::empty({(int64_t)atomSpecies.size(), 3},
+                                            torch::TensorOptions().device(device).dtype(torch::kFloat32));
+        nnpops_ani_set_stream(impl, current_stream(device));
+        if (nnpops_ani_backprop(impl, radialGrad.data_ptr<float>(), angularGrad.data_ptr<float>(),
+                                positionsGrad.data_ptr<float>()) != NNPOPS_OK)
+            raise_last("NNPOpsANISymmetryFunctions::backward");
+        return {Tensor(), positionsGrad, Tensor()};          // no gradient for the holder and the box (:174)
+    }
+
+    static std::string serialize(const HolderPtr& self) {
+        torch::serialize::OutputArchive archive;
+        archive.write("numSpecies", self->numSpecies);
+        archive.write("Rcr", self->Rcr);
+        archive.write("Rca", self->Rca);
+        archive.write("EtaR", self->EtaR);
+        archive.write("ShfR", self->ShfR);
+        archive.write("EtaA", self->EtaA);
+        archive.write("Zeta", self->Zeta);
+        archive.write("ShfA", self->ShfA);
+        archive.write("ShfZ", self->ShfZ);
+        archive.write("atomSpecies", self->atomSpecies);
+        std::stringstream stream;
+        archive.save_to(stream);
+        return stream.str();
+    }
+
+    static HolderPtr deserialize(const std::string& state) {
+        std::stringstream stream(state);
+        torch::serialize::InputArchive archive;
+        archive.load_from(stream, torch::kCPU);
+        torch::IValue numSpecies, Rcr, Rca, EtaR, ShfR, EtaA, Zeta, ShfA, ShfZ, atomSpecies;
+        archive.read("numSpecies", numSpecies);
+        archive.read("Rcr", Rcr);
+        archive.read("Rca", Rca);
+        archive.read("EtaR", EtaR);
+        archive.read("ShfR", ShfR);
+        archive.read("EtaA", EtaA);
+        archive.read("Zeta", Zeta);
+        archive.read("ShfA", ShfA);
+        archive.read("ShfZ", ShfZ);
+        archive.read("atomSpecies", atomSpecies);
+        return HolderPtr::make(numSpecies.toInt(), Rcr.toDouble(), Rca.toDouble(), EtaR.toDoubleVector(), ShfR.toDoubleVector(),
+                               EtaA.toDoubleVector(), Zeta.toDoubleVector(), ShfA.toDoubleVector(), ShfZ.toDoubleVector(),
+                               atomSpecies.toIntVector());
+    }
+
+private:
+    int64_t numSpecies;
+    double Rcr, Rca;
+    std::vector<double> EtaR, ShfR, EtaA, Zeta, ShfA, ShfZ;
+    std::vector<int64_t> atomSpecies;
+    torch::Device device = torch::kCPU;
+    bool periodic = false;
+    int64_t numRadial = 0, numAngular = 0;
+    nnpops_ani_t impl = nullptr;
+};
+
+class AutogradFunctions : public torch::autograd::Function<AutogradFunctions> {
+public:
+    static tensor_list forward(AutogradContext* ctx, const HolderPtr& holder, const Tensor& positions,
+                               const c10::optional<Tensor>& periodicBoxVectors) {
+        ctx->saved_data["holder"] = holder;
+        return holder->forward(positions, periodicBoxVectors);
+    }
+    static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
+        const auto holder = ctx->saved_data["holder"].toCustomClass<Holder>();
+        ctx->saved_data.erase("holder");
+        return holder->backward(grads);
+    }
+};
+
+tensor_list operation(const c10::optional<HolderPtr>& holder, const Tensor& positions,
+                      const c10::optional<Tensor>& periodicBoxVectors) {
+    return AutogradFunctions::apply(*holder, positions, periodicBoxVectors);
+}
+
+TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
+    m.class_<Holder>("Holder")
+        .def(torch::init<int64_t, double, double, const std::vector<double>&, const std::vector<double>&,
+                         const std::vector<double>&, const std::vector<double>&, const std::vector<double>&,
+                         const std::vector<double>&, const std::vector<int64_t>&>())
+        .def("forward", &Holder::forward)
+        .def("backward", &Holder::backward)
+        .def_pickle([](const HolderPtr& self) -> std::string { return Holder::serialize(self); },
+                    [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
+    m.def("operation", operation);
+}
+
+}  // namespace ANISymmetryFunctions
+
+// =============================================================================================
+// CFConv neighbours
+// =============================================================================================
+namespace CFConvNeighbors {
+
+class Holder : public torch::CustomClassHolder {
+public:
+    explicit Holder(double cutoff) : cutoff(cutoff) {}
+    ~Holder() override {
+        if (impl) nnpops_cfconv_neighbors_destroy(impl);
+    }
+
+    void build(const Tensor& positions) {
+        if (positions.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"positions\" has to be float32");
+        if (positions.dim() != 2) throw std::runtime_error("The shape of \"positions\" has to have 2 dimensions");
+        if (positions.size(1) != 3) throw std::runtime_error("The size of the 2nd dimension of \"positions\" has to be 3");
+        require_device_tensor(positions, "positions");
+        if (!impl) {
+            numAtoms = positions.size(0);
+            device = positions.device();
+            // non-periodic at this level, like the reference binding (CFConvNeighbors.cpp:52,57,74)
+            if (nnpops_cfconv_neighbors_create(&impl, (int)numAtoms, (float)cutoff, 0, device.index()) != NNPOPS_OK)
+                raise_last("NNPOpsCFConvNeighbors");
+        }
+        if (positions.size(0) != numAtoms) throw std::runtime_error("The size of the 2nd dimension of \"positions\" has changed");
+        if (positions.device() != device) throw std::runtime_error("The device of \"positions\" has changed");
+        const Tensor pos = positions.detach().contiguous();
+        void* stream = current_stream(device);
+        nnpops_cfconv_neighbors_set_stream(impl, stream);
+        const bool capturing = stream_is_capturing(stream);
+        for (int attempt = 0;; attempt++) {
+            if (nnpops_cfconv_neighbors_build(impl, pos.data_ptr<float>(), nullptr) != NNPOPS_OK) raise_last("CFConvNeighbors::build");
+            if (capturing) break;
+            const int rc = nnpops_cfconv_neighbors_check(impl, nullptr);
+            if (rc == NNPOPS_OK) break;
+            if (rc != NNPOPS_ERR_CAPACITY || attempt > 8) raise_last("CFConvNeighbors::build");
+        }
+    }
+    double getCutoff() const { return cutoff; }
+    nnpops_cfconv_neighbors_t getImpl() const { return impl; }
+
+private:
+    double cutoff;
+    int64_t numAtoms = 0;
+    torch::Device device = torch::kCPU;
+    nnpops_cfconv_neighbors_t impl = nullptr;
+};
+using HolderPtr = torch::intrusive_ptr<Holder>;
+
+TORCH_LIBRARY(NNPOpsCFConvNeighbors, m) {
+    m.class_<Holder>("Holder")
+        .def(torch::init<double>())
+        .def("build", &Holder::build)
+        .def_pickle([](const HolderPtr& self) -> double { return self->getCutoff(); },
+                    [](double cutoff) -> HolderPtr { return HolderPtr::make(cutoff); });
+}
+
+}  // namespace CFConvNeighbors
+
+// =============================================================================================
+// CFConv
+// =============================================================================================
+namespace CFConv {
+
+using Neighbors = NNPOps::CFConvNeighbors::Holder;
+using NeighborsPtr = torch::intrusive_ptr<Neighbors>;
+class Holder;
+using HolderPtr = torch::intrusive_ptr<Holder>;
+
+class Holder : public torch::CustomClassHolder {
+public:
+    Holder(double gaussianWidth, const std::string& activation, const Tensor& weights1, const Tensor& biases1,
+           const Tensor& weights2, const Tensor& biases2)
+        : gaussianWidth(gaussianWidth), activation(activation),
+          // host copies, as in the reference (CFConv.cpp:63-66)
+          weights1(weights1.to(torch::kFloat32).cpu().clone()), biases1(biases1.to(torch::kFloat32).cpu().clone()),
+          weights2(weights2.to(torch::kFloat32).cpu().clone()), biases2(biases2.to(torch::kFloat32).cpu().clone()) {}
+
+    ~Holder() override {
+        if (impl) nnpops_cfconv_destroy(impl);
+    }
+
+    Tensor forward(const c10::IValue& neighbors_, const Tensor& positions_, const Tensor& input_) {
+        neighbors = neighbors_.toCustomClass<Neighbors>();      // kept for the backward pass
+        if (positions_.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"positions\" has to be float32");
+        if (positions_.dim() != 2) throw std::runtime_error("The shape of \"positions\" has to have 2 dimensions");
+        if (positions_.size(1) != 3) throw std::runtime_error("The size of the 2nd dimension of \"positions\" has to be 3");
+        if (input_.device() != positions_.device()) throw std::runtime_error("The device of \"input\" and \"positions\" has to be the same");
+        if (input_.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"input\" has to be float32");
+        if (input_.dim() != 2) throw std::runtime_error("The shape of \"input\" has to have 2 dimensions");
+        if (input_.size(0) != positions_.size(0))
+            throw std::runtime_error("The size of the 1nd dimension of \"input\" has to be equal to the 1st dimension of \"positions\"");
+        require_device_tensor(positions_, "positions");
+        positions = positions_.detach().contiguous();
+        input = input_.detach().contiguous();
+        if (!impl) {
+            device = positions.device();
+            numAtoms = positions.size(0);
+            numFilters = input.size(1);
+            cutoff = neighbors->getCutoff();
+            int act;
+            if (activation == "ssp") act = 0;
+            else if (activation == "tanh") act = 1;
+            else throw std::invalid_argument("Invalid value of \"activation\"");
+            // shape checks and messages of the reference (CFConv.cpp:106-127)
+            if (weights1.dim() != 2) throw std::runtime_error("The shape of \"weights1\" has to have 2 dimensions");
+            const int64_t numGaussians = weights1.size(0);
+            if (weights1.size(1) != numFilters)
+                throw std::runtime_error("The size of the 2nd dimension of \"weights1\" has to be equal to the 2st dimension of \"input\"");
+            if (biases1.dim() != 1) throw std::runtime_error("The shape of \"biases1\" has to have 1 dimension");
+            if (biases1.size(0) != numFilters) throw std::runtime_error("The size of \"biases1\" has to be equal to the 2st dimension of \"input\"");
+            if (weights2.dim() != 2) throw std::runtime_error("The shape of \"weights2\" has to have 2 dimensions");
+            if (weights2.size(0) != numFilters)
+                throw std::runtime_error("The size of the 1nd dimension of \"weights2\" has to be equal to the 2st dimension of \"input\"");
+            if (weights2.size(1) != numFilters)
+                throw std::runtime_error("The size of the 2nd dimension of \"weights2\" has to be equal to the 2st dimension of \"input\"");
+            if (biases2.dim() != 1) throw std::runtime_error("The shape of \"biases2\" has to have 1 dimension");
+            if (biases2.size(0) != numFilters) throw std::runtime_error("The size of \"biases2\" has to be equal to the 2st dimension of \"input\"");
+            // Layout note: the reference hands the contiguous [G, W] buffer of weights1 to a core that indexes it
+            // as [W][G] (CFConv.cpp:131-132 -> CpuCFConv.cpp:163), i.e. a reinterpretation, not a transpose.  The
+            // C ABI takes the core layout, so the same buffer is passed through unchanged.
+            const Tensor w1 = weights1.contiguous(), w2 = weights2.contiguous();
+            if (nnpops_cfconv_create(&impl, (int)numAtoms, (int)numFilters, (int)numGaussians, (float)cutoff, 0, (float)gaussianWidth,
+                                     act, w1.data_ptr<float>(), biases1.data_ptr<float>(), w2.data_ptr<float>(),
+                                     biases2.data_ptr<float>(), device.index()) != NNPOPS_OK)
+                raise_last("NNPOpsCFConv");
+        }
+        if (neighbors->getCutoff() != cutoff) throw std::runtime_error("The cutoff of \"neighbors\" has changed");
+        if (positions.size(0) != numAtoms) throw std::runtime_error("The size of the 1nd dimension of \"positions\" has changed");
+        if (positions.device() != device) throw std::runtime_error("The device of \"positions\" has changed");
+        if (input.size(0) != numAtoms) throw std::runtime_error("The size of the 1nd dimension of \"input\" has changed");
+        if (input.size(1) != numFilters) throw std::runtime_error("The size of the 2nd dimension of \"input\" has changed");
+        if (input.device() != device) throw std::runtime_error("The device of \"input\" has changed");
+        if (!neighbors->getImpl()) throw std::runtime_error("\"neighbors\" has not been built");
+
+        Tensor output = torch::empty({numAtoms, numFilters}, torch::TensorOptions().device(device).dtype(torch::kFloat32));
+        nnpops_cfconv_set_stream(impl, current_stream(device));
+        if (nnpops_cfconv_compute(impl, neighbors->getImpl(), positions.data_ptr<float>(), nullptr, input.data_ptr<float>(),
+                                  output.data_ptr<float>()) != NNPOPS_OK)
+            raise_last("NNPOpsCFConv::forward");
+        return output;
+    }
+
+    tensor_list backward(const tensor_list& grads) {
+        if (!impl) throw std::runtime_error("backward() called before forward()");
+        const Tensor outputGrad = grads[0].contiguous();
+        const auto opts = torch::TensorOptions().device(device).dtype(torch::kFloat32);
+        Tensor inputGrad = torch::empty({numAtoms, numFilters}, opts);
+        Tensor positionsGrad = torch::empty({numAtoms, 3}, opts);
+        nnpops_cfconv_set_stream(impl, current_stream(device));
+        if (nnpops_cfconv_backprop(impl, neighbors->getImpl(), positions.data_ptr<float>(), nullptr, input.data_ptr<float>(),
+                                   outputGrad.data_ptr<float>(), inputGrad.data_ptr<float>(), positionsGrad.data_ptr<float>()) != NNPOPS_OK)
+            raise_last("NNPOpsCFConv::backward");
+        return {Tensor(), Tensor(), positionsGrad, inputGrad};    // nothing for the holder and the neighbours (:189)
+    }
+
+    static std::string serialize(const HolderPtr& self) {
+        torch::serialize::OutputArchive archive;
+        archive.write("gaussianWidth", self->gaussianWidth);
+        archive.write("activation", self->activation);
+        archive.write("weights1", self->weights1);
+        archive.write("biases1", self->biases1);
+        archive.write("weights2", self->weights2);
+        archive.write("biases2", self->biases2);
+        std::stringstream stream;
+        archive.save_to(stream);
+        return stream.str();
+    }
+
+    static HolderPtr deserialize(const std::string& state) {
+        std::stringstream stream(state);
+        torch::serialize::InputArchive archive;
+        archive.load_from(stream, torch::kCPU);
+        torch::IValue gaussianWidth, activation;
+        Tensor weights1, biases1, weights2, biases2;
+        archive.read("gaussianWidth", gaussianWidth);
+        archive.read("activation", activation);
+        archive.read("weights1", weights1);
+        archive.read("biases1", biases1);
+        archive.read("weights2", weights2);
+        archive.read("biases2", biases2);
+        return HolderPtr::make(gaussianWidth.toDouble(), activation.toStringRef(), weights1, biases1, weights2, biases2);
+    }
+
+private:
+    double gaussianWidth;
+    std::string activation;
+    Tensor weights1, biases1, weights2, biases2;
+    torch::Device device = torch::kCPU;
+    int64_t numAtoms = 0, numFilters = 0;
+    double cutoff = 0;
+    NeighborsPtr neighbors;
+    Tensor positions, input;
+    nnpops_cfconv_t impl = nullptr;
+};
+
+class AutogradFunctions : public torch::autograd::Function<AutogradFunctions> {
+public:
+    static Tensor forward(AutogradContext* ctx, const HolderPtr& holder, const c10::IValue& neighbors, const Tensor& positions,
+                          const Tensor& input) {
+        ctx->saved_data["holder"] = holder;
+        return holder->forward(neighbors, positions, input);
+    }
+    static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
+        const HolderPtr holder = ctx->saved_data["holder"].toCustomClass<Holder>();
+        ctx->saved_data.erase("holder");
+        return holder->backward(grads);
+    }
+};
+
+Tensor operation(const c10::optional<HolderPtr>& holder, const c10::IValue& neighbors, const Tensor& positions,
+                 const Tensor& input) {
+    return AutogradFunctions::apply(*holder, neighbors, positions, input);
+}
+
+TORCH_LIBRARY(NNPOpsCFConv, m) {
+    m.class_<Holder>("Holder")
+        .def(torch::init<double, const std::string&, const Tensor&, const Tensor&, const Tensor&, const Tensor&>())
+        .def("forward", &Holder::forward)
+        .def("backward", &Holder::backward)
+        .def_pickle([](const HolderPtr& self) -> std::string { return Holder::serialize(self); },
+                    [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
+    m.def("operation", operation);
+}
+
+}  // namespace CFConv
+}  // namespace NNPOps
+
+// =============================================================================================
+// getNeighborPairs
+// =============================================================================================
+namespace {
+
+class NeighborPairsFunction : public torch::autograd::Function<NeighborPairsFunction> {
+public:
+    static tensor_list forward(AutogradContext* ctx, const Tensor& positions, const torch::Scalar& cutoff,
+                               const torch::Scalar& max_num_pairs, const Tensor& box_vectors, bool checkErrors) {
+        // checks and messages of the reference (getNeighborPairsCUDA.cu:112-126,145-146)
+        TORCH_CHECK(positions.dim() == 2, "Expected \"positions\" to have two dimensions");
+        TORCH_CHECK(positions.size(0) > 0, "Expected the 1nd dimension size of \"positions\" to be more than 0");
+        TORCH_CHECK(positions.size(1) == 3, "Expected the 2nd dimension size of \"positions\" to be 3");
+        TORCH_CHECK(positions.is_contiguous(), "Expected \"positions\" to be contiguous");
+        TORCH_CHECK(positions.scalar_type() == torch::kFloat32 || positions.scalar_type() == torch::kFloat64,
+                    "Expected \"positions\" to be float32 or float64");
+        const int64_t max_pairs = max_num_pairs.toLong();
+        TORCH_CHECK(max_pairs > 0 || max_pairs == -1, "Expected \"max_num_pairs\" to be positive or equal to -1");
+        TORCH_CHECK(cutoff.toDouble() > 0, "Expected \"cutoff\" to be positive");
+        const bool use_periodic = box_vectors.size(0) != 0;
+        Tensor box;
+        if (use_periodic) {
+            TORCH_CHECK(box_vectors.dim() == 2, "Expected \"box_vectors\" to have two dimensions");
+            TORCH_CHECK(box_vectors.size(0) == 3 && box_vectors.size(1) == 3, "Expected \"box_vectors\" to have shape (3, 3)");
+            box = box_vectors.to(positions.options()).contiguous();
+        }
+        const int64_t num_atoms = positions.size(0);
+        const int64_t slots = max_pairs == -1 ? num_atoms * (num_atoms - 1) / 2 : max_pairs;
+        const auto options = positions.options();
+        Tensor neighbors = torch::empty({2, slots}, options.dtype(torch::kInt32));
+        Tensor deltas = torch::empty({slots, 3}, options);
+        Tensor distances = torch::empty({slots}, options);
+        Tensor num_pairs = torch::empty({1}, options.dtype(torch::kInt32));
+        Tensor workspace = torch::empty({nnpops_neighbor_pairs_workspace_bytes((int)num_atoms)}, options.dtype(torch::kUInt8));
+        const int dtype = positions.scalar_type() == torch::kFloat64 ? 1 : 0;
+        c10::hip::HIPGuard guard(positions.device().index());
+        void* stream = current_stream(positions.device());
+        if (nnpops_neighbor_pairs_forward(dtype, (int)num_atoms, positions.data_ptr(), use_periodic ? box.data_ptr() : nullptr,
+                                          cutoff.toDouble(), max_pairs, neighbors.data_ptr<int32_t>(), deltas.data_ptr(),
+                                          distances.data_ptr(), num_pairs.data_ptr<int32_t>(), workspace.data_ptr(), stream) != NNPOPS_OK)
+            raise_last("neighbors::getNeighborPairs");
+        if (checkErrors) {      // synchronises: incompatible with graph capture, as documented by the reference (:156-160)
+            const int found = num_pairs.item<int32_t>();
+            TORCH_CHECK(found <= slots, "Too many neighbor pairs found. Maximum is " + std::to_string(slots),
+                        " but found " + std::to_string(found));
+        }
+        ctx->save_for_backward({neighbors, deltas, distances});
+        ctx->saved_data["num_atoms"] = num_atoms;
+        return {neighbors, deltas, distances, num_pairs};
+    }
+
+    static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor neighbors = saved[0], deltas = saved[1], distances = saved[2];
+        const int64_t num_atoms = ctx->saved_data["num_atoms"].toInt();
+        const Tensor grad_deltas = grad_outputs[1].defined() ? grad_outputs[1].contiguous() : torch::zeros_like(deltas);
+        const Tensor grad_distances = grad_outputs[2].defined() ? grad_outputs[2].contiguous() : torch::zeros_like(distances);
+        Tensor grad_positions = torch::empty({num_atoms, 3}, deltas.options());
+        const int dtype = deltas.scalar_type() == torch::kFloat64 ? 1 : 0;
+        c10::hip::HIPGuard guard(deltas.device().index());
+        if (nnpops_neighbor_pairs_backward(dtype, (int)num_atoms, distances.size(0), neighbors.data_ptr<int32_t>(), deltas.data_ptr(),
+                                           distances.data_ptr(), grad_deltas.data_ptr(), grad_distances.data_ptr(),
+                                           grad_positions.data_ptr(), current_stream(deltas.device())) != NNPOPS_OK)
+            raise_last("neighbors::getNeighborPairs backward");
+        return {grad_positions, Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+TORCH_LIBRARY(neighbors, m) {
+    m.def("getNeighborPairs(Tensor positions, Scalar cutoff, Scalar max_num_neighbors, Tensor box_vectors, bool checkErrors) -> "
+          "(Tensor neighbors, Tensor deltas, Tensor distances, Tensor num_pairs)");
+}
+
+TORCH_LIBRARY_IMPL(neighbors, AutogradCUDA, m) {
+    m.impl("getNeighborPairs", [](const Tensor& positions, const torch::Scalar& cutoff, const torch::Scalar& max_num_pairs,
+                                  const Tensor& box_vectors, bool checkErrors) {
+        const tensor_list r = NeighborPairsFunction::apply(positions, cutoff, max_num_pairs, box_vectors, checkErrors);
+        return std::make_tuple(r[0], r[1], r[2], r[3]);
+    });
+}
+
+TORCH_LIBRARY_IMPL(neighbors, CPU, m) {
+    m.impl("getNeighborPairs", [](const Tensor& positions, const torch::Scalar&, const torch::Scalar&, const Tensor&, bool)
+                                   -> std::tuple<Tensor, Tensor, Tensor, Tensor> {
+        require_device_tensor(positions, "positions");
+        return {};
+    });
+}
+
+// =============================================================================================
+// BatchedLinear (reference src/pytorch/BatchedNN.cpp:30-50): y = W v + b broadcast over
+// [molecules, atoms, models]; the backward skips the parameter gradients.
+// =============================================================================================
+class BatchedLinearFunction : public torch::autograd::Function<BatchedLinearFunction> {
+public:
+    static Tensor forward(AutogradContext* ctx, const Tensor& vectors, const Tensor& weights, const Tensor& biases) {
+        ctx->save_for_backward({weights});
+        return torch::matmul(weights, vectors) + biases;
+    }
+    static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
+        const Tensor weights = ctx->get_saved_variables()[0];
+        // dL/dv = W^T dL/dy, written as a row-vector product so no transpose is materialised
+        const Tensor row = grads[0].squeeze(-1).unsqueeze(-2);
+        return {torch::matmul(row, weights).squeeze(-2).unsqueeze(-1), Tensor(), Tensor()};
+    }
+};
+
+Tensor BatchedLinear(const Tensor& vectors, const Tensor& weights, const Tensor& biases) {
+    return BatchedLinearFunction::apply(vectors, weights, biases);
+}
+
+TORCH_LIBRARY(NNPOpsBatchedNN, m) { m.def("BatchedLinear", BatchedLinear); }
+
+}  // namespace

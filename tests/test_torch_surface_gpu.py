@@ -1,0 +1,286 @@
+"""The reference's PyTorch surface (torch.ops / torch.classes / NNPOps.* modules) on the HIP kernels.
+
+torchani is not installed here, so the TorchANI objects the wrappers consume are replaced by small
+stand-ins with the same attributes (the wrappers duck-type them).  Numerics are checked against the
+oracle (AEV, CFConv) or against plain PyTorch (neighbours, BatchedNN); TorchScript script/save/load,
+a non-default stream and graph capture mirror the reference's own Python tests
+(src/pytorch/TestSymmetryFunctions.py:107-179, TestCFConv.py:100-140, neighbors/TestNeighbors.py:170-206,273-289).
+"""
+import io
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from nnpops_amd import workloads
+from oracle import AniOracle, CFConvNeighborsOracle, CFConvOracle
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+Z_OF_SPECIES = [1, 6, 7, 8, 16, 9, 17]          # ANI-2x order H C N O S F Cl
+
+
+class FakeConverter(nn.Module):
+    """Stands in for torchani.nn.SpeciesConverter."""
+
+    def __init__(self):
+        super().__init__()
+        conv = torch.full((120,), -1, dtype=torch.long)
+        for s, z in enumerate(Z_OF_SPECIES):
+            conv[z] = s
+        self.register_buffer("conv_tensor", conv)
+
+    def forward(self, inp):
+        numbers, coords = inp
+        return SimpleNamespace(species=self.conv_tensor.to(numbers.device)[numbers], coordinates=coords)
+
+
+def fake_aev_computer():
+    """Stands in for torchani.AEVComputer with the ANI-2x constants, tensors shaped as TorchANI shapes them."""
+    c = workloads.ANI2X
+    t = torch.tensor
+    return SimpleNamespace(num_species=7, Rcr=c["Rcr"], Rca=c["Rca"],
+                           EtaR=t(c["EtaR"]).view(-1, 1), ShfR=t(c["ShfR"]).view(1, -1),
+                           EtaA=t(c["EtaA"]).view(-1, 1, 1, 1), Zeta=t(c["Zeta"]).view(1, -1, 1, 1),
+                           ShfA=t(c["ShfA"]).view(1, 1, -1, 1), ShfZ=t(c["ShfZ"]).view(1, 1, 1, -1))
+
+
+def _numbers(species):
+    return torch.tensor([[Z_OF_SPECIES[s] for s in species]], device=DEV)
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_symmetry_functions_module(periodic):
+    from NNPOps.SymmetryFunctions import TorchANISymmetryFunctions
+    if periodic:
+        pos, species, box = workloads.water_box(100, seed=3)
+    else:
+        pos, species = workloads.conformer(73, seed=4)
+        box = None
+    rf, af = workloads.ani2x_functions()
+    numbers = _numbers(species)
+    module = TorchANISymmetryFunctions(FakeConverter(), fake_aev_computer(), numbers.cpu()).to(DEV)
+    tpos = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+    cell = torch.tensor(box, device=DEV) if periodic else None
+    pbc = torch.tensor([True, True, True], device=DEV) if periodic else None
+    sp, aev = module((torch.tensor(species, device=DEV).unsqueeze(0), tpos), cell, pbc)
+    assert aev.shape == (1, len(species), 1008)
+    w = torch.randn(aev.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    (aev * w).sum().backward()
+    oracle = AniOracle(7, 5.1, 3.5, species, rf, af, periodic=periodic)
+    r_ref, a_ref = oracle.forward(pos, box)
+    ref = np.concatenate([r_ref, a_ref], axis=1)
+    np.testing.assert_allclose(aev[0].detach().cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+    wn = w[0].cpu().numpy()
+    g_ref = oracle.backward(np.ascontiguousarray(wn[:, :112]), np.ascontiguousarray(wn[:, 112:]))
+    g = tpos.grad[0].cpu().numpy()
+    assert np.abs(g - g_ref).max() <= 1e-4 * np.abs(g_ref).max()
+
+
+def test_symmetry_functions_errors():
+    from NNPOps.SymmetryFunctions import TorchANISymmetryFunctions
+    pos, species = workloads.conformer(10, seed=1)
+    module = TorchANISymmetryFunctions(FakeConverter(), fake_aev_computer(), _numbers(species).cpu())
+    tpos = torch.tensor(pos, device=DEV).unsqueeze(0)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    with pytest.raises(ValueError, match="Batched"):
+        module((sp.repeat(2, 1), tpos.repeat(2, 1, 1)))
+    with pytest.raises(ValueError, match="pbc"):
+        module((sp, tpos), torch.eye(3, device=DEV) * 30)
+    with pytest.raises(ValueError, match="fully periodic"):
+        module((sp, tpos), torch.eye(3, device=DEV) * 30, torch.tensor([True, True, False]))
+    with pytest.raises(RuntimeError, match="float32"):
+        module((sp, tpos.double()))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        module((sp.cpu(), tpos.cpu()))
+
+
+def test_symmetry_functions_torchscript_roundtrip_and_stream():
+    from NNPOps.SymmetryFunctions import TorchANISymmetryFunctions
+    pos, species = workloads.conformer(46, seed=8)
+    module = TorchANISymmetryFunctions(FakeConverter(), fake_aev_computer(), _numbers(species).cpu()).to(DEV)
+    tpos = torch.tensor(pos, device=DEV).unsqueeze(0)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    ref = module((sp, tpos))[1]
+    scripted = torch.jit.script(module)
+    buf = io.BytesIO()
+    torch.jit.save(scripted, buf)
+    buf.seek(0)
+    loaded = torch.jit.load(buf)
+    out = loaded((sp, tpos))[1]
+    assert torch.equal(out, ref)
+    # non-default stream (TestSymmetryFunctions.py:145-179)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        p2 = tpos.clone().requires_grad_(True)
+        e = loaded((sp, p2))[1].sum()
+        e.backward()
+    stream.synchronize()
+    p3 = tpos.clone().requires_grad_(True)
+    module((sp, p3))[1].sum().backward()
+    assert torch.allclose(p2.grad, p3.grad, rtol=1e-5, atol=1e-6)
+
+
+def _cfconv_weights(G, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (0.3 * torch.randn(G, W, generator=g), 0.3 * torch.randn(W, generator=g), 0.2 * torch.randn(W, W, generator=g),
+            0.3 * torch.randn(W, generator=g))
+
+
+@pytest.mark.parametrize("activation", ["ssp", "tanh"])
+def test_cfconv_module(activation):
+    from NNPOps.CFConv import CFConv
+    from NNPOps.CFConvNeighbors import CFConvNeighbors
+    n, W, G, cutoff, sigma = 90, 32, 12, 4.0, 0.4
+    pos, _ = workloads.conformer(n, seed=12)
+    w1, b1, w2, b2 = _cfconv_weights(G, W, 5)
+    x = torch.randn(n, W, generator=torch.Generator().manual_seed(6))
+    gy = torch.randn(n, W, generator=torch.Generator().manual_seed(7))
+    neighbors = CFConvNeighbors(cutoff)
+    conv = CFConv(sigma, activation, w1, b1, w2, b2)
+    tpos = torch.tensor(pos, device=DEV, requires_grad=True)
+    tx = x.to(DEV).requires_grad_(True)
+    neighbors.build(tpos)
+    out = conv(neighbors, tpos, tx)
+    assert out.shape == (n, W) and out.dtype == torch.float32 and out.device == tpos.device
+    (out * gy.to(DEV)).sum().backward()
+    # the binding hands the [G, W] buffer to a core that reads it as [W][G] (SURVEY.md s8b "weight layout trap")
+    core_w1 = w1.contiguous().view(-1).view(W, G).numpy()
+    onb = CFConvNeighborsOracle(n, cutoff)
+    onb.build(pos)
+    ocf = CFConvOracle(n, W, G, cutoff, sigma, activation, core_w1, b1.numpy(), w2.numpy(), b2.numpy())
+    y_ref = ocf.forward(onb, pos, x.numpy())
+    xg_ref, pg_ref = ocf.backward(onb, pos, x.numpy(), gy.numpy())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), y_ref, rtol=2e-5, atol=2e-6 * np.abs(y_ref).max())
+    np.testing.assert_allclose(tx.grad.cpu().numpy(), xg_ref, rtol=2e-5, atol=2e-6 * np.abs(xg_ref).max())
+    assert np.abs(tpos.grad.cpu().numpy() - pg_ref).max() <= 1e-4 * np.abs(pg_ref).max()
+
+
+def test_cfconv_torchscript_roundtrip():
+    from NNPOps.CFConv import CFConv
+    from NNPOps.CFConvNeighbors import CFConvNeighbors
+
+    class Layer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.neighbors = CFConvNeighbors(3.0)
+            self.conv = CFConv(0.5, "ssp", *_cfconv_weights(6, 16, 1))
+
+        def forward(self, positions, x):
+            self.neighbors.build(positions)
+            return self.conv(self.neighbors, positions, x)
+
+    pos, _ = workloads.conformer(30, seed=2)
+    tpos, x = torch.tensor(pos, device=DEV), torch.randn(30, 16, device=DEV)
+    layer = Layer()
+    ref = layer(tpos, x)
+    buf = io.BytesIO()
+    torch.jit.save(torch.jit.script(layer), buf)
+    buf.seek(0)
+    out = torch.jit.load(buf)(tpos, x)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_get_neighbor_pairs_op_values_and_grads(dtype):
+    from NNPOps.neighbors import getNeighborPairs
+    n = 64
+    pos = (3 * torch.randn(n, 3, generator=torch.Generator().manual_seed(0))).to(dtype).to(DEV)
+    ref_nb = torch.tril_indices(n, n, -1, device=DEV)
+    p_ref = pos.clone().requires_grad_(True)
+    d_ref = p_ref[ref_nb[0]] - p_ref[ref_nb[1]]
+    r_ref = torch.linalg.norm(d_ref, dim=1)
+    p = pos.clone().requires_grad_(True)
+    nb, deltas, dist, npairs = getNeighborPairs(p, cutoff=1000.0)
+    assert torch.equal(nb.long(), ref_nb) and int(npairs) == n * (n - 1) // 2
+    assert torch.allclose(deltas, d_ref) and torch.allclose(dist, r_ref)
+    (deltas.sum() + (dist ** 2).sum()).backward()
+    (d_ref.sum() + (r_ref ** 2).sum()).backward()
+    assert torch.allclose(p.grad, p_ref.grad, rtol=1e-3 if dtype == torch.float32 else 1e-9, atol=1e-3 if dtype == torch.float32 else 1e-9)
+
+
+def test_get_neighbor_pairs_check_errors_and_graph_capture():
+    from NNPOps.neighbors import getNeighborPairs
+    pos = torch.zeros(4, 3, device=DEV)
+    pos[:, 0] = torch.arange(4) * 0.1
+    with pytest.raises(RuntimeError, match="Too many neighbor pairs"):
+        getNeighborPairs(pos, cutoff=1.0, max_num_pairs=4, check_errors=True)
+    nb, _, _, npairs = getNeighborPairs(pos, cutoff=1.0, max_num_pairs=4, check_errors=False)
+    assert int(npairs) == 6 and nb.shape == (2, 4)
+    # graph capture (TestNeighbors.py:170-206)
+    big = torch.randn(200, 3, device=DEV) * 5
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            getNeighborPairs(big, cutoff=4.0, max_num_pairs=4000)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_nb, g_dl, g_ds, g_n = getNeighborPairs(big, cutoff=4.0, max_num_pairs=4000)
+    big.copy_(torch.randn(200, 3, device=DEV) * 5)
+    graph.replay()
+    torch.cuda.synchronize()
+    e_nb, e_dl, e_ds, e_n = getNeighborPairs(big, cutoff=4.0, max_num_pairs=4000)
+    assert torch.equal(g_nb, e_nb) and int(g_n) == int(e_n)
+    assert torch.allclose(g_ds, e_ds, equal_nan=True)
+
+
+class FakeANIModel(nn.ModuleDict):
+    """species symbol -> Sequential(Linear, CELU, Linear, CELU, Linear, CELU, Linear), like torchani.ANIModel"""
+
+
+def _fake_ensemble(n_models, seed, widths):
+    torch.manual_seed(seed)
+    models = []
+    for _ in range(n_models):
+        nets = {}
+        for sym, (h1, h2, h3) in widths.items():
+            nets[sym] = nn.Sequential(nn.Linear(1008, h1), nn.CELU(0.1), nn.Linear(h1, h2), nn.CELU(0.1), nn.Linear(h2, h3),
+                                      nn.CELU(0.1), nn.Linear(h3, 1))
+        models.append(FakeANIModel(nets))
+    return nn.ModuleList(models)
+
+
+def test_batched_nn_and_optimized_torchani():
+    """OptimizedTorchANI = species converter + HIP AEV + BatchedNN + shifter; compared with the plain
+    per-species evaluation of the same random networks on the oracle's AEV (BASELINE config 2 shapes)."""
+    from NNPOps import OptimizedTorchANI
+    widths = {"H": (256, 192, 160), "C": (224, 192, 160), "N": (192, 160, 128), "O": (192, 160, 128),
+              "S": (160, 128, 96), "F": (160, 128, 96), "Cl": (160, 128, 96)}
+    ensemble = _fake_ensemble(3, 0, widths)
+    sae = torch.tensor([-0.5, -38.0, -54.7, -75.2, -398.1, -99.8, -460.1], dtype=torch.float64)
+    model = SimpleNamespace(species_converter=FakeConverter(), aev_computer=fake_aev_computer(), neural_networks=ensemble,
+                            energy_shifter=SimpleNamespace(sae=lambda species: sae[species].sum(dim=1)))
+    pos, species, box = workloads.water_box(40, seed=9)
+    numbers = _numbers(species)
+    opt = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+    tpos = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True], device=DEV)
+    energy = opt((numbers, tpos), cell, pbc).energies
+    energy.sum().backward()
+    # plain evaluation on the oracle's AEV, float64
+    rf, af = workloads.ani2x_functions()
+    oracle = AniOracle(7, 5.1, 3.5, species, rf, af, periodic=True)
+    r_ref, a_ref = oracle.forward(pos, box)
+    aev = torch.tensor(np.concatenate([r_ref, a_ref], axis=1), dtype=torch.float64, requires_grad=True)
+    syms = list(widths)
+    total = 0
+    for net_dict in ensemble:
+        for i, s in enumerate(species):
+            total = total + net_dict[syms[s]].double()(aev[i]).sum()
+    e_ref = total / len(ensemble) + sae[torch.tensor(species, dtype=torch.long)].sum()
+    for net_dict in ensemble:
+        net_dict.float()
+    assert abs(float(energy) - float(e_ref)) <= 5e-6 * abs(float(e_ref)) + 1e-4
+    e_ref.backward()
+    g_aev = aev.grad.float().numpy()
+    f_ref = oracle.backward(np.ascontiguousarray(g_aev[:, :112]), np.ascontiguousarray(g_aev[:, 112:]))
+    f = tpos.grad[0].cpu().numpy()
+    assert np.abs(f - f_ref).max() <= 2e-4 * np.abs(f_ref).max()
+    # buffers keep the reference's names
+    names = {k for k, _ in opt.neural_networks.named_buffers()}
+    assert {"0.layer0_weights", "0.layer6_biases"} <= names
