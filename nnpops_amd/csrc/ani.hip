@@ -78,6 +78,16 @@ struct KernelTimer {
     }
 };
 
+// Waves per workgroup for a per-atom kernel that needs `lds_wave` bytes of LDS per wave: the largest of
+// {4, 2, 1} that does not lower the number of waves a CU can hold (160 KiB LDS, 32 wave slots).
+int waves_per_group(size_t lds_wave) {
+    auto resident = [&](int wpg) { return (int)std::min<size_t>(32, (160 * 1024 / std::max<size_t>(1, lds_wave * wpg)) * wpg); };
+    int best = 1;
+    for (int wpg : {2, 4})
+        if (resident(wpg) >= resident(best)) best = wpg;
+    return best;
+}
+
 int pad_pow2(int n, int lo) {
     int p = lo;
     while (p < n) p <<= 1;
@@ -143,17 +153,21 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
     const size_t lds = forward ? ang_fwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB)
                                : ang_bwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, h->tile);
     if (lds > 160 * 1024)
-        return fail(NNPOPS_ERR_UNSUPPORTED, "angular kernel needs %zu bytes of LDS (> 160 KiB)", lds);
+        return fail(NNPOPS_ERR_UNSUPPORTED, "angular kernel needs %zu bytes of LDS per wave (> 160 KiB)", lds);
+    const int lds_wave = (int)((lds + 15) & ~(size_t)15);
+    const int wpg = waves_per_group(lds_wave);
+    const size_t lds_group = (size_t)lds_wave * wpg;
+    const dim3 grid(div_up(N, wpg)), block(64 * wpg);
     if (forward) {
         auto k = ani_angular_forward<TA, NFRP, NFZP>;
-        if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB,
-                           h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->debug);
+        if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
+        hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB,
+                           h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->debug, lds_wave);
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
-        if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lds, h->stream, h->d_params, h->cap, h->cap_angular, h->tile, h->d_recA,
-                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, out, h->debug);
+        if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
+        hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->tile, h->d_recA,
+                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, out, h->debug, lds_wave);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
@@ -296,53 +310,56 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
     const int N = h->hp.N;
     const bool per = h->hp.periodic;
-    // retain inputs for backprop (ANISymmetryFunctions.h:83-84)
-    NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_pos, positions, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, h->stream));
-    if (per) NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_box, box, sizeof(float) * 9, hipMemcpyDeviceToDevice, h->stream));
-    NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));
+    // What backprop needs from this call (ANISymmetryFunctions.h:83-84) is kept in the neighbour rows and
+    // records the builder writes (displacements, not positions), so positions and box are read in place:
+    // no copies, no memsets on the hot path.
 
     // neighbour search: cell grid for large systems, the reference's all-pairs scan for small ones
     // (or when a previous compute found the box too small for the 27-cell stencil)
-    const size_t lds_b = builder_lds_bytes(h->cap_angular, h->hp.S, h->hp.NB);
+    const int lds_bw = (int)((builder_lds_bytes(h->cap_angular, h->hp.S, h->hp.NB) + 15) & ~(size_t)15);
+    const int wpg_b = waves_per_group(lds_bw);
+    const size_t lds_b = (size_t)lds_bw * wpg_b;
+    const dim3 agrid(div_up(N, wpg_b)), ablock(64 * wpg_b);
     const bool use_cells = h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled);
     {
     KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
     if (use_cells) {
         const int tb = 256;
-        hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, h->stream, N, h->d_pos, h->d_box, (int)per, h->hp.rcr,
+        hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, h->stream, N, positions, box, (int)per, h->hp.rcr,
                            h->max_cells, h->d_grid, h->d_cell_count);
-        hipLaunchKernelGGL(assign_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid,
+        hipLaunchKernelGGL(assign_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, positions, h->d_grid,
                            h->d_cell_count, h->d_atom_cell, h->d_atom_rank);
         hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, h->stream, h->d_grid, h->d_cell_count, h->d_cell_start);
         hipLaunchKernelGGL(fill_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_grid, h->d_cell_start,
                            h->d_atom_cell, h->d_atom_rank, h->d_unsorted_atom);
-        hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid,
+        hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, positions, h->d_grid,
                            h->d_cell_start, h->d_atom_cell, h->d_unsorted_atom, h->d_species, h->d_sorted_atom,
                            h->d_sorted_pos);
         if (per)
-            hipLaunchKernelGGL(ani_neighbors_cells<true>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_box, h->d_grid,
+            hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw);
         else
-            hipLaunchKernelGGL(ani_neighbors_cells<false>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_box, h->d_grid,
+            hipLaunchKernelGGL(ani_neighbors_cells<false>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw);
     } else if (per)
-        hipLaunchKernelGGL(ani_neighbors_allpairs<true>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_pos, h->d_box,
+        hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri, h->d_cnt_a,
-                           h->d_cnt_ro);
+                           h->d_cnt_ro, lds_bw);
     else
-        hipLaunchKernelGGL(ani_neighbors_allpairs<false>, dim3(N), dim3(64), lds_b, h->stream, h->d_params, h->d_pos, h->d_box,
+        hipLaunchKernelGGL(ani_neighbors_allpairs<false>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri, h->d_cnt_a,
-                           h->d_cnt_ro);
+                           h->d_cnt_ro, lds_bw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
 
-    const size_t lds_r = 3 * (size_t)h->cap * sizeof(float);
+    const int lds_rw = (int)((3 * (size_t)h->cap * sizeof(float) + 15) & ~(size_t)15);
     {
     KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_FWD);
-    hipLaunchKernelGGL(ani_radial_forward, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_nbr, h->cap,
-                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial);
+    const int wpg_r = waves_per_group(lds_rw);
+    hipLaunchKernelGGL(ani_radial_forward, dim3(div_up(N, wpg_r)), dim3(64 * wpg_r), (size_t)lds_rw * wpg_r, h->stream, h->d_params, h->d_nbr, h->cap,
+                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial, lds_rw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
 
@@ -359,13 +376,16 @@ int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* 
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
     const int N = h->hp.N;
-    const size_t lds_r = ((size_t)h->hp.S * h->hp.nR + 8 * (size_t)h->cap) * sizeof(float);
+    const int lds_rw = (int)((((size_t)h->hp.S * h->hp.nR + 8 * (size_t)h->cap) * sizeof(float) + 15) & ~(size_t)15);
+    const int wpg_r = waves_per_group(lds_rw);
+    const size_t lds_r = (size_t)lds_rw * wpg_r;
     if (lds_r > 64 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "radial backward needs %zu bytes of LDS", lds_r);
+    const dim3 agrid(div_up(N, wpg_r)), ablock(64 * wpg_r);
     // radial backward owns position_deriv[i] (plain store) ...
     {
     KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD);
-    hipLaunchKernelGGL(ani_radial_backward, dim3(N), dim3(64), lds_r, h->stream, h->d_params, h->d_species, h->d_nbr, h->cap,
-                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, position_deriv);
+    hipLaunchKernelGGL(ani_radial_backward, agrid, ablock, lds_r, h->stream, h->d_params, h->d_species, h->d_nbr, h->cap,
+                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, position_deriv, lds_rw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     // ... and angular backward accumulates on top of it
@@ -381,6 +401,7 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
                        h->d_cnt_ro, h->cap, h->cap_angular, h->d_status);
     NNPOPS_HIP_TRY(hipGetLastError());
     NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));      // clean slate for the next build
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
     // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
     h->tile = std::min(32, std::max(8, (st[kStatMaxAngular] + 3) / 4 * 4));

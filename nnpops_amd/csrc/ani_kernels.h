@@ -160,7 +160,7 @@ __device__ __forceinline__ int build_bucket_offsets(int NB, const AtomGroups& G)
         carry += __shfl(incl, 63, 64);
     }
     if (lane == 0) G.boff[NB] = carry;
-    __syncthreads();
+    wave_fence();
     return carry;
 }
 
@@ -222,14 +222,14 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     const float rca = P->rca;
     for (int s = lane; s < S; s += 64) { G.gn[s] = 0; G.run[s] = 0; }
     for (int bk = lane; bk < NB; bk += 64) { G.ba[bk] = P->bkt_a[bk]; G.bb[bk] = P->bkt_b[bk]; }
-    __syncthreads();
+    wave_fence();
     for (int e = lane; e < n; e += 64) atomicAdd(&G.gn[__float_as_int(stage[e].w) >> kTagShift], 1);   // int LDS atomics
-    __syncthreads();
+    wave_fence();
     if (lane == 0) {
         int accum = 0;
         for (int s = 0; s < S; s++) { G.gs[s] = accum; accum += G.gn[s]; }
     }
-    __syncthreads();
+    wave_fence();
     for (int base = 0; base < n; base += 64) {
         const int e = base + lane;
         const bool valid = e < n;
@@ -241,9 +241,9 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
             const unsigned long long m = __ballot(valid && sp == s);
             if (m == 0) continue;                         // wave-uniform
             if (sp == s) rank = G.gs[s] + G.run[s] + prefix_popc(m);
-            __syncthreads();
+            wave_fence();
             if (lane == 0) G.run[s] += __popcll(m);
-            __syncthreads();
+            wave_fence();
         }
         if (valid) {
             const float r = sqrtf(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);
@@ -270,19 +270,21 @@ __host__ __device__ inline size_t builder_lds_bytes(int capA, int S, int NB) {
 // All-pairs scan (the reference's O(N^2) search, one wave per atom; used for small systems and for
 // boxes too small for the cell stencil).  Row order = ascending atom id.
 template <bool PERIODIC>
-__global__ __launch_bounds__(64) void ani_neighbors_allpairs(const AniParams* __restrict__ P,
+__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(const AniParams* __restrict__ P,
                                                              const float* __restrict__ pos,
                                                              const float* __restrict__ box,
                                                              const int* __restrict__ species, float4* __restrict__ nbr,
                                                              int cap, int capA, float4* __restrict__ recA,
                                                              float4* __restrict__ recB, int* __restrict__ tri,
-                                                             int* __restrict__ cnt_a, int* __restrict__ cnt_ro) {
+                                                             int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
+                                                             int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    float4* stage = (float4*)lds_raw;
+    float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     const AtomGroups G = carve_groups((int*)(stage + capA), P->S, P->NB);
-    const int i = blockIdx.x;
+    const int i = wave_global_id();
     const int lane = lane_id();
     const int N = P->N;
+    if (i >= N) return;
     const float rcr2 = P->rcr2, rca2 = P->rca2;
     Box b{};
     if (PERIODIC) b = load_box(box);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(64) void ani_neighbors_allpairs(const AniParams* __
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
-    __syncthreads();
+    wave_fence();
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
                      tri + (size_t)i * triples_capacity(capA), G);
 }
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(64) void ani_neighbors_allpairs(const AniParams* __
 // Cell-grid search (celllist.h): one wave per atom walks the 3x3x3 stencil of its cell; candidates
 // are read as coalesced float4 {x,y,z,(species<<24)|id} runs.  Row order = stencil order.
 template <bool PERIODIC>
-__global__ __launch_bounds__(64) void ani_neighbors_cells(const AniParams* __restrict__ P,
+__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const AniParams* __restrict__ P,
                                                           const float* __restrict__ box,
                                                           const CellGrid* __restrict__ grid,
                                                           const int* __restrict__ cell_start,
@@ -324,24 +326,26 @@ __global__ __launch_bounds__(64) void ani_neighbors_cells(const AniParams* __res
                                                           int cap, int capA, float4* __restrict__ recA,
                                                           float4* __restrict__ recB, int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
-                                                          int* __restrict__ status) {
+                                                          int* __restrict__ status, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    float4* stage = (float4*)lds_raw;
+    float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     const AtomGroups G = carve_groups((int*)(stage + capA), P->S, P->NB);
     const int lane = lane_id();
+    const int slot_id = wave_global_id();                  // position in cell order
+    if (slot_id >= P->N) return;
     const CellGrid g = *grid;
     if (!g.ok) {                                           // box too small for the stencil: tell the host
         if (lane == 0) {
-            if (blockIdx.x == 0) atomicOr(&status[kStatOverflow], 2);
-            cnt_a[blockIdx.x] = 0;                         // keep the consumers of this (void) build harmless
-            cnt_ro[blockIdx.x] = 0;
+            if (slot_id == 0) atomicOr(&status[kStatOverflow], 2);
+            cnt_a[slot_id] = 0;                            // keep the consumers of this (void) build harmless
+            cnt_ro[slot_id] = 0;
         }
         return;
     }
     const float rcr2 = P->rcr2, rca2 = P->rca2;
     Box b{};
     if (PERIODIC) b = load_box(box);
-    const float4 me = sorted_pos[blockIdx.x];
+    const float4 me = sorted_pos[slot_id];
     const int i = __float_as_int(me.w) & kIdMask;
     const int c = atom_cell[i];
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(64) void ani_neighbors_cells(const AniParams* __res
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
-    __syncthreads();
+    wave_fence();
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
                      tri + (size_t)i * triples_capacity(capA), G);
 }
@@ -378,12 +382,15 @@ __global__ __launch_bounds__(64) void ani_neighbors_cells(const AniParams* __res
 // =============================================================================================
 // Radial forward.  LDS: per-neighbour {r, fc, species}.
 // =============================================================================================
-__global__ __launch_bounds__(64) void ani_radial_forward(const AniParams* __restrict__ P,
+__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_forward(const AniParams* __restrict__ P,
                                                          const float4* __restrict__ nbr, int cap, int cap_angular,
                                                          const int* __restrict__ cnt_a,
-                                                         const int* __restrict__ cnt_ro, float* __restrict__ radial) {
-    extern __shared__ float lds[];
-    const int i = blockIdx.x, lane = lane_id();
+                                                         const int* __restrict__ cnt_ro, float* __restrict__ radial,
+                                                         int lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float* lds = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
+    const int i = wave_global_id(), lane = lane_id();
+    if (i >= P->N) return;
     const int S = P->S, nR = P->nR, width = S * nR;
     float* nb_r = lds;                       // [cap]
     float* nb_fc = nb_r + cap;               // [cap]
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(64) void ani_radial_forward(const AniParams* __rest
         nb_fc[e] = 0.5f * cospif(r / rcr) + 0.5f;
         nb_sp[e] = __float_as_int(rec.w) >> kTagShift;
     }
-    __syncthreads();
+    wave_fence();
 
     // lanes = (stream, k): KP = smallest power of two >= nR.  Each lane keeps one partial sum per
     // species in registers (select-accumulate), streams are folded with xor-shuffles at the end.
@@ -436,15 +443,17 @@ __global__ __launch_bounds__(64) void ani_radial_forward(const AniParams* __rest
 // =============================================================================================
 // Radial backward (owner computes; writes position_deriv[i], no atomics).      ref :228-263
 // =============================================================================================
-__global__ __launch_bounds__(64) void ani_radial_backward(const AniParams* __restrict__ P,
+__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const AniParams* __restrict__ P,
                                                           const int* __restrict__ species,
                                                           const float4* __restrict__ nbr, int cap, int cap_angular,
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
                                                           const float* __restrict__ radial_grad,
-                                                          float* __restrict__ pos_grad) {
-    extern __shared__ float lds[];
-    const int i = blockIdx.x, lane = lane_id();
+                                                          float* __restrict__ pos_grad, int lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float* lds = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
+    const int i = wave_global_id(), lane = lane_id();
+    if (i >= P->N) return;
     const int S = P->S, nR = P->nR, width = S * nR;
     float* g_own = lds;                       // [S*nR] this atom's gradient row
     float* nb_r = g_own + width;              // [cap]
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(64) void ani_radial_backward(const AniParams* __res
         nb_sp[e] = word >> kTagShift;
         nb_j[e] = word & kIdMask;
     }
-    __syncthreads();
+    wave_fence();
 
     int KP = 1;
     while (KP < nR) KP <<= 1;
@@ -588,21 +597,21 @@ __device__ __forceinline__ void row_add(float* dst, const float (&v)[NFZP]) {
 }
 
 template <bool TORCHANI, int NFRP, int NFZP>
-__global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __restrict__ P, int cap, int capA,
+__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const AniParams* __restrict__ P, int cap, int capA,
                                                           const float4* __restrict__ recA_g,
                                                           const float4* __restrict__ recB_g,
                                                           const int* __restrict__ tri_g,
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
-                                                          float* __restrict__ angular, int dbg) {
+                                                          float* __restrict__ angular, int dbg, int lds_per_wave) {
     using L = FwdLayout<NFRP, NFZP>;
     constexpr int CH = L::CH, NSTREAM = L::NSTREAM, SR = L::SR, BLK = L::BLK;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int i = blockIdx.x, lane = lane_id();
+    const int i = wave_global_id(), lane = lane_id();
     const int NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
-    if (dbg & 32) return;                                  // ablation: launch + dispatch floor
+    if (i >= P->N || (dbg & 32)) return;                   // (dbg & 32: ablation, launch + dispatch floor)
 
-    char* cursor = lds_raw;
+    char* cursor = lds_raw + (size_t)wave_in_group() * lds_per_wave;
     float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float* row = (float*)cursor;          cursor += (size_t)(NB + 1) * BLK * sizeof(float);
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
         zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
         zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
     }
-    __syncthreads();
+    wave_fence();
 
     const int a2 = lane & (NFRP - 1), stream = lane / NFRP;
     for (int base = 0; base < T; base += 64) {
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
         word = next_word;
         const int b0 = __shfl(bucket, 0, 64);
         const bool uniform = __all(bucket == b0);          // implies all 64 lanes hold a triple
-        __syncthreads();
+        wave_fence();
         // ---------------- phase 2: lane = (stream, a) ----------------
         const float* srcR = facR + stream * SR + a2;
         if (dbg & 2) {
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(64) void ani_angular_forward(const AniParams* __res
             row_add<NFZP>(row + (head_ends_here ? hb : NB) * BLK + a2 * NFZP, total);
             row_add<NFZP>(row + (tail_ends_here ? tb : NB) * BLK + a2 * NFZP, acc);
         }
-        __syncthreads();
+        wave_fence();
     }
 
     // ---------------- epilogue: canonical LDS row -> reference column order, coalesced rows ----------------
@@ -901,21 +910,22 @@ __device__ __forceinline__ void triple_forces(const float4& A, const float4& A2,
 }
 
 template <bool TORCHANI, int NFRP, int NFZP>
-__global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __restrict__ P, int cap, int capA, int tile,
+__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(const AniParams* __restrict__ P, int cap, int capA, int tile,
                                                            const float4* __restrict__ recA_g,
                                                            const float4* __restrict__ recB_g,
                                                            const int* __restrict__ tri_g,
                                                            const int* __restrict__ cnt_a,
                                                            const int* __restrict__ cnt_ro,
                                                            const float* __restrict__ angular_grad,
-                                                           float* __restrict__ pos_grad, int dbg) {
+                                                           float* __restrict__ pos_grad, int dbg, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int i = blockIdx.x, lane = lane_id();
+    const int i = wave_global_id(), lane = lane_id();
     const int S = P->S, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
     constexpr int BLK = NFRP * NFZP;
     const int tstride = tile + 1;
+    if (i >= P->N) return;
 
-    char* cursor = lds_raw;
+    char* cursor = lds_raw + (size_t)wave_in_group() * lds_per_wave;
     float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float* facc = (float*)cursor;         cursor += (size_t)capA * 4 * sizeof(float);   // per-slot force accumulators
@@ -957,7 +967,7 @@ __global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __re
             }
         } else {
             for (int q = lane; q < NB * BLK; q += 64) grow[q] = 0.f;
-            __syncthreads();
+            wave_fence();
             for (int bk = 0; bk < NB; bk++)
                 for (int m = lane; m < nA; m += 64) grow[bk * BLK + P->c_of_m[m]] = g[bk * nA + m] * P->scale_m[m];
         }
@@ -979,7 +989,7 @@ __global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __re
         zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
         zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
     }
-    __syncthreads();
+    wave_fence();
 
     if (n <= tile) {
         // ---------------- common case: one tile, triples from the builder's list ----------------
@@ -996,7 +1006,7 @@ __global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __re
             }
             word = next_word;
         }
-        __syncthreads();
+        wave_fence();
         // row sums: lane (e, half) adds up to 16 columns of row e; halves folded by one shuffle
         const int e = lane & 31, half = lane >> 5;
         float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -1015,7 +1025,7 @@ __global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __re
         }
         fx += __shfl_xor(fx, 32, 64); fy += __shfl_xor(fy, 32, 64); fz += __shfl_xor(fz, 32, 64);
         if (half == 0 && e < n) { facc[e * 4] = fx; facc[e * 4 + 1] = fy; facc[e * 4 + 2] = fz; }
-        __syncthreads();
+        wave_fence();
     } else {
         // ---------------- an atom larger than the pair matrix: tile pairs ----------------
         const int nblk = (n + tile - 1) / tile;
@@ -1045,7 +1055,7 @@ __global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __re
                             Mx[ql * tstride + pl] = Fq[0]; My[ql * tstride + pl] = Fq[1]; Mz[ql * tstride + pl] = Fq[2];
                         }
                     }
-                    __syncthreads();
+                    wave_fence();
                     const int e = lane & 31, half = lane >> 5;
                     const int rows = (diag || pass == 0) ? np : nq;
                     const int cols = diag ? np : (pass == 0 ? nq : np);
@@ -1062,7 +1072,7 @@ __global__ __launch_bounds__(64) void ani_angular_backward(const AniParams* __re
                         const int slot = ((diag || pass == 0) ? p0 : q0) + e;
                         facc[slot * 4] += fx; facc[slot * 4 + 1] += fy; facc[slot * 4 + 2] += fz;
                     }
-                    __syncthreads();
+                    wave_fence();
                 }
             }
         }
