@@ -73,7 +73,11 @@ def main():
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
+    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv"],
+                    help="aev: the headline metric (default); cfconv: BASELINE config 3 (side measurement, same JSON shape)")
     args = ap.parse_args()
+    if args.workload == "cfconv":
+        return main_cfconv(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,6 +172,82 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_cfconv(args):
+    """BASELINE config 3: CFConv + CFConvNeighbors, W=128, G=50, 5 A cutoff, 10 000-atom periodic box.
+    One step = neighbour build + forward + backward.  Side measurement (not the headline metric)."""
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    n, W, G, cutoff, sigma = args.atoms, 128, 50, 5.0, 0.1
+    pos, _, box = workloads.random_box(n, density=0.1, seed=3)
+    rng = np.random.default_rng(4)
+    w1 = (0.1 * rng.standard_normal((W, G))).astype(np.float32)
+    w2 = (0.1 * rng.standard_normal((W, W))).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(W)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(W)).astype(np.float32)
+    x = rng.standard_normal((n, W)).astype(np.float32)
+    gy = rng.standard_normal((n, W)).astype(np.float32)
+    nb = CFConvNeighbors(n, cutoff, periodic=True, device=local_rank)
+    cf = CFConv(n, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True, device=local_rank)
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    tx, tg = torch.tensor(x, device=dev), torch.tensor(gy, device=dev)
+    out = torch.empty_like(tx)
+    nb.build(tpos, tbox, check=True)
+    pairs = nb.num_pairs()
+
+    def step():
+        nb.build(tpos, tbox, check=False)
+        cf.compute(nb, tpos, tx, tbox, out)
+        return cf.backprop(nb, tpos, tx, tg, tbox)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    t0 = time.perf_counter()
+    tb = tf = tbw = 0.0
+    for _ in range(args.steps):
+        ev[0].record(); nb.build(tpos, tbox, check=False)
+        ev[1].record(); cf.compute(nb, tpos, tx, tbox, out)
+        ev[2].record(); cf.backprop(nb, tpos, tx, tg, tbox)
+        ev[3].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # per-phase times of the last step (events are re-recorded each iteration)
+    tb, tf, tbw = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    flops_fwd = 2.0 * (G * W + W * W) * pairs            # SURVEY s8(d): per half pair
+    out_json = {
+        "metric": "CFConv build+forward+backward evaluations/sec, W=128 G=50 cutoff 5 A, 10k-atom periodic box",
+        "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"SchNet CFConv + neighbour list, {n} atoms periodic, W={W}, G={G}, cutoff {cutoff} A, ssp",
+                   "half_pairs": pairs},
+        "phases_ms": {"build": round(tb, 4), "forward": round(tf, 4), "backward": round(tbw, 4)},
+        "roofline": {"bound": "mfma", "kernel": "cfconv_forward", "achieved": round(flops_fwd / (tf * 1e-3) / 1e12, 3),
+                     "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops_fwd / (tf * 1e-3) / 1e12 / 157.3, 5), "traffic": None,
+                     "note": "algorithmic flops (half-pair count) / measured forward time; fp32 matrix peak"},
+    }
+    if not args.no_cpu_baseline:
+        import oracle
+        kind = "reference" if oracle.have_ref() else "port"
+        NB, CF = (oracle.RefCFConvNeighbors, oracle.RefCFConv) if kind == "reference" else (oracle.CFConvNeighborsOracle, oracle.CFConvOracle)
+        m = 2000                                        # bounded sample: the first 2000 atoms' worth of work scales ~linearly
+        pos_s, _, box_s = workloads.random_box(m, density=0.1, seed=3)
+        onb = NB(m, cutoff, True)
+        ocf = CF(m, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True)
+        t1 = time.perf_counter()
+        onb.build(pos_s, box_s)
+        y = ocf.forward(onb, pos_s, x[:m], box_s)
+        ocf.backward(onb, pos_s, x[:m], gy[:m], box_s)
+        dt = time.perf_counter() - t1
+        out_json["cpu_baseline"] = {"value": round(1.0 / dt * m / n, 5), "unit": "evals/s", "cores": 1, "kind": kind,
+                                    "sample": f"one build+fwd+bwd of a {m}-atom box of the same density ({dt:.1f} s), scaled by "
+                                              f"{m}/{n} atoms (pair count is linear in N at fixed density)"}
+    print(json.dumps(out_json), flush=True)
 
 
 if __name__ == "__main__":
