@@ -152,6 +152,13 @@ def main():
         nb_na = sym.angular_width
         alg_bytes = {"angular_forward": n * 16 + n * nb_na * 4, "angular_backward": n * nb_na * 4 + n * 12}
         achieved = alg_bytes[dominant] / kern[dominant] / 1e9
+        traffic = None                                           # HBM bytes/launch from the committed PMC passes
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("atoms") == n:
+                traffic = tj.get(dominant)
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "AEV+forces evaluations/sec (ANI-2x symmetry functions, energy+gradient), 10k-atom periodic box",
             "value": round(value, 3), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,7 +170,7 @@ def main():
                        "atoms": n, "frames_per_gpu": 1, "max_neighbors_rcr": max_row, "max_neighbors_rca": max_ang},
             "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes[dominant]},
         }
         if not args.no_cpu_baseline:
