@@ -73,11 +73,14 @@ def main():
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
-    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv"],
-                    help="aev: the headline metric (default); cfconv: BASELINE config 3 (side measurement, same JSON shape)")
+    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv", "conformers"],
+                    help="aev: the headline metric (default); cfconv: BASELINE config 3; conformers: BASELINE config 4 "
+                         "(side measurements, same JSON shape)")
     args = ap.parse_args()
     if args.workload == "cfconv":
         return main_cfconv(args)
+    if args.workload == "conformers":
+        return main_conformers(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -176,6 +179,84 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, species, box, rf, af)
         print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_conformers(args):
+    """BASELINE config 4: ANI-2x AEV forward+backward on 1 024 independent ~60-atom conformers, sharded over
+    the ranks by contiguous blocks of the batch (strong scaling: total work is fixed).  Each rank evaluates its
+    block with ONE batched handle (nnpops_ani_set_molecules); the only collective is the final all_gather of the
+    per-atom forces (RCCL over xGMI; ~0.74 MB in total)."""
+    from nnpops_amd.parallel import gather_rows, shard_molecules
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    B = 1024
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(50, 71, size=B).tolist()
+    blocks = shard_molecules(sizes, world)
+    offsets_all = np.concatenate([[0], np.cumsum(sizes)])
+    rows = [int(offsets_all[hi] - offsets_all[lo]) for lo, hi in blocks]
+    lo, hi = blocks[rank]
+    mols = [workloads.conformer(sizes[m], seed=1000 + m) for m in range(lo, hi)]
+    pos = np.concatenate([m[0] for m in mols]).astype(np.float32)
+    species = np.concatenate([m[1] for m in mols]).astype(np.int32)
+    offsets = (offsets_all[lo:hi + 1] - offsets_all[lo]).astype(np.int32)
+    rf, af = workloads.ani2x_functions()
+    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, device=local_rank)
+    sym.set_molecules(offsets)
+    n = pos.shape[0]
+    tpos = torch.tensor(pos, device=dev)
+    radial = torch.empty((n, sym.radial_width), device=dev)
+    angular = torch.empty((n, sym.angular_width), device=dev)
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    g_rad = torch.randn(radial.shape, device=dev, generator=gen)
+    g_ang = torch.randn(angular.shape, device=dev, generator=gen)
+    grad = torch.empty((n, 3), device=dev)
+
+    def step():
+        sym.compute(tpos, None, radial, angular, check=False)
+        sym.backprop(g_rad, g_ang, grad)
+        return gather_rows(grad, rows) if dist else grad
+
+    sym.compute(tpos, None, radial, angular, check=True)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        forces = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert forces.shape[0] == int(offsets_all[-1]) and bool(torch.isfinite(forces).all())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "AEV+forces evaluations/sec of a 1024-conformer batch (ANI-2x, ~60 atoms each)",
+            "value": round(args.steps / elapsed, 3), "unit": "batch evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ANI-2x AEV forward+backward, 1024 independent conformers of 50-70 atoms, contiguous batch "
+                                   "blocks per GPU, one all_gather of the forces per step", "conformers": B,
+                       "atoms_total": int(offsets_all[-1]), "atoms_this_rank": n}}), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

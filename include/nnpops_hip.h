@@ -87,6 +87,14 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
  * algorithm, O(N^2)), 2 = cell list (O(N); periodic boxes must be at least 3 cells wide per axis). */
 int nnpops_ani_set_neighbor_algorithm(nnpops_ani_t h, int algorithm);
 
+/* Batched evaluation of independent NON-PERIODIC molecules in one handle (the reference has no batch
+ * dimension: src/pytorch/SymmetryFunctions.py:110; this is the additive API SURVEY.md s8f ranks second).
+ * Atoms [molecule_offsets[m], molecule_offsets[m+1]) form molecule m (host array, num_molecules+1 entries,
+ * first 0, last num_atoms); atoms of different molecules never see each other.  compute()/backprop() are
+ * unchanged -- every kernel is per atom -- so one launch sequence evaluates the whole batch.
+ * num_molecules <= 0 restores the single-system behaviour. */
+int nnpops_ani_set_molecules(nnpops_ani_t h, int num_molecules, const int32_t* molecule_offsets);
+
 /* Per-kernel timing with HIP events recorded on the handle's stream around every kernel launch
  * (off by default; not for use during graph capture).  get_timing blocks on the stream, returns for
  * each kernel id the summed duration in milliseconds and the number of launches since the last

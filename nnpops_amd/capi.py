@@ -35,6 +35,7 @@ SIGNATURES = {
     "nnpops_ani_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_ani_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nnpops_ani_set_neighbor_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
+    "nnpops_ani_set_molecules": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "nnpops_ani_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
@@ -140,6 +141,15 @@ class AniSymmetryFunctions:
         if h:
             self._lib.nnpops_ani_destroy(h)
             self._h = None
+
+    def set_molecules(self, molecule_offsets):
+        """Treat the handle's atoms as a batch of independent non-periodic molecules:
+        atoms [offsets[m], offsets[m+1]) belong to molecule m (None restores one system)."""
+        if molecule_offsets is None:
+            _check(self._lib.nnpops_ani_set_molecules(self._h, 0, None))
+            return
+        off = np.ascontiguousarray(molecule_offsets, dtype=np.int32)
+        _check(self._lib.nnpops_ani_set_molecules(self._h, int(off.shape[0]) - 1, off.ctypes.data_as(C.c_void_p)))
 
     def set_neighbor_algorithm(self, algorithm):
         _check(self._lib.nnpops_ani_set_neighbor_algorithm(self._h, int(algorithm)))

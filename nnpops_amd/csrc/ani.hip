@@ -23,6 +23,7 @@ struct nnpops_ani {
     int algorithm = 0;              // 0 auto, 1 all-pairs, 2 cell list
     // device state
     int32_t* d_species = nullptr;
+    int2* d_segment = nullptr;      // [N] per-atom [lo, hi) of its molecule (batched handles only)
     float* d_pos = nullptr;         // [N][3] positions of the last compute()
     float* d_box = nullptr;         // [9]
     float4* d_nbr = nullptr;        // [N][cap] records {dx, dy, dz, (species<<24)|atom}
@@ -277,7 +278,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
 int nnpops_ani_destroy(nnpops_ani_t h) {
     if (!h) return NNPOPS_OK;
     DeviceGuard guard(h->device);
-    dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_pos); dev_free(h->d_box);
+    dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_segment); dev_free(h->d_pos); dev_free(h->d_box);
     dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
     dev_free(h->d_atom_rank); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
@@ -292,6 +293,29 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
 int nnpops_ani_set_stream(nnpops_ani_t h, void* stream) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
     h->stream = (hipStream_t)stream;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_set_molecules(nnpops_ani_t h, int num_molecules, const int32_t* molecule_offsets) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    DeviceGuard guard(h->device);
+    if (num_molecules <= 0 || molecule_offsets == nullptr) {     // back to one system
+        dev_free(h->d_segment);
+        h->computed = false;
+        return NNPOPS_OK;
+    }
+    NNPOPS_REQUIRE(!h->hp.periodic, "batched molecules are non-periodic systems");
+    NNPOPS_REQUIRE(molecule_offsets[0] == 0 && molecule_offsets[num_molecules] == h->hp.N,
+                   "molecule_offsets must start at 0 and end at num_atoms (%d)", h->hp.N);
+    std::vector<int2> seg(h->hp.N);
+    for (int m = 0; m < num_molecules; m++) {
+        NNPOPS_REQUIRE(molecule_offsets[m] < molecule_offsets[m + 1], "molecule %d is empty or offsets are not increasing", m);
+        for (int i = molecule_offsets[m]; i < molecule_offsets[m + 1]; i++) seg[i] = int2{molecule_offsets[m], molecule_offsets[m + 1]};
+    }
+    int rc;
+    if (!h->d_segment && (rc = dev_alloc(&h->d_segment, (size_t)h->hp.N))) return rc;
+    NNPOPS_HIP_TRY(hipMemcpy(h->d_segment, seg.data(), sizeof(int2) * seg.size(), hipMemcpyHostToDevice));
+    h->computed = false;
     return NNPOPS_OK;
 }
 
@@ -320,7 +344,7 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     const int wpg_b = waves_per_group(lds_bw);
     const size_t lds_b = (size_t)lds_bw * wpg_b;
     const dim3 agrid(div_up(N, wpg_b)), ablock(64 * wpg_b);
-    const bool use_cells = h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled);
+    const bool use_cells = !h->d_segment && (h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled));
     {
     KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
     if (use_cells) {
@@ -345,12 +369,12 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
                                h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw);
     } else if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
-                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri, h->d_cnt_a,
-                           h->d_cnt_ro, lds_bw);
+                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_cnt_a, h->d_cnt_ro, lds_bw);
     else
         hipLaunchKernelGGL(ani_neighbors_allpairs<false>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
-                           h->d_species, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri, h->d_cnt_a,
-                           h->d_cnt_ro, lds_bw);
+                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_cnt_a, h->d_cnt_ro, lds_bw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
 

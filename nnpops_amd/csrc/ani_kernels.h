@@ -273,7 +273,9 @@ template <bool PERIODIC>
 __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(const AniParams* __restrict__ P,
                                                              const float* __restrict__ pos,
                                                              const float* __restrict__ box,
-                                                             const int* __restrict__ species, float4* __restrict__ nbr,
+                                                             const int* __restrict__ species,
+                                                             const int2* __restrict__ segment,   // per-atom [lo, hi) or NULL
+                                                             float4* __restrict__ nbr,
                                                              int cap, int capA, float4* __restrict__ recA,
                                                              float4* __restrict__ recB, int* __restrict__ tri,
                                                              int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
@@ -290,13 +292,15 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     if (PERIODIC) b = load_box(box);
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
     float4* row = nbr + (size_t)i * cap;
+    // batched molecules: an atom only sees the atoms of its own molecule (independent systems in one handle)
+    const int lo = segment ? segment[i].x : 0, hi = segment ? segment[i].y : N;
     int na = 0, nro = 0;
-    for (int base = 0; base < N; base += 64) {
+    for (int base = lo; base < hi; base += 64) {
         const int j = base + lane;
         bool in_r = false, in_a = false;
         int word = 0;
         float dx = 0.f, dy = 0.f, dz = 0.f;
-        if (j < N && j != i) {
+        if (j < hi && j != i) {
             word = j | (species[j] << kTagShift);
             dx = pos[3 * j] - xi; dy = pos[3 * j + 1] - yi; dz = pos[3 * j + 2] - zi;
             min_image<PERIODIC>(dx, dy, dz, b);

@@ -1,0 +1,44 @@
+"""Batch sharding over GPUs (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The hot path shards only over independent molecules / frames: every rank owns a
+contiguous block of the batch, evaluates it with no communication, and the results (per-atom
+forces, per-molecule energies) are assembled with ONE all_gather at the end.  There is no
+all-reduce anywhere, so the per-link xGMI ring bound never binds; the gather is latency-bound.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+def shard_molecules(sizes: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Contiguous blocks of molecule indices, one per rank, balanced by atom count (the cost of an
+    AEV evaluation is linear in atoms at fixed density).  Returns [(lo, hi)] * world; blocks may be
+    empty only when there are fewer molecules than ranks."""
+    total = float(sum(sizes))
+    bounds, acc, lo = [], 0.0, 0
+    n = len(sizes)
+    for r in range(world):
+        target = total * (r + 1) / world
+        hi = lo
+        while hi < n and (acc + sizes[hi] <= target + 1e-9 or hi == lo and n - hi >= world - r):
+            acc += sizes[hi]
+            hi += 1
+        if r == world - 1:
+            hi = n
+        bounds.append((lo, hi))
+        lo = hi
+    return bounds
+
+
+def gather_rows(local: torch.Tensor, rows_per_rank: Sequence[int], group=None) -> torch.Tensor:
+    """all_gather of per-rank blocks with different row counts: [rows_r, ...] -> [sum rows, ...].
+    One collective on a padded buffer (the message is small: 0.74 MB for 1024 conformers)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    width = max(rows_per_rank)
+    padded = local.new_zeros((width,) + tuple(local.shape[1:]))
+    padded[: local.shape[0]] = local
+    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, padded, group=group)
+    parts = [out[r * width: r * width + rows_per_rank[r]] for r in range(world)]
+    return torch.cat(parts, dim=0)

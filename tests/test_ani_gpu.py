@@ -140,3 +140,33 @@ def test_backprop_uses_last_compute():
     oracle.forward(pos2)
     g_ref = oracle.backward(wr.cpu().numpy(), wa.cpu().numpy())
     assert np.abs(g - g_ref).max() <= FORCE_RTOL * np.abs(g_ref).max()
+
+
+def test_batched_molecules_match_per_molecule_oracle():
+    """BASELINE config 4 in miniature: a batch of independent conformers evaluated by ONE handle
+    (nnpops_ani_set_molecules) must equal the oracle run molecule by molecule, even when the molecules
+    overlap in space (they are independent systems, not a cluster)."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    rng = np.random.default_rng(11)
+    sizes = rng.integers(20, 70, size=24)
+    mols = [workloads.conformer(int(n), seed=100 + k) for k, n in enumerate(sizes)]
+    pos = np.concatenate([m[0] for m in mols]).astype(np.float32)
+    species = np.concatenate([m[1] for m in mols]).astype(np.int32)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    dev = torch.device("cuda:0")
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af)
+    sym.set_molecules(offsets)
+    radial, angular = sym.compute(torch.tensor(pos, device=dev))
+    wr = rng.standard_normal(tuple(radial.shape)).astype(np.float32)
+    wa = rng.standard_normal(tuple(angular.shape)).astype(np.float32)
+    grad = sym.backprop(torch.tensor(wr, device=dev), torch.tensor(wa, device=dev)).cpu().numpy()
+    r, a = radial.cpu().numpy(), angular.cpu().numpy()
+    for k in range(len(sizes)):
+        lo, hi = offsets[k], offsets[k + 1]
+        o = AniOracle(7, 5.1, 3.5, species[lo:hi], rf, af)
+        r_ref, a_ref = o.forward(pos[lo:hi])
+        np.testing.assert_allclose(r[lo:hi], r_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
+        np.testing.assert_allclose(a[lo:hi], a_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
+        g_ref = o.backward(np.ascontiguousarray(wr[lo:hi]), np.ascontiguousarray(wa[lo:hi]))
+        assert np.abs(grad[lo:hi] - g_ref).max() <= FORCE_RTOL * np.abs(g_ref).max()

@@ -1,0 +1,55 @@
+"""Batch sharding helpers, exercised with a real 2-process gloo group on CPU."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nnpops_amd.parallel import gather_rows, shard_molecules
+
+
+def test_shard_molecules_is_a_balanced_partition():
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(50, 71, size=1024).tolist()
+    for world in (1, 2, 3, 4, 8):
+        blocks = shard_molecules(sizes, world)
+        assert blocks[0][0] == 0 and blocks[-1][1] == 1024
+        assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        loads = [sum(sizes[lo:hi]) for lo, hi in blocks]
+        assert max(loads) - min(loads) <= 2 * 70
+    assert shard_molecules([10, 10], 4)[-1][1] == 2          # fewer molecules than ranks: still a partition
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, sizes, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blocks = shard_molecules(sizes, world)
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    rows = [int(offsets[hi] - offsets[lo]) for lo, hi in blocks]
+    lo, hi = blocks[rank]
+    # "forces" of my molecules: row index encoded in the values so the assembly can be checked
+    mine = torch.arange(offsets[lo], offsets[hi], dtype=torch.float32).unsqueeze(1).repeat(1, 3)
+    full = gather_rows(mine, rows)
+    torch.save(full, os.path.join(result_dir, f"full_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rows_gloo_world2(tmp_path):
+    sizes = [5, 7, 3, 9, 4, 6, 8]
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, sizes, str(tmp_path)), nprocs=2, join=True)
+    expect = torch.arange(sum(sizes), dtype=torch.float32).unsqueeze(1).repeat(1, 3)
+    for rank in range(2):
+        assert torch.equal(torch.load(tmp_path / f"full_{rank}.pt"), expect)
