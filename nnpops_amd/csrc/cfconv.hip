@@ -25,6 +25,7 @@
 //     from an all-pairs scan for small systems.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -356,6 +357,121 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA forward: the two dense layers of the filter network as 16x16x4 fp32 matrix-core tiles.
+//
+// `v_mfma_f32_16x16x4_f32` is exact fp32 (an fmaf chain) at the fp32 matrix rate.  A tile is 16 pairs of
+// ONE atom (owner computes, as above) x all W = 16*NCB filters; lane l owns pair/row `l & 15` as the A
+// operand and column `l & 15` of each 16-wide column block as the B operand and result, k = 4*step + (l >> 4):
+//   layer 1  A = Gaussians (computed in registers, straight in operand layout: no redundancy),
+//            B = W1^T from LDS, C initialised with b1;  activation on the accumulators -> Y1 tile in LDS
+//   layer 2  A = Y1 tile read back transposed (row stride W+1: conflict-free), B = W2^T from LDS, C = b2
+//   output   acc[row][col] * fc[row] * x[j_row][col] summed over the tile's rows in registers.
+// Result layout of the instruction: D[row = 4*(l >> 4) + reg][col = l & 15].
+// ---------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__host__ __device__ inline size_t mfma_weight_floats(int W, int G) { return (size_t)W * W + (size_t)((G + 3) & ~3) * W; }
+__host__ __device__ inline size_t mfma_wave_floats(int W) { return (size_t)16 * (W + 1) + 64; }
+
+template <int ACT, int NCB>
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
+    ConvParams P, const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
+    const float* __restrict__ b2, const float4* __restrict__ rows, const int* __restrict__ cnt, int cap,
+    const float* __restrict__ x, float* __restrict__ out) {
+    constexpr int W = NCB * 16, YS = W + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = P.G, Gp = (G + 3) & ~3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    float* s_w2t = lds;                                    // [W][W]
+    float* s_w1t = s_w2t + (size_t)W * W;                  // [Gp][W], rows >= G are zero
+    float* y1 = s_w1t + (size_t)Gp * W + (size_t)wave * mfma_wave_floats(W);   // [16][YS]
+    float* ps = y1 + 16 * YS;                              // r[16] | fc[16] | j[16] (bit pattern)
+    for (int q = tid; q < W * W; q += blockDim.x) s_w2t[q] = w2t[q];
+    for (int q = tid; q < Gp * W; q += blockDim.x) s_w1t[q] = q < G * W ? w1t[q] : 0.f;
+    __syncthreads();
+
+    const int col = lane & 15, grp = lane >> 4;
+    float b1v[NCB], b2v[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { b1v[cb] = b1[cb * 16 + col]; b2v[cb] = b2[cb * 16 + col]; }
+    const float mu_step = P.cutoff / (float)(G - 1);
+    const float gscale = -0.5f * kLog2e * P.sigma_inv * P.sigma_inv;       // exp(-x^2/2) = exp2(gscale * (r - mu)^2)
+
+    for (int i = blockIdx.x * waves_per_block + wave; i < P.N; i += gridDim.x * waves_per_block) {
+        const int n = min(cnt[i], cap);
+        const float4* row = rows + (size_t)i * cap;
+        float oacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) oacc[cb] = 0.f;
+        for (int t0 = 0; t0 < n; t0 += 16) {
+            const int np = min(16, n - t0);
+            if (lane < 16) {
+                float r = 1.0f, fc = 0.f;
+                int j = i;
+                if (lane < np) {
+                    const float4 rec = row[t0 + lane];
+                    r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+                    fc = 0.5f * cospif(r / P.cutoff) + 0.5f;                            // ref :301-303
+                    j = __float_as_int(rec.w) & kIdMask;
+                }
+                ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = __int_as_float(j);
+            }
+            wave_fence();
+            // inputs of my four result rows, requested now so that the two GEMMs hide the latency
+            float xv[NCB][4], fcq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int rr = grp * 4 + q;
+                const int j = __float_as_int(ps[32 + rr]);
+                fcq[q] = ps[16 + rr];
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) xv[cb][q] = x[(size_t)j * W + cb * 16 + col];
+            }
+            // ---- layer 1 ----
+            f32x4 acc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b1v[cb], b1v[cb], b1v[cb], b1v[cb]};
+            const float rp = ps[col];
+            for (int s = 0; s < Gp / 4; s++) {
+                const int g = 4 * s + grp;
+                const float d = rp - (float)g * mu_step;
+                const float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                   // ref :151-154
+                const float* wrow = s_w1t + g * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) y1[(grp * 4 + q) * YS + cb * 16 + col] = activate<ACT>(acc[cb][q]);
+            wave_fence();
+            // ---- layer 2 ----
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+            for (int s = 0; s < W / 4; s++) {
+                const int k = 4 * s + grp;
+                const float a = y1[col * YS + k];
+                const float* wrow = s_w2t + k * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) oacc[cb] += fcq[q] * acc[cb][q] * xv[cb][q];      // ref :175, :181
+            wave_fence();
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            float v = oacc[cb];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (grp == 0) out[(size_t)i * W + cb * 16 + col] = v;
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -390,6 +506,7 @@ struct nnpops_cfconv {
     hipStream_t stream = nullptr;
     float *d_w1t = nullptr, *d_b1 = nullptr, *d_w2t = nullptr, *d_b2 = nullptr;
     int blocks = 256;
+    bool force_valu = false;        // $NNPOPS_CFCONV_VALU=1: keep the matrix cores out (A/B timing, debugging)
 };
 
 extern "C" {
@@ -583,6 +700,7 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
         return cleanup(fail(NNPOPS_ERR_HIP, "weight upload failed"));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->blocks = prop.multiProcessorCount;
+    if (const char* e = std::getenv("NNPOPS_CFCONV_VALU")) h->force_valu = std::atoi(e) != 0;
     *out = h;
     return NNPOPS_OK;
 }
@@ -624,8 +742,44 @@ int launch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, c
     return NNPOPS_OK;
 }
 
+template <int ACT, int NCB>
+int launch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, float* out) {
+    const size_t budget = 156 * 1024 / sizeof(float);
+    const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats(h->p.W);
+    const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
+    const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
+    auto k = cfconv_forward_mfma<ACT, NCB>;
+    if (lds > 64 * 1024)
+        NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int blocks = std::max(1, std::min(h->blocks, div_up(h->p.N, wpb)));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1t, h->d_b1, h->d_w2t, h->d_b2,
+                       nb->d_rows, nb->d_cnt, nb->cap, x, out);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+// widths that are a multiple of 16 take the matrix-core forward path
+template <int ACT>
+int dispatch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, float* out, bool& handled) {
+    handled = true;
+    switch (h->p.W) {
+        case 16:  return launch_forward_mfma<ACT, 1>(h, nb, x, out);
+        case 32:  return launch_forward_mfma<ACT, 2>(h, nb, x, out);
+        case 64:  return launch_forward_mfma<ACT, 4>(h, nb, x, out);
+        case 96:  return launch_forward_mfma<ACT, 6>(h, nb, x, out);
+        case 128: return launch_forward_mfma<ACT, 8>(h, nb, x, out);
+        default: handled = false; return NNPOPS_OK;
+    }
+}
+
 template <bool BWD>
 int dispatch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out, float* pos_grad) {
+    if (!BWD && !h->force_valu) {
+        bool handled = false;
+        const int rc = h->p.activation == 0 ? dispatch_forward_mfma<0>(h, nb, x, out, handled)
+                                            : dispatch_forward_mfma<1>(h, nb, x, out, handled);
+        if (handled) return rc;
+    }
     const bool two = h->p.W > 64;
     if (h->p.activation == 0)
         return two ? launch_conv<0, 2, BWD>(h, nb, x, gout, out, pos_grad) : launch_conv<0, 1, BWD>(h, nb, x, gout, out, pos_grad);
