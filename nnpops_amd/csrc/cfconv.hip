@@ -14,13 +14,12 @@
 //     out[i] (and, backward, dE/dx[i] and dE/dpos[i]) in registers -- no atomics, no scatter,
 //     deterministic.  Every pair is therefore evaluated from both ends; the filter network is the
 //     same function of r on either side, so this doubles its flops in exchange for removing
-//     2W atomics per pair and all cross-wave traffic.  (An MFMA pair-tile version with a half list is
-//     the planned next step; see DESIGN.md.)
-//   * one wave per atom, lane = filter channel(s) (W <= 128: up to two per lane); 8 waves per
-//     workgroup share the transposed weight matrices in LDS (W2^T is 64 KB at W = 128), loaded once
-//     per persistent workgroup.
-//   * pairs are processed 8 at a time: every weight read from LDS feeds 8 (x2 channels) FMAs, which
-//     moves the kernel from LDS-bound to VALU-bound.
+//     2W atomics per pair and all cross-wave traffic.
+//   * widths that are a multiple of 16 (16 ... 128: every SchNet in use) run the two dense layers on the
+//     MATRIX CORES: 16 pairs of one atom x W filters per tile, v_mfma_f32_16x16x4_f32 (exact fp32),
+//     weights resident in LDS, 8 waves per CU (cfconv_forward_mfma / cfconv_backward_mfma below).
+//   * other widths use the vector kernel: one wave per atom, lane = filter channel(s) (up to two per
+//     lane), pairs processed 8 at a time so every weight read from LDS feeds 8 (x2 channels) FMAs.
 //   * the neighbour list (rows of {dx, dy, dz, j}) comes from the shared cell grid (celllist.h), or
 //     from an all-pairs scan for small systems.
 #include <algorithm>
@@ -370,6 +369,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_kernel(
 // Result layout of the instruction: D[row = 4*(l >> 4) + reg][col = l & 15].
 // ---------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int ACT> __device__ __forceinline__ float activate_fast(float s);
 
 __host__ __device__ inline size_t mfma_weight_floats(int W, int G) { return (size_t)W * W + (size_t)((G + 3) & ~3) * W; }
 __host__ __device__ inline size_t mfma_wave_floats(int W) { return (size_t)16 * (W + 1) + 64; }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) y1[(grp * 4 + q) * YS + cb * 16 + col] = activate<ACT>(acc[cb][q]);
+                for (int q = 0; q < 4; q++) y1[(grp * 4 + q) * YS + cb * 16 + col] = activate_fast<ACT>(acc[cb][q]);
             wave_fence();
             // ---- layer 2 ----
 #pragma unroll
@@ -469,6 +469,187 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
             v += __shfl_xor(v, 32, 64);
             if (grp == 0) out[(size_t)i * W + cb * 16 + col] = v;
         }
+    }
+}
+
+
+// Single-instruction transcendentals for the matrix-core kernels (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp):
+// the 2 x 16 x W activations of a tile would otherwise cost as much issue time as its MFMAs.
+template <int ACT>
+__device__ __forceinline__ float activate_fast(float s) {
+    if (ACT == 0) return (1.0f / kLog2e) * fast_log2(0.5f * fast_exp2(kLog2e * s) + 0.5f);       // ref :163
+    return tanhf(s);
+}
+template <int ACT>
+__device__ __forceinline__ void activate_d_fast(float s, float& y, float& dy) {
+    if (ACT == 0) {
+        const float e = fast_exp2(kLog2e * s);
+        y = (1.0f / kLog2e) * fast_log2(0.5f * e + 0.5f);
+        dy = e * fast_rcp(e + 1.0f);                                                              // ref :254-257
+    } else {
+        const float th = tanhf(s);
+        y = th;
+        dy = 1.0f - th * th;                                                                      // ref :259-262
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA backward: same tiling as the forward kernel, with the d/dr path riding along.
+//   layer 1   S1 = Gam W1^T + b1 and dS1 = dGam W1^T share every B operand (two MFMAs per LDS read)
+//   Y1 = act(S1) goes to the LDS tile; dY1 = dS1 * act'(S1) waits in registers
+//   layer 2   S2 = Y1 W2^T + b2, then the SAME LDS tile is refilled with dY1 for dS2 = dY1 W2^T
+//             (one tile per wave instead of two keeps 7 waves per CU resident at W = 128)
+//   epilogue  y2 = fc S2 -> input gradient ; dy2 = dfc S2 + fc dS2 -> force on the owner atom   ref :275-291
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t mfma_wave_floats_bwd(int W) { return (size_t)16 * (W + 1) + 128; }
+
+template <int ACT, int NCB>
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
+    ConvParams P, const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
+    const float* __restrict__ b2, const float4* __restrict__ rows, const int* __restrict__ cnt, int cap,
+    const float* __restrict__ x, const float* __restrict__ gout, float* __restrict__ xgrad, float* __restrict__ pos_grad) {
+    constexpr int W = NCB * 16, YS = W + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = P.G, Gp = (G + 3) & ~3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    float* s_w2t = lds;
+    float* s_w1t = s_w2t + (size_t)W * W;
+    float* y1 = s_w1t + (size_t)Gp * W + (size_t)wave * mfma_wave_floats_bwd(W);   // [16][YS]
+    float* ps = y1 + 16 * YS;                              // r | fc | dfc | j | 1/r | dx | dy | dz, 16 each
+    for (int q = tid; q < W * W; q += blockDim.x) s_w2t[q] = w2t[q];
+    for (int q = tid; q < Gp * W; q += blockDim.x) s_w1t[q] = q < G * W ? w1t[q] : 0.f;
+    __syncthreads();
+
+    const int col = lane & 15, grp = lane >> 4;
+    float b1v[NCB], b2v[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { b1v[cb] = b1[cb * 16 + col]; b2v[cb] = b2[cb * 16 + col]; }
+    const float mu_step = P.cutoff / (float)(G - 1);
+    const float sig2 = P.sigma_inv * P.sigma_inv;
+    const float gscale = -0.5f * kLog2e * sig2;
+
+    for (int i = blockIdx.x * waves_per_block + wave; i < P.N; i += gridDim.x * waves_per_block) {
+        const int n = min(cnt[i], cap);
+        const float4* row = rows + (size_t)i * cap;
+        float xi[NCB], gi[NCB], gacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            xi[cb] = x[(size_t)i * W + cb * 16 + col];
+            gi[cb] = gout[(size_t)i * W + cb * 16 + col];
+            gacc[cb] = 0.f;
+        }
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        for (int t0 = 0; t0 < n; t0 += 16) {
+            const int np = min(16, n - t0);
+            if (lane < 16) {
+                float r = 1.0f, fc = 0.f, dfc = 0.f;
+                float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(i));
+                if (lane < np) {
+                    rec = row[t0 + lane];
+                    r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+                    float sn, cs;
+                    sincospif(r / P.cutoff, &sn, &cs);
+                    fc = 0.5f * cs + 0.5f;                                              // ref :301-303
+                    dfc = -(0.5f * kPi / P.cutoff) * sn;                                // ref :305-307
+                }
+                ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = dfc;
+                ps[48 + lane] = __int_as_float(__float_as_int(rec.w) & kIdMask);
+                ps[64 + lane] = 1.0f / r; ps[80 + lane] = rec.x; ps[96 + lane] = rec.y; ps[112 + lane] = rec.z;
+            }
+            wave_fence();
+            // ---- layer 1: value and d/dr together ----
+            f32x4 acc[NCB], dacc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                acc[cb] = f32x4{b1v[cb], b1v[cb], b1v[cb], b1v[cb]};
+                dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const float rp = ps[col];
+            for (int s = 0; s < Gp / 4; s++) {
+                const int g = 4 * s + grp;
+                const float d = rp - (float)g * mu_step;
+                const float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                   // ref :151-154
+                const float da = -d * sig2 * a;                                            // ref :242
+                const float* wrow = s_w1t + g * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    const float b = wrow[cb * 16];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[cb], 0, 0, 0);
+                    dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, b, dacc[cb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float yv, dact;
+                    activate_d_fast<ACT>(acc[cb][q], yv, dact);
+                    y1[(grp * 4 + q) * YS + cb * 16 + col] = yv;
+                    dacc[cb][q] *= dact;                                                   // dY1, kept in registers
+                }
+            wave_fence();
+            // ---- layer 2 on Y1 ----
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+            for (int s = 0; s < W / 4; s++) {
+                const int k = 4 * s + grp;
+                const float a = y1[col * YS + k];
+                const float* wrow = s_w2t + k * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
+            }
+            wave_fence();
+            // ---- refill the tile with dY1, layer 2 again ----
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    y1[(grp * 4 + q) * YS + cb * 16 + col] = dacc[cb][q];
+                    dacc[cb][q] = 0.f;
+                }
+            wave_fence();
+            for (int s = 0; s < W / 4; s++) {
+                const int k = 4 * s + grp;
+                const float a = y1[col * YS + k];
+                const float* wrow = s_w2t + k * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], dacc[cb], 0, 0, 0);
+            }
+            // ---- epilogue: my four rows of the tile ----
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int rr = grp * 4 + q;
+                const int j = __float_as_int(ps[48 + rr]);
+                const float fc = ps[16 + rr], dfc = ps[32 + rr];
+                float sc = 0.f;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    const float xj = x[(size_t)j * W + cb * 16 + col], gj = gout[(size_t)j * W + cb * 16 + col];
+                    const float s2 = acc[cb][q];
+                    gacc[cb] += fc * s2 * gj;                                              // ref :275, :284
+                    const float dy2 = dfc * s2 + fc * dacc[cb][q];                         // ref :276
+                    sc += dy2 * (xj * gi[cb] + xi[cb] * gj);                               // ref :286
+                }
+                sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
+                sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+                sc *= ps[64 + rr];
+                // position_deriv[i] -= sc * delta  (owner side of ref :287-291; delta = pos_j - pos_i)
+                fx -= sc * ps[80 + rr]; fy -= sc * ps[96 + rr]; fz -= sc * ps[112 + rr];
+                __builtin_amdgcn_sched_barrier(0);      // one row's 2*NCB gathers in flight at a time: no spills at W = 128
+            }
+            wave_fence();
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            float v = gacc[cb];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (grp == 0) xgrad[(size_t)i * W + cb * 16 + col] = v;
+        }
+        fx += __shfl_xor(fx, 16, 64); fx += __shfl_xor(fx, 32, 64);
+        fy += __shfl_xor(fy, 16, 64); fy += __shfl_xor(fy, 32, 64);
+        fz += __shfl_xor(fz, 16, 64); fz += __shfl_xor(fz, 32, 64);
+        if (lane == 0) { pos_grad[3 * i] = fx; pos_grad[3 * i + 1] = fy; pos_grad[3 * i + 2] = fz; }
     }
 }
 
@@ -744,7 +925,7 @@ int launch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, c
 
 template <int ACT, int NCB>
 int launch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, float* out) {
-    const size_t budget = 156 * 1024 / sizeof(float);
+    const size_t budget = 160 * 1024 / sizeof(float);   // all of a CU: 8 waves (2 per SIMD) at W = 128, G <= 52
     const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats(h->p.W);
     const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
     const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
@@ -756,6 +937,36 @@ int launch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const flo
                        nb->d_rows, nb->d_cnt, nb->cap, x, out);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
+}
+
+template <int ACT, int NCB>
+int launch_backward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* xgrad, float* pos_grad) {
+    const size_t budget = 160 * 1024 / sizeof(float);   // all of a CU: 8 waves (2 per SIMD) at W = 128, G <= 52
+    const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats_bwd(h->p.W);
+    const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
+    const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
+    auto k = cfconv_backward_mfma<ACT, NCB>;
+    if (lds > 64 * 1024)
+        NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int blocks = std::max(1, std::min(h->blocks, div_up(h->p.N, wpb)));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1t, h->d_b1, h->d_w2t, h->d_b2,
+                       nb->d_rows, nb->d_cnt, nb->cap, x, gout, xgrad, pos_grad);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+template <int ACT>
+int dispatch_backward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* xgrad,
+                           float* pos_grad, bool& handled) {
+    handled = true;
+    switch (h->p.W) {
+        case 16:  return launch_backward_mfma<ACT, 1>(h, nb, x, gout, xgrad, pos_grad);
+        case 32:  return launch_backward_mfma<ACT, 2>(h, nb, x, gout, xgrad, pos_grad);
+        case 64:  return launch_backward_mfma<ACT, 4>(h, nb, x, gout, xgrad, pos_grad);
+        case 96:  return launch_backward_mfma<ACT, 6>(h, nb, x, gout, xgrad, pos_grad);
+        case 128: return launch_backward_mfma<ACT, 8>(h, nb, x, gout, xgrad, pos_grad);
+        default: handled = false; return NNPOPS_OK;
+    }
 }
 
 // widths that are a multiple of 16 take the matrix-core forward path
@@ -778,6 +989,12 @@ int dispatch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x,
         bool handled = false;
         const int rc = h->p.activation == 0 ? dispatch_forward_mfma<0>(h, nb, x, out, handled)
                                             : dispatch_forward_mfma<1>(h, nb, x, out, handled);
+        if (handled) return rc;
+    }
+    if (BWD && !h->force_valu) {
+        bool handled = false;
+        const int rc = h->p.activation == 0 ? dispatch_backward_mfma<0>(h, nb, x, gout, out, pos_grad, handled)
+                                            : dispatch_backward_mfma<1>(h, nb, x, gout, out, pos_grad, handled);
         if (handled) return rc;
     }
     const bool two = h->p.W > 64;

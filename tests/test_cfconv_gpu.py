@@ -69,11 +69,20 @@ def test_water18_golden(golden_dir, tag):
     np.testing.assert_allclose(y, g[f"{tag}_output"], rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("W,G", [(128, 50), (64, 25), (32, 16), (5, 3)])
+@pytest.mark.parametrize("W,G", [(128, 50), (96, 50), (64, 25), (32, 16), (16, 7), (100, 50), (5, 3)])
 @pytest.mark.parametrize("act", ["ssp", "tanh"])
 def test_random_cluster(W, G, act):
     pos, _ = workloads.conformer(120, seed=W + G)
     _case(pos, None, W, G, 5.0, 0.1 if G >= 25 else 0.4, act, seed=W)
+
+
+def test_vector_kernels_at_matrix_widths(monkeypatch):
+    """W = 128 normally runs on the matrix cores; $NNPOPS_CFCONV_VALU=1 (read at handle creation) keeps the
+    vector kernels, which serve every width that is not a multiple of 16, under the same parity bar."""
+    monkeypatch.setenv("NNPOPS_CFCONV_VALU", "1")
+    pos, _ = workloads.conformer(90, seed=77)
+    _case(pos, None, 128, 50, 5.0, 0.1, "ssp", seed=5)
+    _case(pos, None, 64, 25, 5.0, 0.1, "tanh", seed=6)
 
 
 def test_periodic_box_cells():
