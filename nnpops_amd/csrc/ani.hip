@@ -24,8 +24,6 @@ struct nnpops_ani {
     // device state
     int32_t* d_species = nullptr;
     int2* d_segment = nullptr;      // [N] per-atom [lo, hi) of its molecule (batched handles only)
-    float* d_pos = nullptr;         // [N][3] positions of the last compute()
-    float* d_box = nullptr;         // [9]
     float4* d_nbr = nullptr;        // [N][cap] records {dx, dy, dz, (species<<24)|atom}
     float4* d_recA = nullptr;       // [N][cap_angular] sorted angular records {dx,dy,dz,r}
     float4* d_recB = nullptr;       // [N][cap_angular]                        {fc,dfc,1/r,word}
@@ -43,6 +41,9 @@ struct nnpops_ani {
     int* d_sorted_atom = nullptr;   // [N]
     float4* d_sorted_pos = nullptr; // [N]
     int max_cells = 0;
+    int* d_hist = nullptr;          // two-kernel cell build (celllist.h): [kBinnedCells + 1]
+    int* d_bins = nullptr;          // [kBinnedCells][bin_cap]
+    int bin_cap = 64;
     bool cells_disabled = false;    // set when a box turned out too small for the 27-cell stencil
     int cap = 0;                    // row capacity (angular + radial-only neighbours)
     int cap_angular = 0;            // LDS capacity of the angular kernels
@@ -250,8 +251,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     auto cleanup = [&](int code) { nnpops_ani_destroy(h); return code; };
     if ((rc = dev_alloc(&h->d_params, 1))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_species, (size_t)num_atoms))) return cleanup(rc);
-    if ((rc = dev_alloc(&h->d_pos, (size_t)num_atoms * 3))) return cleanup(rc);
-    if ((rc = dev_alloc(&h->d_box, 9))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_a, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_ro, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_status, (size_t)kStatWords))) return cleanup(rc);
@@ -260,6 +259,12 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_grid, 1))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cell_count, (size_t)h->max_cells))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cell_start, (size_t)h->max_cells + 1))) return cleanup(rc);
+    if (const char* e = std::getenv("NNPOPS_CELL_BIN_CAP")) h->bin_cap = std::max(4, std::atoi(e) & ~3);   // tests: force growth
+    if (periodic && num_atoms <= kBinnedAtoms) {
+        if ((rc = dev_alloc(&h->d_hist, (size_t)kBinnedCells + 1))) return cleanup(rc);
+        if ((rc = dev_alloc(&h->d_bins, (size_t)kBinnedCells * h->bin_cap))) return cleanup(rc);
+        if (hipMemset(h->d_hist, 0, sizeof(int) * (kBinnedCells + 1)) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
+    }
     if ((rc = dev_alloc(&h->d_atom_cell, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_atom_rank, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_atom, (size_t)num_atoms))) return cleanup(rc);
@@ -278,8 +283,9 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
 int nnpops_ani_destroy(nnpops_ani_t h) {
     if (!h) return NNPOPS_OK;
     DeviceGuard guard(h->device);
-    dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_segment); dev_free(h->d_pos); dev_free(h->d_box);
+    dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_segment);
     dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
+    dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
     dev_free(h->d_atom_rank); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
@@ -348,25 +354,18 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     {
     KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
     if (use_cells) {
-        const int tb = 256;
-        hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, h->stream, N, positions, box, (int)per, h->hp.rcr,
-                           h->max_cells, h->d_grid, h->d_cell_count);
-        hipLaunchKernelGGL(assign_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, positions, h->d_grid,
-                           h->d_cell_count, h->d_atom_cell, h->d_atom_rank);
-        hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, h->stream, h->d_grid, h->d_cell_count, h->d_cell_start);
-        hipLaunchKernelGGL(fill_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_grid, h->d_cell_start,
-                           h->d_atom_cell, h->d_atom_rank, h->d_unsorted_atom);
-        hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, positions, h->d_grid,
-                           h->d_cell_start, h->d_atom_cell, h->d_unsorted_atom, h->d_species, h->d_sorted_atom,
-                           h->d_sorted_pos);
+        const CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank,
+                             h->d_unsorted_atom, h->d_sorted_atom, h->d_sorted_pos, h->max_cells,
+                             h->d_hist, h->d_bins, h->bin_cap};
+        launch_cell_build(h->stream, N, positions, box, per, h->hp.rcr, h->d_species, cb);
         if (per)
             hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw, h->d_hist);
         else
             hipLaunchKernelGGL(ani_neighbors_cells<false>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw, h->d_hist);
     } else if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
@@ -431,6 +430,16 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     h->tile = std::min(32, std::max(8, (st[kStatMaxAngular] + 3) / 4 * 4));
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
+    if (st[kStatOverflow] & 4) {          // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins
+        const int old_bin = h->bin_cap;
+        h->bin_cap *= 2;
+        dev_free(h->d_bins);
+        h->d_bins = nullptr;
+        int rc = dev_alloc(&h->d_bins, (size_t)kBinnedCells * h->bin_cap);
+        if (rc != NNPOPS_OK) return rc;
+        h->computed = false;
+        return fail(NNPOPS_ERR_CAPACITY, "cell bins overflowed (%d ids per cell); grown to %d, call compute() again", old_bin, h->bin_cap);
+    }
     if (st[kStatOverflow] & 2) {
         if (h->algorithm == 2)
             return fail(NNPOPS_ERR_UNSUPPORTED, "cell list forced but the periodic box is fewer than 3 cells wide on some axis");

@@ -330,17 +330,19 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           int cap, int capA, float4* __restrict__ recA,
                                                           float4* __restrict__ recB, int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
-                                                          int* __restrict__ status, int lds_per_wave) {
+                                                          int* __restrict__ status, int lds_per_wave,
+                                                          int* __restrict__ cell_hist) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     const AtomGroups G = carve_groups((int*)(stage + capA), P->S, P->NB);
     const int lane = lane_id();
     const int slot_id = wave_global_id();                  // position in cell order
+    clear_cell_histogram(cell_hist);
     if (slot_id >= P->N) return;
     const CellGrid g = *grid;
     if (!g.ok) {                                           // box too small for the stencil: tell the host
         if (lane == 0) {
-            if (slot_id == 0) atomicOr(&status[kStatOverflow], 2);
+            if (slot_id == 0) atomicOr(&status[kStatOverflow], g.bin_overflow ? 6 : 2);   // 4: grow the cell bins
             cnt_a[slot_id] = 0;                            // keep the consumers of this (void) build harmless
             cnt_ro[slot_id] = 0;
         }

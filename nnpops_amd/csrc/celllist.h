@@ -9,6 +9,7 @@
 //   fill_cells      1 thread/atom   scatter atom ids into their cell segment (arrival order)
 //   order_cells     1 thread/atom   rank inside the segment by atom id (deterministic order), emit
 //                                   cell-ordered float4 {x, y, z, id}
+//   bin_atoms + order_binned   the same in two launches for stateful periodic callers (see below)
 // Consumers walk the 3x3x3 block of cells around an atom.  The stencil only prunes candidates: the
 // displacement of every candidate is still computed with the reference's minimum-image rule
 // (device_common.h: min_image), so results are identical to the all-pairs scan.  The stencil is
@@ -26,7 +27,8 @@ constexpr int kIdMask = (1 << kTagShift) - 1;
 struct CellGrid {
     int nx, ny, nz, ncells;
     int periodic;
-    int ok;                 // 0: the stencil would be invalid for this box (too few cells)
+    int ok;                 // 0: the stencil would be invalid for this box (too few cells), or a bin overflowed
+    int bin_overflow;       // 1: ok was cleared because a cell holds more atoms than the bins of the two-kernel build
     // lattice coordinates: sz = (z-oz)*izz; sy = ((y-oy) - sz*cy)*iyy; sx = ((x-ox) - sy*bx - sz*cx)*ixx
     float ox, oy, oz;
     float ixx, iyy, izz;
@@ -45,6 +47,49 @@ __device__ __forceinline__ void cell_of(const CellGrid& g, float x, float y, flo
     cx = min(max((int)(sx * g.nx), 0), g.nx - 1);
     cy = min(max((int)(sy * g.ny), 0), g.ny - 1);
     cz = min(max((int)(sz * g.nz), 0), g.nz - 1);
+}
+
+// The grid for a box (periodic) or a bounding box lo..hi (non-periodic): the largest dims whose cells are at
+// least `cutoff` wide, capped at max_cells.
+__device__ inline CellGrid decide_grid(int periodic, const float* __restrict__ box, const float* lo, const float* hi,
+                                       float cutoff, int max_cells) {
+    CellGrid g;
+    g.periodic = periodic;
+    g.ok = 1;
+    g.bin_overflow = 0;
+    float wx, wy, wz;      // perpendicular widths of the cell-able region
+    if (periodic) {
+        const float ax = box[0], bx = box[3], by = box[4], cx = box[6], cy = box[7], cz = box[8];
+        g.ox = g.oy = g.oz = 0.f;
+        g.ixx = 1.0f / ax; g.iyy = 1.0f / by; g.izz = 1.0f / cz;
+        g.cy = cy; g.bx = bx; g.cx = cx;
+        // perpendicular widths of the box (lower-triangular cell)
+        wz = cz;
+        wy = by * cz / sqrtf(cy * cy + cz * cz);
+        const float nxv = by * cz, nyv = -bx * cz, nzv = bx * cy - by * cx;
+        wx = ax * by * cz / sqrtf(nxv * nxv + nyv * nyv + nzv * nzv);
+    } else {
+        const float pad = 1e-3f;
+        g.ox = lo[0] - pad; g.oy = lo[1] - pad; g.oz = lo[2] - pad;
+        wx = hi[0] - lo[0] + 2 * pad; wy = hi[1] - lo[1] + 2 * pad; wz = hi[2] - lo[2] + 2 * pad;
+        g.ixx = 1.0f / wx; g.iyy = 1.0f / wy; g.izz = 1.0f / wz;
+        g.bx = g.cx = g.cy = 0.f;
+    }
+    // largest dims with cell width >= cutoff (a hair of slack for rounding in cell_of)
+    const float c = cutoff * 1.0001f;
+    int nx = max(1, (int)floorf(wx / c)), ny = max(1, (int)floorf(wy / c)), nz = max(1, (int)floorf(wz / c));
+    if (periodic && (nx < 3 || ny < 3 || nz < 3)) g.ok = 0;
+    // cap the total cell count (sparse systems): coarser cells are always valid
+    while ((long long)nx * ny * nz > max_cells) {
+        if (nx >= ny && nx >= nz) nx = max(periodic ? 3 : 1, nx - (nx + 7) / 8);
+        else if (ny >= nz) ny = max(periodic ? 3 : 1, ny - (ny + 7) / 8);
+        else nz = max(periodic ? 3 : 1, nz - (nz + 7) / 8);
+        if (periodic && nx == 3 && ny == 3 && nz == 3) break;
+    }
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    g.ncells = nx * ny * nz;
+    if (g.ncells > max_cells) g.ok = 0;
+    return g;
 }
 
 // One block of 256 threads.
@@ -74,40 +119,8 @@ static __global__ __launch_bounds__(256) void grid_setup(int N, const float* __r
         }
     }
     if (tid == 0) {
-        g.periodic = periodic;
-        g.ok = 1;
-        float wx, wy, wz;      // perpendicular widths of the cell-able region
-        if (periodic) {
-            const float ax = box[0], bx = box[3], by = box[4], cx = box[6], cy = box[7], cz = box[8];
-            g.ox = g.oy = g.oz = 0.f;
-            g.ixx = 1.0f / ax; g.iyy = 1.0f / by; g.izz = 1.0f / cz;
-            g.cy = cy; g.bx = bx; g.cx = cx;
-            // perpendicular widths of the box (lower-triangular cell)
-            wz = cz;
-            wy = by * cz / sqrtf(cy * cy + cz * cz);
-            const float nxv = by * cz, nyv = -bx * cz, nzv = bx * cy - by * cx;
-            wx = ax * by * cz / sqrtf(nxv * nxv + nyv * nyv + nzv * nzv);
-        } else {
-            const float pad = 1e-3f;
-            g.ox = red[0][0] - pad; g.oy = red[1][0] - pad; g.oz = red[2][0] - pad;
-            wx = red[3][0] - red[0][0] + 2 * pad; wy = red[4][0] - red[1][0] + 2 * pad; wz = red[5][0] - red[2][0] + 2 * pad;
-            g.ixx = 1.0f / wx; g.iyy = 1.0f / wy; g.izz = 1.0f / wz;
-            g.bx = g.cx = g.cy = 0.f;
-        }
-        // largest dims with cell width >= cutoff (a hair of slack for rounding in cell_of)
-        const float c = cutoff * 1.0001f;
-        int nx = max(1, (int)floorf(wx / c)), ny = max(1, (int)floorf(wy / c)), nz = max(1, (int)floorf(wz / c));
-        if (periodic && (nx < 3 || ny < 3 || nz < 3)) g.ok = 0;
-        // cap the total cell count (sparse systems): coarser cells are always valid
-        while ((long long)nx * ny * nz > max_cells) {
-            if (nx >= ny && nx >= nz) nx = max(periodic ? 3 : 1, nx - (nx + 7) / 8);
-            else if (ny >= nz) ny = max(periodic ? 3 : 1, ny - (ny + 7) / 8);
-            else nz = max(periodic ? 3 : 1, nz - (nz + 7) / 8);
-            if (periodic && nx == 3 && ny == 3 && nz == 3) break;
-        }
-        g.nx = nx; g.ny = ny; g.nz = nz;
-        g.ncells = nx * ny * nz;
-        if (g.ncells > max_cells) g.ok = 0;
+        float lo3[3] = {red[0][0], red[1][0], red[2][0]}, hi3[3] = {red[3][0], red[4][0], red[5][0]};
+        g = decide_grid(periodic, box, lo3, hi3, cutoff, max_cells);
         *grid = g;
     }
     __syncthreads();
@@ -184,6 +197,150 @@ static __global__ void order_cells(int N, const float* __restrict__ pos, const C
     // .w carries the atom id in its low 24 bits and an optional 8-bit tag (e.g. the species) above them
     const int packed = i | (tag ? (tag[i] << kTagShift) : 0);
     sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-kernel build for handles that keep state between calls (periodic systems of up to kBinnedAtoms
+// atoms).  Every kernel boundary costs ~4 us of dependent-launch latency on MI355X -- more than any of
+// the five steps above -- so the steps are regrouped around the one true dependency (all ids of a cell
+// must be known before an atom can be ranked inside it):
+//   bin_atoms      1 thread/atom   grid from the box (recomputed per block: no setup kernel), cell id,
+//                                  histogram, and the id dropped into a fixed-capacity bin of its cell
+//   order_binned   1 thread/atom   every block scans the (<= 8192-cell) histogram in LDS on its own
+//                                  (no scan kernel), ranks its atoms inside their bins by id and emits
+//                                  the same cell-ordered arrays as order_cells
+//   (consumer)                     the kernel that walks the grid next clears the histogram for the
+//                                  following build (clear_cell_histogram): no memset node, and a captured
+//                                  graph replays correctly
+// A bin that overflows clears grid.ok; the owner grows the bins in its check() and rebuilds.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBinnedAtoms = 65536;
+constexpr int kBinnedCells = 8192;
+constexpr int kBinnedThreads = 256;
+
+// hist: [kBinnedCells + 1] ints, the last one is the overflow flag of that build
+static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const float* __restrict__ pos,
+                                                                   const float* __restrict__ box, float cutoff, int max_cells,
+                                                                   CellGrid* __restrict__ grid, int* __restrict__ hist,
+                                                                   int* __restrict__ bins, int bin_cap,
+                                                                   int* __restrict__ atom_cell) {
+    __shared__ CellGrid g;
+    if (threadIdx.x == 0) {
+        g = decide_grid(1, box, nullptr, nullptr, cutoff, min(max_cells, kBinnedCells));
+        if (blockIdx.x == 0) *grid = g;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * kBinnedThreads + threadIdx.x;
+    if (i >= N || !g.ok) return;
+    int cx, cy, cz;
+    cell_of(g, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], cx, cy, cz);
+    const int c = (cz * g.ny + cy) * g.nx + cx;
+    atom_cell[i] = c;
+    const int r = atomicAdd(&hist[c], 1);
+    if (r < bin_cap) bins[(size_t)c * bin_cap + r] = i;
+    else hist[kBinnedCells] = 1;                              // benign race: everyone writes the same value
+}
+
+static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, const float* __restrict__ pos,
+                                                                      const int* __restrict__ tag, CellGrid* __restrict__ grid,
+                                                                      const int* __restrict__ hist,
+                                                                      const int* __restrict__ bins, int bin_cap,
+                                                                      const int* __restrict__ atom_cell, int* __restrict__ cell_start,
+                                                                      int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos) {
+    __shared__ int s_start[kBinnedCells + 1];
+    __shared__ int wave_tot[kBinnedThreads / 64];
+    constexpr int T = kBinnedThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const CellGrid g = *grid;
+    if (!g.ok) return;
+    if (hist[kBinnedCells] != 0) {                            // a bin overflowed: this grid is unusable
+        if (blockIdx.x == 0 && tid == 0) { grid->ok = 0; grid->bin_overflow = 1; }
+        return;
+    }
+    const int ncells = g.ncells;
+    // exclusive scan of the histogram, redundantly in every block: coalesced into LDS, then thread t owns a
+    // contiguous run of cells
+    for (int c = tid; c < ncells; c += T) s_start[c] = hist[c];
+    __syncthreads();
+    const int per = (ncells + T - 1) / T;
+    const int c0 = min(tid * per, ncells), c1 = min(c0 + per, ncells);
+    int sum = 0;
+    for (int c = c0; c < c1; c++) sum += s_start[c];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; w++) run += wave_tot[w];
+    for (int c = c0; c < c1; c++) { const int v = s_start[c]; s_start[c] = run; run += v; }
+    if (tid == T - 1) s_start[ncells] = run;
+    __syncthreads();
+    // the global copy of the offsets, a slice per block
+    for (int c = blockIdx.x * T + tid; c <= ncells; c += gridDim.x * T) cell_start[c] = s_start[c];
+
+    const int i = blockIdx.x * T + tid;
+    if (i >= N) return;
+    const int c = atom_cell[i];
+    const int lo = s_start[c], n = s_start[c + 1] - lo;
+    const int* bin = bins + (size_t)c * bin_cap;
+    int rank = 0;                                             // deterministic order inside the cell
+    const int4* bin4 = reinterpret_cast<const int4*>(bin);    // bin_cap is a multiple of 4
+    for (int k = 0; k < n; k += 4) {
+        const int4 v = bin4[k >> 2];
+        rank += (v.x < i) + (k + 1 < n && v.y < i) + (k + 2 < n && v.z < i) + (k + 3 < n && v.w < i);
+    }
+    sorted_atom[lo + rank] = i;
+    const int packed = i | (tag ? (tag[i] << kTagShift) : 0);
+    sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
+}
+
+// Called by the kernel that consumes the grid (all of its threads, before any early exit): leaves the
+// histogram of the two-kernel build zeroed for the next build.  `hist` may be NULL (five-kernel path).
+__device__ __forceinline__ void clear_cell_histogram(int* __restrict__ hist) {
+    if (hist == nullptr) return;
+    const int stride = gridDim.x * blockDim.x;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= kBinnedCells; c += stride) hist[c] = 0;
+}
+
+// Host side: the buffers of one grid and the launch sequence.
+struct CellBuffers {
+    CellGrid* grid;
+    int *cell_count, *cell_start;          // [max_cells], [max_cells + 1]
+    int *atom_cell, *atom_rank;            // [N]
+    int *unsorted_atom, *sorted_atom;      // [N]
+    float4* sorted_pos;                    // [N]
+    int max_cells;
+    // two-kernel path (optional): a zero-initialised histogram of kBinnedCells + 1 ints that the consumer kernel
+    // clears again after every build, and bins of kBinnedCells * bin_cap ints
+    int* hist = nullptr;
+    int* bins = nullptr;
+    int bin_cap = 0;
+};
+
+static inline bool cell_build_is_binned(int N, bool periodic, const CellBuffers& b) {
+    return periodic && b.hist != nullptr && b.bins != nullptr && N <= kBinnedAtoms;
+}
+
+static inline void launch_cell_build(hipStream_t stream, int N, const float* pos, const float* box, bool periodic, float cutoff,
+                                     const int* tag, const CellBuffers& b) {
+    const int tb = 256, nb = (N + tb - 1) / tb;
+    if (cell_build_is_binned(N, periodic, b)) {
+        hipLaunchKernelGGL(bin_atoms, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, box, cutoff, b.max_cells, b.grid, b.hist, b.bins,
+                           b.bin_cap, b.atom_cell);
+        hipLaunchKernelGGL(order_binned, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, tag, b.grid, b.hist, b.bins, b.bin_cap,
+                           b.atom_cell, b.cell_start, b.sorted_atom, b.sorted_pos);
+        return;
+    }
+    hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, stream, N, pos, box, (int)periodic, cutoff, b.max_cells, b.grid, b.cell_count);
+    hipLaunchKernelGGL(assign_cells, dim3(nb), dim3(tb), 0, stream, N, pos, b.grid, b.cell_count, b.atom_cell, b.atom_rank);
+    hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, stream, b.grid, b.cell_count, b.cell_start);
+    hipLaunchKernelGGL(fill_cells, dim3(nb), dim3(tb), 0, stream, N, b.grid, b.cell_start, b.atom_cell, b.atom_rank, b.unsorted_atom);
+    hipLaunchKernelGGL(order_cells, dim3(nb), dim3(tb), 0, stream, N, pos, b.grid, b.cell_start, b.atom_cell, b.unsorted_atom, tag,
+                       b.sorted_atom, b.sorted_pos);
 }
 
 // Iterate the candidate ranges of the 3x3x3 stencil around cell (cx,cy,cz).  For every (dy,dz)

@@ -83,12 +83,13 @@ __global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, 
                                                  const CellGrid* __restrict__ grid, const int* __restrict__ cell_start,
                                                  const int* __restrict__ atom_cell, const float4* __restrict__ sorted_pos,
                                                  float4* __restrict__ rows, int cap, int* __restrict__ cnt,
-                                                 int* __restrict__ status) {
+                                                 int* __restrict__ status, int* __restrict__ cell_hist) {
     const int lane = lane_id();
+    clear_cell_histogram(cell_hist);
     const CellGrid g = *grid;
     if (!g.ok) {
         if (lane == 0) {
-            if (blockIdx.x == 0) atomicOr(&status[kStOverflow], 2);
+            if (blockIdx.x == 0) atomicOr(&status[kStOverflow], g.bin_overflow ? 6 : 2);   // 4: grow the cell bins
             cnt[blockIdx.x] = 0;
         }
         return;
@@ -670,14 +671,15 @@ struct nnpops_cfconv_neighbors {
     float4* d_rows = nullptr;
     int* d_cnt = nullptr;
     int* d_status = nullptr;
-    float* d_pos = nullptr;
-    float* d_box = nullptr;
     // cell grid
     CellGrid* d_grid = nullptr;
     int *d_cell_count = nullptr, *d_cell_start = nullptr, *d_atom_cell = nullptr, *d_atom_rank = nullptr;
     int *d_unsorted = nullptr, *d_sorted = nullptr;
     float4* d_sorted_pos = nullptr;
     int max_cells = 0;
+    int* d_hist = nullptr;          // two-kernel cell build (celllist.h)
+    int* d_bins = nullptr;
+    int bin_cap = 64;
 };
 
 struct nnpops_cfconv {
@@ -709,11 +711,15 @@ int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t* out, int num_atoms
     if ((rc = dev_alloc(&h->d_rows, (size_t)num_atoms * h->cap))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_status, (size_t)kStWordsN))) return cleanup(rc);
-    if ((rc = dev_alloc(&h->d_pos, (size_t)num_atoms * 3))) return cleanup(rc);
-    if ((rc = dev_alloc(&h->d_box, 9))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_grid, 1))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cell_count, (size_t)h->max_cells))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cell_start, (size_t)h->max_cells + 1))) return cleanup(rc);
+    if (const char* e = std::getenv("NNPOPS_CELL_BIN_CAP")) h->bin_cap = std::max(4, std::atoi(e) & ~3);   // tests: force growth
+    if (periodic && num_atoms <= kBinnedAtoms) {
+        if ((rc = dev_alloc(&h->d_hist, (size_t)kBinnedCells + 1))) return cleanup(rc);
+        if ((rc = dev_alloc(&h->d_bins, (size_t)kBinnedCells * h->bin_cap))) return cleanup(rc);
+        if (hipMemset(h->d_hist, 0, sizeof(int) * (kBinnedCells + 1)) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
+    }
     if ((rc = dev_alloc(&h->d_atom_cell, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_atom_rank, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_unsorted, (size_t)num_atoms))) return cleanup(rc);
@@ -728,7 +734,8 @@ int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t* out, int num_atoms
 int nnpops_cfconv_neighbors_destroy(nnpops_cfconv_neighbors_t h) {
     if (!h) return NNPOPS_OK;
     DeviceGuard guard(h->device);
-    dev_free(h->d_rows); dev_free(h->d_cnt); dev_free(h->d_status); dev_free(h->d_pos); dev_free(h->d_box);
+    dev_free(h->d_rows); dev_free(h->d_cnt); dev_free(h->d_status);
+    dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
     dev_free(h->d_atom_rank); dev_free(h->d_unsorted); dev_free(h->d_sorted); dev_free(h->d_sorted_pos);
     delete h;
@@ -748,31 +755,23 @@ int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t h, const float* posi
     const int N = h->N;
     const bool per = h->periodic;
     const float c2 = h->cutoff * h->cutoff;
-    NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_pos, positions, sizeof(float) * 3 * N, hipMemcpyDeviceToDevice, h->stream));
-    if (per) NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_box, box, sizeof(float) * 9, hipMemcpyDeviceToDevice, h->stream));
-    NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStWordsN, h->stream));
+    // positions and box are read in place (the rows keep displacements, nothing refers back to them later); the
+    // status words are cleared by create() and by check() after it has read them, not per build
     const bool use_cells = N >= 1024 && !h->cells_disabled;
     if (use_cells) {
-        const int tb = 256;
-        hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, h->stream, N, h->d_pos, h->d_box, (int)per, h->cutoff, h->max_cells,
-                           h->d_grid, h->d_cell_count);
-        hipLaunchKernelGGL(assign_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid, h->d_cell_count,
-                           h->d_atom_cell, h->d_atom_rank);
-        hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, h->stream, h->d_grid, h->d_cell_count, h->d_cell_start);
-        hipLaunchKernelGGL(fill_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_grid, h->d_cell_start, h->d_atom_cell,
-                           h->d_atom_rank, h->d_unsorted);
-        hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, h->stream, N, h->d_pos, h->d_grid, h->d_cell_start,
-                           h->d_atom_cell, h->d_unsorted, (const int*)nullptr, h->d_sorted, h->d_sorted_pos);
+        const CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank, h->d_unsorted,
+                             h->d_sorted, h->d_sorted_pos, h->max_cells, h->d_hist, h->d_bins, h->bin_cap};
+        launch_cell_build(h->stream, N, positions, box, per, h->cutoff, nullptr, cb);
         if (per)
-            hipLaunchKernelGGL(rows_cells<true>, dim3(N), dim3(64), 0, h->stream, h->d_box, c2, h->d_grid, h->d_cell_start,
-                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status);
+            hipLaunchKernelGGL(rows_cells<true>, dim3(N), dim3(64), 0, h->stream, box, c2, h->d_grid, h->d_cell_start,
+                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status, h->d_hist);
         else
-            hipLaunchKernelGGL(rows_cells<false>, dim3(N), dim3(64), 0, h->stream, h->d_box, c2, h->d_grid, h->d_cell_start,
-                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status);
+            hipLaunchKernelGGL(rows_cells<false>, dim3(N), dim3(64), 0, h->stream, box, c2, h->d_grid, h->d_cell_start,
+                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status, h->d_hist);
     } else if (per) {
-        hipLaunchKernelGGL(rows_allpairs<true>, dim3(N), dim3(64), 0, h->stream, N, h->d_pos, h->d_box, c2, h->d_rows, h->cap, h->d_cnt);
+        hipLaunchKernelGGL(rows_allpairs<true>, dim3(N), dim3(64), 0, h->stream, N, positions, box, c2, h->d_rows, h->cap, h->d_cnt);
     } else {
-        hipLaunchKernelGGL(rows_allpairs<false>, dim3(N), dim3(64), 0, h->stream, N, h->d_pos, h->d_box, c2, h->d_rows, h->cap, h->d_cnt);
+        hipLaunchKernelGGL(rows_allpairs<false>, dim3(N), dim3(64), 0, h->stream, N, positions, box, c2, h->d_rows, h->cap, h->d_cnt);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     h->built = true;
@@ -789,8 +788,19 @@ int nnpops_cfconv_neighbors_check(nnpops_cfconv_neighbors_t h, int* num_pairs) {
                        h->cap, h->d_status);
     NNPOPS_HIP_TRY(hipGetLastError());
     NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStWordsN, h->stream));   // consumed: builds do not clear it
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
     if (num_pairs) *num_pairs = st[kStPairs];
+    if (st[kStOverflow] & 4) {            // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins
+        const int old_bin = h->bin_cap;
+        h->bin_cap *= 2;
+        dev_free(h->d_bins);
+        h->d_bins = nullptr;
+        int rc = dev_alloc(&h->d_bins, (size_t)kBinnedCells * h->bin_cap);
+        if (rc != NNPOPS_OK) return rc;
+        h->built = false;
+        return fail(NNPOPS_ERR_CAPACITY, "cell bins overflowed (%d ids per cell); grown to %d, call build() again", old_bin, h->bin_cap);
+    }
     if (st[kStOverflow] & 2) {
         h->cells_disabled = true;
         h->built = false;

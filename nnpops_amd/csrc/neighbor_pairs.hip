@@ -291,16 +291,10 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
                 fbox = (const float*)box;
             }
         }
-        hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, stream, N, fpos, fbox, periodic, (float)cutoff, w.max_cells, w.grid,
-                           w.cell_count);
-        hipLaunchKernelGGL(assign_cells, dim3(div_up(N, tb)), dim3(tb), 0, stream, N, fpos, w.grid, w.cell_count, w.atom_cell,
-                           w.atom_rank);
-        hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, stream, w.grid, w.cell_count, w.cell_start);
-        hipLaunchKernelGGL(fill_cells, dim3(div_up(N, tb)), dim3(tb), 0, stream, N, w.grid, w.cell_start, w.atom_cell,
-                           w.atom_rank, w.unsorted_atom);
-        // order_cells also writes sorted positions; point it at scratch we do not otherwise use
-        hipLaunchKernelGGL(order_cells, dim3(div_up(N, tb)), dim3(tb), 0, stream, N, fpos, w.grid, w.cell_start, w.atom_cell,
-                           w.unsorted_atom, (const int*)nullptr, w.sorted_atom, w.sorted_pos);
+        // (the grid also emits cell-ordered positions; they land in scratch this op does not otherwise use)
+        const CellBuffers cb{w.grid, w.cell_count, w.cell_start, w.atom_cell, w.atom_rank, w.unsorted_atom, w.sorted_atom,
+                             w.sorted_pos, w.max_cells};
+        launch_cell_build(stream, N, fpos, fbox, periodic != 0, (float)cutoff, nullptr, cb);
         hipLaunchKernelGGL((pairs_cells<T, 0>), dim3(N), dim3(64), 0, stream, N, pos, box, periodic, cutoff2, num_slots, w.grid,
                            w.cell_start, w.atom_cell, w.sorted_atom, w.row_count, w.row_offset, neighbors, deltas, distances);
         hipLaunchKernelGGL(scan_rows, dim3(1), dim3(1024), 0, stream, N, w.row_count, w.row_offset, num_pairs);

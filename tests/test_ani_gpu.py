@@ -115,6 +115,36 @@ def test_cell_grid_falls_back_when_box_too_small():
     _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
 
 
+def test_cell_bins_grow_on_overflow(monkeypatch):
+    """The two-kernel grid build drops atom ids into fixed-capacity per-cell bins; a cell with more atoms than
+    a bin must be noticed on the device and the bins grown by check() (here forced: 4 ids per bin, ~13 per cell)."""
+    monkeypatch.setenv("NNPOPS_CELL_BIN_CAP", "4")
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1500, seed=21)
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, box, algorithm=2)
+
+
+def test_repeated_builds_reuse_clean_histogram():
+    """Ten evaluations on moving atoms through one handle: the cell histogram is cleared by the consumer kernel,
+    never by a memset, so stale counts would show up as wrong neighbours from the second call on."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1400, seed=22)
+    oracle = AniOracle(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True)
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True)
+    sym.set_neighbor_algorithm(2)
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    tbox = torch.tensor(box, device=dev)
+    for it in range(10):
+        pos = (pos + rng.normal(0, 0.05, pos.shape)).astype(np.float32)
+        radial, angular = sym.compute(torch.tensor(pos, device=dev), tbox)
+        if it in (0, 1, 9):
+            r_ref, a_ref = oracle.forward(pos, box)
+            np.testing.assert_allclose(radial.cpu().numpy(), r_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
+            np.testing.assert_allclose(angular.cpu().numpy(), a_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
+
+
 def test_single_atom_and_isolated_atoms():
     rf, af = workloads.ani2x_functions()
     pos = np.array([[0, 0, 0], [30, 0, 0], [0, 30, 0]], dtype=np.float32)

@@ -91,6 +91,13 @@ def test_periodic_box_cells():
     _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=1)
 
 
+def test_cell_bins_grow_on_overflow(monkeypatch):
+    """Same fixed-capacity bin protocol as the ANI handle (celllist.h): forced overflow, check() grows, rebuild."""
+    monkeypatch.setenv("NNPOPS_CELL_BIN_CAP", "4")
+    pos, _, box = workloads.random_box(1200, seed=41)
+    _case(pos, box, 32, 16, 5.0, 0.4, "ssp", seed=7)
+
+
 def test_nonperiodic_box_cells():
     pos, _, _ = workloads.random_box(1300, seed=32)
     _case(pos, None, 64, 50, 5.0, 0.1, "tanh", seed=2)
