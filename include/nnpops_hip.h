@@ -95,13 +95,15 @@ int nnpops_ani_set_neighbor_algorithm(nnpops_ani_t h, int algorithm);
  * num_molecules <= 0 restores the single-system behaviour. */
 int nnpops_ani_set_molecules(nnpops_ani_t h, int num_molecules, const int32_t* molecule_offsets);
 
-/* Per-kernel timing with HIP events recorded on the handle's stream around every kernel launch
- * (off by default; not for use during graph capture).  get_timing blocks on the stream, returns for
- * each kernel id the summed duration in milliseconds and the number of launches since the last
- * call / enable, and resets the counters.  Arrays have NNPOPS_ANI_NUM_KERNELS entries. */
+/* Per-kernel timing with HIP events recorded on the handle's stream around kernel launches
+ * (off by default; not for use during graph capture).  enable: 0 = off, 1 = every kernel, any other
+ * value = a mask with bit (id + 1) set for each kernel id to time (an event pair costs ~3 us of stream
+ * time on MI355X, so a benchmark times only the kernel it reports on).  get_timing blocks on the
+ * stream, returns for each kernel id the summed duration in milliseconds and the number of launches
+ * since the last call / enable, and resets the counters.  Arrays have NNPOPS_ANI_NUM_KERNELS entries. */
 enum {
     NNPOPS_ANI_K_NEIGHBORS = 0,
-    NNPOPS_ANI_K_RADIAL_FWD = 1,
+    NNPOPS_ANI_K_RADIAL_FWD = 1,      /* always 0 launches: the radial AEV is written by the neighbour kernel */
     NNPOPS_ANI_K_ANGULAR_FWD = 2,
     NNPOPS_ANI_K_RADIAL_BWD = 3,
     NNPOPS_ANI_K_ANGULAR_BWD = 4,

@@ -194,8 +194,13 @@ class AniSymmetryFunctions:
 
     KERNELS = ("neighbors", "radial_forward", "angular_forward", "radial_backward", "angular_backward")
 
-    def enable_timing(self, enable=True):
-        _check(self._lib.nnpops_ani_enable_timing(self._h, int(bool(enable))))
+    def enable_timing(self, enable=True, only=None):
+        """HIP-event timing of the kernels: all of them, or just the names in ``only`` (each event pair costs
+        a few microseconds of stream time, so benchmarks time one kernel inside their timed region)."""
+        mask = int(bool(enable))
+        if enable and only:
+            mask = sum(1 << (self.KERNELS.index(k) + 1) for k in only)
+        _check(self._lib.nnpops_ani_enable_timing(self._h, mask))
 
     def get_timing(self):
         """-> {kernel: (total_ms, launches)} since the last call; blocks on the stream."""

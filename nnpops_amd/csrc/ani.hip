@@ -51,7 +51,7 @@ struct nnpops_ani {
     bool computed = false;
     int debug = 0;                  // kernel ablation bits from $NNPOPS_ANI_DEBUG (timing experiments only)
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
-    bool timing = false;
+    unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
     size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {0, 0, 0, 0, 0};
 };
@@ -63,7 +63,7 @@ struct KernelTimer {
     nnpops_ani* h;
     int id;
     KernelTimer(nnpops_ani* h_, int id_) : h(h_), id(id_) {
-        if (!h->timing) return;
+        if (!(h->timing_mask >> id & 1)) return;
         if (h->ev_used[id] == h->ev_start[id].size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a);
@@ -74,7 +74,7 @@ struct KernelTimer {
         (void)hipEventRecord(h->ev_start[id][h->ev_used[id]], h->stream);
     }
     ~KernelTimer() {
-        if (!h->timing) return;
+        if (!(h->timing_mask >> id & 1)) return;
         (void)hipEventRecord(h->ev_stop[id][h->ev_used[id]], h->stream);
         h->ev_used[id]++;
     }
@@ -344,9 +344,9 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     // records the builder writes (displacements, not positions), so positions and box are read in place:
     // no copies, no memsets on the hot path.
 
-    // neighbour search: cell grid for large systems, the reference's all-pairs scan for small ones
+    // neighbour search + radial AEV: cell grid for large systems, the reference's all-pairs scan for small ones
     // (or when a previous compute found the box too small for the 27-cell stencil)
-    const int lds_bw = (int)((builder_lds_bytes(h->cap_angular, h->hp.S, h->hp.NB) + 15) & ~(size_t)15);
+    const int lds_bw = (int)((builder_lds_bytes(h->cap, h->hp.S, h->hp.NB) + 15) & ~(size_t)15);
     const int wpg_b = waves_per_group(lds_bw);
     const size_t lds_b = (size_t)lds_bw * wpg_b;
     const dim3 agrid(div_up(N, wpg_b)), ablock(64 * wpg_b);
@@ -361,30 +361,23 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
         if (per)
             hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw, h->d_hist);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist);
         else
             hipLaunchKernelGGL(ani_neighbors_cells<false>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, lds_bw, h->d_hist);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist);
     } else if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, lds_bw);
+                           h->d_cnt_a, h->d_cnt_ro, radial, lds_bw);
     else
         hipLaunchKernelGGL(ani_neighbors_allpairs<false>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, lds_bw);
+                           h->d_cnt_a, h->d_cnt_ro, radial, lds_bw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
 
-    const int lds_rw = (int)((3 * (size_t)h->cap * sizeof(float) + 15) & ~(size_t)15);
-    {
-    KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_FWD);
-    const int wpg_r = waves_per_group(lds_rw);
-    hipLaunchKernelGGL(ani_radial_forward, dim3(div_up(N, wpg_r)), dim3(64 * wpg_r), (size_t)lds_rw * wpg_r, h->stream, h->d_params, h->d_nbr, h->cap,
-                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial, lds_rw);
-    }
-    NNPOPS_HIP_TRY(hipGetLastError());
+    // (the radial AEV is written by the builder wave itself: radial_forward_from_lds)
 
     int rc = dispatch_angular(h, true, nullptr, angular);
     if (rc != NNPOPS_OK) return rc;
@@ -467,7 +460,7 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
 
 int nnpops_ani_enable_timing(nnpops_ani_t h, int enable) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
-    h->timing = enable != 0;
+    h->timing_mask = enable == 1 ? ~0u : (unsigned)enable >> 1;      // 1: all kernels; else bit (id + 1) selects kernel id
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) h->ev_used[k] = 0;
     return NNPOPS_OK;
 }

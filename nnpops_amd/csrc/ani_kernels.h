@@ -193,19 +193,19 @@ __device__ __forceinline__ void decode_triple(int NB, const AtomGroups& G, int t
 // Neighbour build.
 // =============================================================================================
 // Appends the lanes flagged in_a / in_ro to the two ends of a row (ballot compaction keeps scan
-// order); angular ones are also staged in LDS for the sort that follows the scan.
-__device__ __forceinline__ void append_to_row(float4* __restrict__ row, int cap, float4* stage, int capA, bool in_a,
+// order); the row is mirrored in LDS (`stage`, same layout) for the radial sums and the species sort
+// that follow the scan in the same kernel.
+__device__ __forceinline__ void append_to_row(float4* __restrict__ row, int cap, float4* stage, bool in_a,
                                               bool in_ro, float dx, float dy, float dz, int word, int& na, int& nro) {
     const unsigned long long ma = __ballot(in_a), mro = __ballot(in_ro);
     const float4 rec = make_float4(dx, dy, dz, __int_as_float(word));
     if (in_a) {
         const int slot = na + prefix_popc(ma);
-        if (slot < cap) row[slot] = rec;
-        if (slot < capA) stage[slot] = rec;
+        if (slot < cap) { row[slot] = rec; stage[slot] = rec; }
     }
     if (in_ro) {
         const int slot = nro + prefix_popc(mro);
-        if (slot < cap) row[cap - 1 - slot] = rec;
+        if (slot < cap) { row[cap - 1 - slot] = rec; stage[cap - 1 - slot] = rec; }
     }
     na += __popcll(ma);
     nro += __popcll(mro);
@@ -263,8 +263,59 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     }
 }
 
-__host__ __device__ inline size_t builder_lds_bytes(int capA, int S, int NB) {
-    return (size_t)capA * sizeof(float4) + group_ints(S, NB) * sizeof(int);
+// LDS of one builder wave: the row mirror [cap] float4 | radial scratch r, fc, species [3][cap] | species groups
+__host__ __device__ inline size_t builder_lds_bytes(int cap, int S, int NB) {
+    return (size_t)cap * (sizeof(float4) + 3 * sizeof(float)) + group_ints(S, NB) * sizeof(int);
+}
+
+// =============================================================================================
+// Radial forward, run by the builder wave on the row it has just assembled (LDS mirror): the radial
+// AEV needs nothing else, and a separate kernel would cost a launch boundary plus a re-read of the row.
+// =============================================================================================
+__device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restrict__ P, const float4* stage, int cap,
+                                                        int na, int nro, float* scratch, float* __restrict__ out) {
+    const int lane = lane_id();
+    const int S = P->S, nR = P->nR;
+    float* nb_r = scratch;                   // [cap]
+    float* nb_fc = nb_r + cap;               // [cap]
+    int* nb_sp = (int*)(nb_fc + cap);        // [cap]
+    const int total = na + nro;
+    const float rcr = P->rcr;
+    for (int e = lane; e < total; e += 64) {
+        const float4 rec = e < na ? stage[e] : stage[cap - 1 - (e - na)];
+        const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+        nb_r[e] = r;
+        nb_fc[e] = 0.5f * cospif(r / rcr) + 0.5f;
+        nb_sp[e] = __float_as_int(rec.w) >> kTagShift;
+    }
+    wave_fence();
+
+    // lanes = (stream, k): KP = smallest power of two >= nR.  Each lane keeps one partial sum per
+    // species in registers (select-accumulate), streams are folded with xor-shuffles at the end.
+    int KP = 1;
+    while (KP < nR) KP <<= 1;
+    const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
+    const float ck = P->rad_c[min(k, nR - 1)], rs = P->rad_rs[min(k, nR - 1)];
+    const float scale = P->radial_scale;
+    constexpr int SCHUNK = 8;
+    for (int s0 = 0; s0 < S; s0 += SCHUNK) {           // one pass per group of 8 species (one pass for ANI)
+        float part[SCHUNK];
+#pragma unroll
+        for (int s = 0; s < SCHUNK; s++) part[s] = 0.f;
+        for (int e = stream; e < total; e += nstreams) {
+            const float sh = nb_r[e] - rs;
+            const float v = nb_fc[e] * fast_exp2(ck * sh * sh);
+            const int sp = nb_sp[e] - s0;
+#pragma unroll
+            for (int s = 0; s < SCHUNK; s++) part[s] += (sp == s) ? v : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < SCHUNK; s++) {
+            float v = part[s];
+            for (int off = KP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (stream == 0 && k < nR && s0 + s < S) out[(s0 + s) * nR + k] = v * scale;
+        }
+    }
 }
 
 // All-pairs scan (the reference's O(N^2) search, one wave per atom; used for small systems and for
@@ -279,10 +330,11 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
                                                              int cap, int capA, float4* __restrict__ recA,
                                                              float4* __restrict__ recB, int* __restrict__ tri,
                                                              int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
-                                                             int lds_per_wave) {
+                                                             float* __restrict__ radial, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
-    const AtomGroups G = carve_groups((int*)(stage + capA), P->S, P->NB);
+    float* rscratch = (float*)(stage + cap);
+    const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap), P->S, P->NB);
     const int i = wave_global_id();
     const int lane = lane_id();
     const int N = P->N;
@@ -308,12 +360,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
             in_r = r2 < rcr2;
             in_a = in_r && (r2 < rca2);
         }
-        append_to_row(row, cap, stage, capA, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
+        append_to_row(row, cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
     }
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
+    radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
                      tri + (size_t)i * triples_capacity(capA), G);
 }
@@ -330,11 +383,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           int cap, int capA, float4* __restrict__ recA,
                                                           float4* __restrict__ recB, int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
-                                                          int* __restrict__ status, int lds_per_wave,
-                                                          int* __restrict__ cell_hist) {
+                                                          int* __restrict__ status, float* __restrict__ radial,
+                                                          int lds_per_wave, int* __restrict__ cell_hist) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
-    const AtomGroups G = carve_groups((int*)(stage + capA), P->S, P->NB);
+    float* rscratch = (float*)(stage + cap);
+    const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap), P->S, P->NB);
     const int lane = lane_id();
     const int slot_id = wave_global_id();                  // position in cell order
     clear_cell_histogram(cell_hist);
@@ -374,76 +428,16 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                     in_a = in_r && (r2 < rca2);
                 }
             }
-            append_to_row(row, cap, stage, capA, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
+            append_to_row(row, cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
         }
     });
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
+    radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
                      tri + (size_t)i * triples_capacity(capA), G);
-}
-
-// =============================================================================================
-// Radial forward.  LDS: per-neighbour {r, fc, species}.
-// =============================================================================================
-__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_forward(const AniParams* __restrict__ P,
-                                                         const float4* __restrict__ nbr, int cap, int cap_angular,
-                                                         const int* __restrict__ cnt_a,
-                                                         const int* __restrict__ cnt_ro, float* __restrict__ radial,
-                                                         int lds_per_wave) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    float* lds = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
-    const int i = wave_global_id(), lane = lane_id();
-    if (i >= P->N) return;
-    const int S = P->S, nR = P->nR, width = S * nR;
-    float* nb_r = lds;                       // [cap]
-    float* nb_fc = nb_r + cap;               // [cap]
-    int* nb_sp = (int*)(nb_fc + cap);        // [cap]
-
-    int na, nro;
-    clamp_counts(cnt_a[i], cnt_ro[i], cap, cap_angular, na, nro);
-    const int total = na + nro;
-    const float4* row = nbr + (size_t)i * cap;
-    const float rcr = P->rcr;
-
-    for (int e = lane; e < total; e += 64) {
-        const float4 rec = e < na ? row[e] : row[cap - 1 - (e - na)];
-        const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
-        nb_r[e] = r;
-        nb_fc[e] = 0.5f * cospif(r / rcr) + 0.5f;
-        nb_sp[e] = __float_as_int(rec.w) >> kTagShift;
-    }
-    wave_fence();
-
-    // lanes = (stream, k): KP = smallest power of two >= nR.  Each lane keeps one partial sum per
-    // species in registers (select-accumulate), streams are folded with xor-shuffles at the end.
-    int KP = 1;
-    while (KP < nR) KP <<= 1;
-    const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
-    const float ck = P->rad_c[min(k, nR - 1)], rs = P->rad_rs[min(k, nR - 1)];
-    const float scale = P->radial_scale;
-    float* out = radial + (size_t)i * width;
-    constexpr int SCHUNK = 8;
-    for (int s0 = 0; s0 < S; s0 += SCHUNK) {           // one pass per group of 8 species (one pass for ANI)
-        float part[SCHUNK];
-#pragma unroll
-        for (int s = 0; s < SCHUNK; s++) part[s] = 0.f;
-        for (int e = stream; e < total; e += nstreams) {
-            const float sh = nb_r[e] - rs;
-            const float v = nb_fc[e] * fast_exp2(ck * sh * sh);
-            const int sp = nb_sp[e] - s0;
-#pragma unroll
-            for (int s = 0; s < SCHUNK; s++) part[s] += (sp == s) ? v : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < SCHUNK; s++) {
-            float v = part[s];
-            for (int off = KP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            if (stream == 0 && k < nR && s0 + s < S) out[(s0 + s) * nR + k] = v * scale;
-        }
-    }
 }
 
 // =============================================================================================
