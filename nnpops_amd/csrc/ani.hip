@@ -27,6 +27,9 @@ struct nnpops_ani {
     float4* d_nbr = nullptr;        // [N][cap] records {dx, dy, dz, (species<<24)|atom}
     float4* d_recA = nullptr;       // [N][cap_angular] sorted angular records {dx,dy,dz,r}
     float4* d_recB = nullptr;       // [N][cap_angular]                        {fc,dfc,1/r,word}
+    int* d_ids = nullptr;           // [N][cap_angular] atom ids in record order (reverse lookup of the backward gather)
+    float4* d_leg_force = nullptr;  // [N][cap_angular] angular backward: force on each leg, record order
+    float4* d_centre_force = nullptr; // [N]            angular backward: reaction on the centre atom
     int* d_tri = nullptr;           // [N][cap_angular*(cap_angular-1)/2] bucket-major triple words
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
@@ -140,11 +143,13 @@ int factor_angular(AniParams& hp, const float* af, int nA) {
 }
 
 int alloc_rows(nnpops_ani* h) {
-    dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri);
+    dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_ids); dev_free(h->d_leg_force);
     int rc;
     if ((rc = dev_alloc(&h->d_nbr, (size_t)h->hp.N * h->cap))) return rc;
     if ((rc = dev_alloc(&h->d_recA, (size_t)h->hp.N * h->cap_angular))) return rc;
     if ((rc = dev_alloc(&h->d_recB, (size_t)h->hp.N * h->cap_angular))) return rc;
+    if ((rc = dev_alloc(&h->d_ids, (size_t)h->hp.N * h->cap_angular))) return rc;
+    if ((rc = dev_alloc(&h->d_leg_force, (size_t)h->hp.N * h->cap_angular))) return rc;
     return dev_alloc(&h->d_tri, (size_t)h->hp.N * triples_capacity(h->cap_angular));
 }
 
@@ -169,7 +174,8 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->tile, h->d_recA,
-                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, out, h->debug, lds_wave);
+                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->d_leg_force, h->d_centre_force, h->debug,
+                           lds_wave);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
@@ -253,6 +259,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_species, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_a, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_ro, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_centre_force, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_status, (size_t)kStatWords))) return cleanup(rc);
     if ((rc = alloc_rows(h))) return cleanup(rc);
     h->max_cells = num_atoms + 4096;
@@ -285,6 +292,7 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     DeviceGuard guard(h->device);
     dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_segment);
     dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
+    dev_free(h->d_ids); dev_free(h->d_leg_force); dev_free(h->d_centre_force);
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
     dev_free(h->d_atom_rank); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
@@ -361,18 +369,18 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
         if (per)
             hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist);
+                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist);
         else
             hipLaunchKernelGGL(ani_neighbors_cells<false>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist);
+                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist);
     } else if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
-                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, radial, lds_bw);
     else
         hipLaunchKernelGGL(ani_neighbors_allpairs<false>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
-                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, radial, lds_bw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
@@ -397,15 +405,18 @@ int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* 
     const size_t lds_r = (size_t)lds_rw * wpg_r;
     if (lds_r > 64 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "radial backward needs %zu bytes of LDS", lds_r);
     const dim3 agrid(div_up(N, wpg_r)), ablock(64 * wpg_r);
-    // radial backward owns position_deriv[i] (plain store) ...
+    // 1. angular backward parks the per-leg forces in leg_force / centre_force (no scatter) ...
+    int rc = dispatch_angular(h, false, angular_deriv, nullptr);
+    if (rc != NNPOPS_OK) return rc;
+    // 2. ... and the radial backward wave of every atom, the only writer of position_deriv[i], gathers them
     {
     KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD);
     hipLaunchKernelGGL(ani_radial_backward, agrid, ablock, lds_r, h->stream, h->d_params, h->d_species, h->d_nbr, h->cap,
-                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, position_deriv, lds_rw);
+                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->d_ids, h->d_leg_force, h->d_centre_force,
+                       position_deriv, lds_rw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
-    // ... and angular backward accumulates on top of it
-    return dispatch_angular(h, false, angular_deriv, position_deriv);
+    return NNPOPS_OK;
 }
 
 int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors) {

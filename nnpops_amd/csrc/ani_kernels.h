@@ -216,7 +216,7 @@ __device__ __forceinline__ void append_to_row(float4* __restrict__ row, int cap,
 // and the bucket-major triple list.  Runs once per atom per evaluation; forward and backward reuse it.
 __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P, const float4* stage, int n,
                                                  float4* __restrict__ recA, float4* __restrict__ recB,
-                                                 int* __restrict__ tri, const AtomGroups& G) {
+                                                 int* __restrict__ ids, int capA, int* __restrict__ tri, const AtomGroups& G) {
     const int lane = lane_id();
     const int S = P->S, NB = P->NB;
     const float rca = P->rca;
@@ -251,8 +251,10 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
             sincospif(r / rca, &sn, &cs);                  // fc = (cos(pi r/Rc)+1)/2, ref :381-387
             recA[rank] = make_float4(r4.x, r4.y, r4.z, r);
             recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi / rca) * sn, 1.0f / r, r4.w);
+            ids[rank] = word & kIdMask;                    // compact copy for the backward gather's reverse lookup
         }
     }
+    for (int e = n + lane; e < capA; e += 64) ids[e] = -1;    // the gather scans whole rows: no stale ids behind the list
     const int T = build_bucket_offsets(NB, G);
     int steps = 0;
     while ((1 << steps) < NB) steps++;
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
                                                              const int2* __restrict__ segment,   // per-atom [lo, hi) or NULL
                                                              float4* __restrict__ nbr,
                                                              int cap, int capA, float4* __restrict__ recA,
-                                                             float4* __restrict__ recB, int* __restrict__ tri,
+                                                             float4* __restrict__ recB, int* __restrict__ ids,
+                                                             int* __restrict__ tri,
                                                              int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
                                                              float* __restrict__ radial, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
     radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
-    finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
+    finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
                      tri + (size_t)i * triples_capacity(capA), G);
 }
 
@@ -381,7 +384,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           const int* __restrict__ atom_cell,
                                                           const float4* __restrict__ sorted_pos, float4* __restrict__ nbr,
                                                           int cap, int capA, float4* __restrict__ recA,
-                                                          float4* __restrict__ recB, int* __restrict__ tri,
+                                                          float4* __restrict__ recB, int* __restrict__ ids,
+                                                          int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
                                                           int* __restrict__ status, float* __restrict__ radial,
                                                           int lds_per_wave, int* __restrict__ cell_hist) {
@@ -436,12 +440,16 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
     radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
-    finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA,
+    finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
                      tri + (size_t)i * triples_capacity(capA), G);
 }
 
 // =============================================================================================
-// Radial backward (owner computes; writes position_deriv[i], no atomics).      ref :228-263
+// Radial backward + gather of the angular forces (owner computes; the only writer of
+// position_deriv[i]; no atomics anywhere in the backward pass).                      ref :228-263, :310-344
+// Runs AFTER ani_angular_backward.  The angular force on atom i is
+//     centre_force[i]  +  sum over angular neighbours i' of  leg_force[i'][slot of i in the records of i']
+// and the slot is found by scanning the compact id list of i' (<= capA ints, one or two cache lines).
 // =============================================================================================
 __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const AniParams* __restrict__ P,
                                                           const int* __restrict__ species,
@@ -449,6 +457,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
                                                           const float* __restrict__ radial_grad,
+                                                          const int* __restrict__ ids,
+                                                          const float4* __restrict__ leg_force,
+                                                          const float4* __restrict__ centre_force,
                                                           float* __restrict__ pos_grad, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float* lds = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
@@ -505,12 +516,34 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
             fx -= sc * nb_ux[e]; fy -= sc * nb_uy[e]; fz -= sc * nb_uz[e];
         }
     }
+    const float scale = P->radial_scale;
+    fx *= scale; fy *= scale; fz *= scale;
+    // angular legs: lane e looks itself up in the records of angular neighbour e (rows are padded with -1)
+    for (int e = lane; e < na; e += 64) {
+        const int ip = nb_j[e];
+        const int4* idrow = reinterpret_cast<const int4*>(ids + (size_t)ip * cap_angular);
+        int k = -1;
+        for (int q = 0; q < cap_angular; q += 4) {
+            const int4 v = idrow[q >> 2];
+            k = v.x == i ? q : k;
+            k = v.y == i ? q + 1 : k;
+            k = v.z == i ? q + 2 : k;
+            k = v.w == i ? q + 3 : k;
+        }
+        if (k >= 0) {
+            const float4 f = leg_force[(size_t)ip * cap_angular + k];
+            fx += f.x; fy += f.y; fz += f.z;
+        }
+    }
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (lane == 0) {
-        const float scale = P->radial_scale;
-        pos_grad[3 * i] = fx * scale;
-        pos_grad[3 * i + 1] = fy * scale;
-        pos_grad[3 * i + 2] = fz * scale;
+        if (na >= 2) {
+            const float4 c = centre_force[i];
+            fx += c.x; fy += c.y; fz += c.z;
+        }
+        pos_grad[3 * i] = fx;
+        pos_grad[3 * i + 1] = fy;
+        pos_grad[3 * i + 2] = fz;
     }
 }
 
@@ -917,7 +950,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                                                            const int* __restrict__ cnt_a,
                                                            const int* __restrict__ cnt_ro,
                                                            const float* __restrict__ angular_grad,
-                                                           float* __restrict__ pos_grad, int dbg, int lds_per_wave) {
+                                                           float4* __restrict__ leg_force,      // [N][capA]
+                                                           float4* __restrict__ centre_force,   // [N]
+                                                           int dbg, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int i = wave_global_id(), lane = lane_id();
     const int S = P->S, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
@@ -936,7 +971,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
 
     int n, nro;
     clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
-    if (n < 2 || (dbg & 32)) return;                       // no triples: nothing to add (wave-uniform)
+    if (n < 2 || (dbg & 32)) {                             // no triples (wave-uniform): a lone leg carries no force
+        if (n == 1 && lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int T = (n * (n - 1)) / 2;
     const int* tri = tri_g + (size_t)i * triples_capacity(capA);
     int word = lane < T ? tri[lane] : 0;
@@ -1077,19 +1115,19 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
             }
         }
     }
-    // scatter: +F on each leg atom, -(sum) on the centre
+    // No scatter: the force on leg e of this atom is parked in leg_force[i][e] (record order) and the reaction
+    // on the centre in centre_force[i]; ani_radial_backward_gather, which owns position_deriv[j], picks the
+    // legs up from the other side.  No atomics, bitwise reproducible forces.
     if (dbg & 4) return;
     float cx = 0.f, cy = 0.f, cz = 0.f;
+    float4* out = leg_force + (size_t)i * capA;
     for (int e = lane; e < n; e += 64) {
         const float fx = facc[e * 4], fy = facc[e * 4 + 1], fz = facc[e * 4 + 2];
-        const int j = __float_as_int(recB[e].w) & kIdMask;
-        atomicAdd(&pos_grad[3 * j], fx); atomicAdd(&pos_grad[3 * j + 1], fy); atomicAdd(&pos_grad[3 * j + 2], fz);
+        out[e] = make_float4(fx, fy, fz, 0.f);
         cx -= fx; cy -= fy; cz -= fz;
     }
     cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
-    if (lane == 0) {
-        atomicAdd(&pos_grad[3 * i], cx); atomicAdd(&pos_grad[3 * i + 1], cy); atomicAdd(&pos_grad[3 * i + 2], cz);
-    }
+    if (lane == 0) centre_force[i] = make_float4(cx, cy, cz, 0.f);
 }
 
 }  // namespace nnpops

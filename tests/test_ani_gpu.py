@@ -145,6 +145,28 @@ def test_repeated_builds_reuse_clean_histogram():
             np.testing.assert_allclose(angular.cpu().numpy(), a_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
 
 
+def test_forces_bitwise_reproducible():
+    """The backward pass has no atomics (legs are gathered by the owner atom), so two evaluations of the same
+    frame must agree to the last bit -- something the reference's CUDA path (atomicAdd scatter) cannot promise."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1300, seed=23)
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    runs = []
+    for _ in range(3):
+        radial, angular = sym.compute(tpos, tbox)
+        if not runs:
+            g_r = torch.randn(radial.shape, device=dev, generator=gen)
+            g_a = torch.randn(angular.shape, device=dev, generator=gen)
+        grad = sym.backprop(g_r, g_a)
+        runs.append((radial.cpu().numpy().copy(), angular.cpu().numpy().copy(), grad.cpu().numpy().copy()))
+    for r, a, g in runs[1:]:
+        assert np.array_equal(r, runs[0][0]) and np.array_equal(a, runs[0][1]) and np.array_equal(g, runs[0][2])
+
+
 def test_single_atom_and_isolated_atoms():
     rf, af = workloads.ani2x_functions()
     pos = np.array([[0, 0, 0], [30, 0, 0], [0, 30, 0]], dtype=np.float32)
