@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
                                                           int* __restrict__ status, float* __restrict__ radial,
-                                                          int lds_per_wave, int* __restrict__ cell_hist) {
+                                                          int lds_per_wave, int* __restrict__ cell_hist, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
@@ -415,31 +415,33 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
     float4* row = nbr + (size_t)i * cap;
     int na = 0, nro = 0;
-    for_each_stencil_range(g, cell_start, cx, cy, cz, [&](int begin, int end) {
-        for (int base = begin; base < end; base += 64) {
-            const int k = base + lane;
-            bool in_r = false, in_a = false;
-            int word = 0;
-            float dx = 0.f, dy = 0.f, dz = 0.f;
-            if (k < end) {
-                const float4 pj = sorted_pos[k];
-                word = __float_as_int(pj.w);
-                if ((word & kIdMask) != i) {
-                    dx = pj.x - me.x; dy = pj.y - me.y; dz = pj.z - me.z;
-                    min_image<PERIODIC>(dx, dy, dz, b);
-                    const float r2 = dx * dx + dy * dy + dz * dz;
-                    in_r = r2 < rcr2;
-                    in_a = in_r && (r2 < rca2);
-                }
+    const Stencil st = gather_stencil(g, cell_start, cx, cy, cz);
+    float4 pj = sorted_pos[lane < st.total ? stencil_slot(st, lane) : 0];
+    for (int base = 0; base < ((dbg & 256) ? 0 : st.total); base += 64) {
+        const int k = base + lane;
+        const float4 cur = pj;
+        if (base + 64 < st.total) pj = sorted_pos[k + 64 < st.total ? stencil_slot(st, k + 64) : 0];   // next batch in flight
+        bool in_r = false, in_a = false;
+        int word = 0;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (k < st.total) {
+            word = __float_as_int(cur.w);
+            if ((word & kIdMask) != i) {
+                dx = cur.x - me.x; dy = cur.y - me.y; dz = cur.z - me.z;
+                min_image<PERIODIC>(dx, dy, dz, b);
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                in_r = r2 < rcr2;
+                in_a = in_r && (r2 < rca2);
             }
-            append_to_row(row, cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
         }
-    });
+        append_to_row(row, cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
+    }
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
-    radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
+    if (!(dbg & 64)) radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
+    if (dbg & 128) return;
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
                      tri + (size_t)i * triples_capacity(capA), G);
 }

@@ -298,6 +298,61 @@ static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, con
     sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
 }
 
+// The same stencil as ONE flat candidate index space: lane r < 18 looks up range r, a wave scan gives
+// the offsets, and candidate k of the atom is sorted slot k + off[range of k].  A consumer then runs
+// ceil(candidates / 64) full iterations with independent loads instead of one (mostly half-empty,
+// latency-serialised) iteration per range.  Same candidate order as for_each_stencil_range.
+constexpr int kStencilRanges = 18;
+struct Stencil {
+    int pre[kStencilRanges];      // first flat index of range r           (wave-uniform: SGPRs)
+    int off[kStencilRanges];      // begin_r - pre[r]
+    int total;
+};
+
+__device__ __forceinline__ Stencil gather_stencil(const CellGrid& g, const int* __restrict__ cell_start, int cx, int cy, int cz) {
+    const int lane = lane_id();
+    int begin = 0, end = 0;
+    if (lane < kStencilRanges) {
+        const int pair = lane >> 1, sub = lane & 1;
+        int z = cz + pair / 3 - 1, y = cy + pair % 3 - 1;
+        bool live = true;
+        if (g.periodic) { z = (z + g.nz) % g.nz; y = (y + g.ny) % g.ny; }
+        else live = z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+        if (live) {
+            const int rowbase = (z * g.ny + y) * g.nx;
+            int x0 = cx - 1, x1 = cx + 1, a = 0, b = -1;              // cells [a, b] of this row
+            if (!g.periodic) { if (sub == 0) { a = max(x0, 0); b = min(x1, g.nx - 1); } }
+            else if (x0 < 0) { if (sub == 0) { a = b = g.nx - 1; } else { a = 0; b = x1; } }
+            else if (x1 >= g.nx) { if (sub == 0) { a = x0; b = g.nx - 1; } else { a = b = 0; } }
+            else if (sub == 0) { a = x0; b = x1; }
+            if (b >= a) { begin = cell_start[rowbase + a]; end = cell_start[rowbase + b + 1]; }
+        }
+    }
+    const int count = end - begin;
+    int incl = count;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {                               // 18 live lanes: five steps
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const int excl = incl - count, delta = begin - excl;
+    Stencil S;
+#pragma unroll
+    for (int r = 0; r < kStencilRanges; r++) {
+        S.pre[r] = __builtin_amdgcn_readlane(excl, r);
+        S.off[r] = __builtin_amdgcn_readlane(delta, r);
+    }
+    S.total = __builtin_amdgcn_readlane(incl, kStencilRanges - 1);
+    return S;
+}
+
+__device__ __forceinline__ int stencil_slot(const Stencil& S, int k) {
+    int off = S.off[0];
+#pragma unroll
+    for (int r = 1; r < kStencilRanges; r++) off = k >= S.pre[r] ? S.off[r] : off;
+    return k + off;
+}
+
 // Called by the kernel that consumes the grid (all of its threads, before any early exit): leaves the
 // histogram of the two-kernel build zeroed for the next build.  `hist` may be NULL (five-kernel path).
 __device__ __forceinline__ void clear_cell_histogram(int* __restrict__ hist) {
