@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 from nnpops_amd import workloads  # noqa: E402
 from nnpops_amd.capi import AniSymmetryFunctions  # noqa: E402
 
+ROOFLINE_KERNELS = ("neighbors", "angular_forward", "angular_backward", "radial_backward")   # candidates for "dominant"
+
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -128,7 +130,7 @@ def main():
     if not args.warmup:
         step()
     kern_all = {k: (1e-3 * ms / max(c, 1)) for k, (ms, c) in breakdown.items()}
-    dominant = max(("angular_forward", "angular_backward"), key=lambda k: kern_all.get(k, 0.0))
+    dominant = max(ROOFLINE_KERNELS, key=lambda k: kern_all.get(k, 0.0))
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -163,8 +165,17 @@ def main():
         kern = dict(kern_all)                                                      # seconds per launch (warm-up pass)
         ms_dom, c_dom = timing[dominant]
         kern[dominant] = 1e-3 * ms_dom / max(c_dom, 1)                             # ... the dominant one from the timed region
-        nb_na = sym.angular_width
-        alg_bytes = {"angular_forward": n * 16 + n * nb_na * 4, "angular_backward": n * nb_na * 4 + n * 12}
+        # Algorithmic bytes per launch: unique bytes in + bytes out, no re-reads.
+        #   angular forward   N*16 (records) + N*896*4 (row written once)
+        #   angular backward  N*896*4 (upstream row read once) + N*12
+        #   neighbours        N*16 in (cell-ordered positions) + per atom: row <n_Rcr>*16, records <n_Rca>*36,
+        #                     triple list <triples>*4, radial AEV S*nR*4, counts 8   (liquid-density means of s8)
+        #   radial backward   N*S*nR*4 (gradient row) + row <n_Rcr>*16 + legs <n_Rca>*20 + N*12
+        nb_na, nb_nr = sym.angular_width, sym.radial_width
+        n_rcr, n_rca, n_tri = 55.6, 18.0, 153.0
+        alg_bytes = {"angular_forward": n * 16 + n * nb_na * 4, "angular_backward": n * nb_na * 4 + n * 12,
+                     "neighbors": int(n * (16 + n_rcr * 16 + n_rca * 36 + n_tri * 4 + nb_nr * 4 + 8)),
+                     "radial_backward": int(n * (nb_nr * 4 + n_rcr * 16 + n_rca * 20 + 12))}
         achieved = alg_bytes[dominant] / kern[dominant] / 1e9 if kern[dominant] > 0 else 0.0
         traffic = None                                           # HBM bytes/launch from the committed PMC passes
         try:

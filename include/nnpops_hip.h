@@ -102,12 +102,13 @@ int nnpops_ani_set_molecules(nnpops_ani_t h, int num_molecules, const int32_t* m
  * stream, returns for each kernel id the summed duration in milliseconds and the number of launches
  * since the last call / enable, and resets the counters.  Arrays have NNPOPS_ANI_NUM_KERNELS entries. */
 enum {
-    NNPOPS_ANI_K_NEIGHBORS = 0,
+    NNPOPS_ANI_K_NEIGHBORS = 0,       /* neighbour rows + records + triple lists + radial AEV (one launch) */
     NNPOPS_ANI_K_RADIAL_FWD = 1,      /* always 0 launches: the radial AEV is written by the neighbour kernel */
     NNPOPS_ANI_K_ANGULAR_FWD = 2,
     NNPOPS_ANI_K_RADIAL_BWD = 3,
     NNPOPS_ANI_K_ANGULAR_BWD = 4,
-    NNPOPS_ANI_NUM_KERNELS = 5
+    NNPOPS_ANI_K_CELL_GRID = 5,       /* the grid build in front of the neighbour kernel (2 or 5 launches; 0 for all-pairs) */
+    NNPOPS_ANI_NUM_KERNELS = 6
 };
 int nnpops_ani_enable_timing(nnpops_ani_t h, int enable);
 int nnpops_ani_get_timing(nnpops_ani_t h, double* total_ms, int* launches);

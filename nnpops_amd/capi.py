@@ -192,7 +192,7 @@ class AniSymmetryFunctions:
         _check(self._lib.nnpops_ani_backprop(self._h, _ptr(radial_grad), _ptr(angular_grad), _ptr(position_grad)))
         return position_grad
 
-    KERNELS = ("neighbors", "radial_forward", "angular_forward", "radial_backward", "angular_backward")
+    KERNELS = ("neighbors", "radial_forward", "angular_forward", "radial_backward", "angular_backward", "cell_grid")
 
     def enable_timing(self, enable=True, only=None):
         """HIP-event timing of the kernels: all of them, or just the names in ``only`` (each event pair costs

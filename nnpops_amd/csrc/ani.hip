@@ -56,7 +56,7 @@ struct nnpops_ani {
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
-    size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {0, 0, 0, 0, 0};
+    size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {};
 };
 
 namespace {
@@ -359,13 +359,16 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     const size_t lds_b = (size_t)lds_bw * wpg_b;
     const dim3 agrid(div_up(N, wpg_b)), ablock(64 * wpg_b);
     const bool use_cells = !h->d_segment && (h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled));
-    {
-    KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
     if (use_cells) {
+        KernelTimer timer(h, NNPOPS_ANI_K_CELL_GRID);
         const CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank,
                              h->d_unsorted_atom, h->d_sorted_atom, h->d_sorted_pos, h->max_cells,
                              h->d_hist, h->d_bins, h->bin_cap};
         launch_cell_build(h->stream, N, positions, box, per, h->hp.rcr, h->d_species, cb);
+    }
+    {
+    KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
+    if (use_cells) {
         if (per)
             hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,

@@ -220,38 +220,56 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     const int lane = lane_id();
     const int S = P->S, NB = P->NB;
     const float rca = P->rca;
-    for (int s = lane; s < S; s += 64) { G.gn[s] = 0; G.run[s] = 0; }
     for (int bk = lane; bk < NB; bk += 64) { G.ba[bk] = P->bkt_a[bk]; G.bb[bk] = P->bkt_b[bk]; }
-    wave_fence();
-    for (int e = lane; e < n; e += 64) atomicAdd(&G.gn[__float_as_int(stage[e].w) >> kTagShift], 1);   // int LDS atomics
-    wave_fence();
-    if (lane == 0) {
-        int accum = 0;
-        for (int s = 0; s < S; s++) { G.gs[s] = accum; accum += G.gn[s]; }
-    }
-    wave_fence();
-    for (int base = 0; base < n; base += 64) {
-        const int e = base + lane;
-        const bool valid = e < n;
-        const float4 r4 = valid ? stage[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int word = __float_as_int(r4.w);
-        const int sp = valid ? (word >> kTagShift) : -1;
-        int rank = 0;
+    auto emit = [&](const float4& r4, int rank) {
+        const float r = sqrtf(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);
+        float sn, cs;
+        sincospif(r / rca, &sn, &cs);                      // fc = (cos(pi r/Rc)+1)/2, ref :381-387
+        recA[rank] = make_float4(r4.x, r4.y, r4.z, r);
+        recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi / rca) * sn, 1.0f / r, r4.w);
+        ids[rank] = __float_as_int(r4.w) & kIdMask;        // compact copy for the backward gather's reverse lookup
+    };
+    if (n <= 64) {
+        // one neighbour per lane: the stable species sort is S ballots, no LDS traffic, no fences
+        const bool valid = lane < n;
+        const float4 r4 = valid ? stage[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int sp = valid ? (__float_as_int(r4.w) >> kTagShift) : -1;
+        int rank = 0, accum = 0, my_gs = 0, my_gn = 0;
         for (int s = 0; s < S; s++) {
-            const unsigned long long m = __ballot(valid && sp == s);
-            if (m == 0) continue;                         // wave-uniform
-            if (sp == s) rank = G.gs[s] + G.run[s] + prefix_popc(m);
-            wave_fence();
-            if (lane == 0) G.run[s] += __popcll(m);
-            wave_fence();
+            const unsigned long long m = __ballot(sp == s);
+            const int c = __popcll(m);
+            if (sp == s) rank = accum + prefix_popc(m);
+            if (lane == s) { my_gs = accum; my_gn = c; }
+            accum += c;
         }
-        if (valid) {
-            const float r = sqrtf(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);
-            float sn, cs;
-            sincospif(r / rca, &sn, &cs);                  // fc = (cos(pi r/Rc)+1)/2, ref :381-387
-            recA[rank] = make_float4(r4.x, r4.y, r4.z, r);
-            recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi / rca) * sn, 1.0f / r, r4.w);
-            ids[rank] = word & kIdMask;                    // compact copy for the backward gather's reverse lookup
+        if (lane < S) { G.gs[lane] = my_gs; G.gn[lane] = my_gn; }     // S <= kMaxSpecies <= 64
+        if (valid) emit(r4, rank);
+        wave_fence();
+    } else {
+        for (int s = lane; s < S; s += 64) { G.gn[s] = 0; G.run[s] = 0; }
+        wave_fence();
+        for (int e = lane; e < n; e += 64) atomicAdd(&G.gn[__float_as_int(stage[e].w) >> kTagShift], 1);   // int LDS atomics
+        wave_fence();
+        if (lane == 0) {
+            int accum = 0;
+            for (int s = 0; s < S; s++) { G.gs[s] = accum; accum += G.gn[s]; }
+        }
+        wave_fence();
+        for (int base = 0; base < n; base += 64) {
+            const int e = base + lane;
+            const bool valid = e < n;
+            const float4 r4 = valid ? stage[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int sp = valid ? (__float_as_int(r4.w) >> kTagShift) : -1;
+            int rank = 0;
+            for (int s = 0; s < S; s++) {
+                const unsigned long long m = __ballot(valid && sp == s);
+                if (m == 0) continue;                         // wave-uniform
+                if (sp == s) rank = G.gs[s] + G.run[s] + prefix_popc(m);
+                wave_fence();
+                if (lane == 0) G.run[s] += __popcll(m);
+                wave_fence();
+            }
+            if (valid) emit(r4, rank);
         }
     }
     for (int e = n + lane; e < capA; e += 64) ids[e] = -1;    // the gather scans whole rows: no stale ids behind the list
@@ -304,6 +322,7 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
         float part[SCHUNK];
 #pragma unroll
         for (int s = 0; s < SCHUNK; s++) part[s] = 0.f;
+#pragma unroll 4
         for (int e = stream; e < total; e += nstreams) {
             const float sh = nb_r[e] - rs;
             const float v = nb_fc[e] * fast_exp2(ck * sh * sh);
@@ -416,11 +435,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     float4* row = nbr + (size_t)i * cap;
     int na = 0, nro = 0;
     const Stencil st = gather_stencil(g, cell_start, cx, cy, cz);
-    float4 pj = sorted_pos[lane < st.total ? stencil_slot(st, lane) : 0];
+    // (stencil_slot reads other lanes' registers: every lane calls it, out-of-range lanes with a clamped index)
+    float4 pj = sorted_pos[stencil_slot(st, min(lane, max(st.total - 1, 0)))];
     for (int base = 0; base < ((dbg & 256) ? 0 : st.total); base += 64) {
         const int k = base + lane;
         const float4 cur = pj;
-        if (base + 64 < st.total) pj = sorted_pos[k + 64 < st.total ? stencil_slot(st, k + 64) : 0];   // next batch in flight
+        const int next_slot = stencil_slot(st, min(k + 64, st.total - 1));
+        if (base + 64 < st.total) pj = sorted_pos[next_slot];                                   // next batch in flight
         bool in_r = false, in_a = false;
         int word = 0;
         float dx = 0.f, dy = 0.f, dz = 0.f;

@@ -305,7 +305,7 @@ static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, con
 constexpr int kStencilRanges = 18;
 struct Stencil {
     int pre[kStencilRanges];      // first flat index of range r           (wave-uniform: SGPRs)
-    int off[kStencilRanges];      // begin_r - pre[r]
+    int delta;                    // lane r: begin_r - pre[r]              (per lane: read back with ds_bpermute)
     int total;
 };
 
@@ -335,22 +335,23 @@ __device__ __forceinline__ Stencil gather_stencil(const CellGrid& g, const int* 
         const int up = __shfl_up(incl, o, 64);
         if (lane >= o) incl += up;
     }
-    const int excl = incl - count, delta = begin - excl;
+    const int excl = incl - count;
     Stencil S;
 #pragma unroll
-    for (int r = 0; r < kStencilRanges; r++) {
-        S.pre[r] = __builtin_amdgcn_readlane(excl, r);
-        S.off[r] = __builtin_amdgcn_readlane(delta, r);
-    }
+    for (int r = 0; r < kStencilRanges; r++) S.pre[r] = __builtin_amdgcn_readlane(excl, r);
+    S.delta = begin - excl;
     S.total = __builtin_amdgcn_readlane(incl, kStencilRanges - 1);
     return S;
 }
 
+// flat candidate index -> sorted slot.  The offsets are non-decreasing, so the range of k is the number of
+// range starts <= k (empty ranges share a start with their successor, which is the one that counts).
+// Must be called by ALL lanes of the wave (ds_bpermute returns 0 for a source lane that is masked off).
 __device__ __forceinline__ int stencil_slot(const Stencil& S, int k) {
-    int off = S.off[0];
+    int r = 0;
 #pragma unroll
-    for (int r = 1; r < kStencilRanges; r++) off = k >= S.pre[r] ? S.off[r] : off;
-    return k + off;
+    for (int q = 1; q < kStencilRanges; q++) r += k >= S.pre[q] ? 1 : 0;
+    return k + __builtin_amdgcn_ds_bpermute(r << 2, S.delta);
 }
 
 // Called by the kernel that consumes the grid (all of its threads, before any early exit): leaves the
