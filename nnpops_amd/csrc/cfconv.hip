@@ -592,6 +592,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
             // ---- layer 2 on Y1 ----
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+#pragma unroll 4
             for (int s = 0; s < W / 4; s++) {
                 const int k = 4 * s + grp;
                 const float a = y1[col * YS + k];
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
                     dacc[cb][q] = 0.f;
                 }
             wave_fence();
+#pragma unroll 4
             for (int s = 0; s < W / 4; s++) {
                 const int k = 4 * s + grp;
                 const float a = y1[col * YS + k];
