@@ -283,9 +283,10 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     }
 }
 
-// LDS of one builder wave: the row mirror [cap] float4 | radial scratch r, fc, species [3][cap] | species groups
+// LDS of one builder wave: the row mirror [cap] float4 | radial scratch r, fc, species [3][cap] | radial bins
+// [64 * S] | species groups
 __host__ __device__ inline size_t builder_lds_bytes(int cap, int S, int NB) {
-    return (size_t)cap * (sizeof(float4) + 3 * sizeof(float)) + group_ints(S, NB) * sizeof(int);
+    return (size_t)cap * (sizeof(float4) + 3 * sizeof(float)) + (size_t)64 * S * sizeof(float) + group_ints(S, NB) * sizeof(int);
 }
 
 // =============================================================================================
@@ -310,32 +311,28 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
     }
     wave_fence();
 
-    // lanes = (stream, k): KP = smallest power of two >= nR.  Each lane keeps one partial sum per
-    // species in registers (select-accumulate), streams are folded with xor-shuffles at the end.
+    // lanes = (stream, k): KP = smallest power of two >= nR.  Every (stream, species, k) has a private LDS bin,
+    // so the scatter by species is one plain read-modify-write per neighbour (LDS operations of a wave execute
+    // in order: back-to-back hits on one bin are safe) instead of a compare/select per species in registers.
     int KP = 1;
     while (KP < nR) KP <<= 1;
     const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
     const float ck = P->rad_c[min(k, nR - 1)], rs = P->rad_rs[min(k, nR - 1)];
+    float* bins = (float*)(nb_sp + cap);               // [nstreams][S][KP] = 64 * S floats
+    for (int s = 0; s < S; s++) bins[s * 64 + lane] = 0.f;
+    wave_fence();
+    float* mine = bins + stream * S * KP + k;
+    for (int e = stream; e < total; e += nstreams) {
+        const float sh = nb_r[e] - rs;
+        mine[nb_sp[e] * KP] += nb_fc[e] * fast_exp2(ck * sh * sh);
+    }
+    wave_fence();
     const float scale = P->radial_scale;
-    constexpr int SCHUNK = 8;
-    for (int s0 = 0; s0 < S; s0 += SCHUNK) {           // one pass per group of 8 species (one pass for ANI)
-        float part[SCHUNK];
-#pragma unroll
-        for (int s = 0; s < SCHUNK; s++) part[s] = 0.f;
-#pragma unroll 4
-        for (int e = stream; e < total; e += nstreams) {
-            const float sh = nb_r[e] - rs;
-            const float v = nb_fc[e] * fast_exp2(ck * sh * sh);
-            const int sp = nb_sp[e] - s0;
-#pragma unroll
-            for (int s = 0; s < SCHUNK; s++) part[s] += (sp == s) ? v : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < SCHUNK; s++) {
-            float v = part[s];
-            for (int off = KP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            if (stream == 0 && k < nR && s0 + s < S) out[(s0 + s) * nR + k] = v * scale;
-        }
+    for (int q = lane; q < S * nR; q += 64) {
+        const int sp = q / nR, kk = q - sp * nR;
+        float v = 0.f;
+        for (int st = 0; st < nstreams; st++) v += bins[(st * S + sp) * KP + kk];
+        out[q] = v * scale;
     }
 }
 
@@ -356,7 +353,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
-    const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap), P->S, P->NB);
+    const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap + 64 * P->S), P->S, P->NB);
     const int i = wave_global_id();
     const int lane = lane_id();
     const int N = P->N;
@@ -411,7 +408,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
-    const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap), P->S, P->NB);
+    const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap + 64 * P->S), P->S, P->NB);
     const int lane = lane_id();
     const int slot_id = wave_global_id();                  // position in cell order
     clear_cell_histogram(cell_hist);
@@ -524,6 +521,18 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     }
     wave_fence();
 
+    // Common shape (capA = 32, at most 64 angular neighbours): the id row of this lane's angular neighbour is
+    // requested now and consumed after the radial loop, which hides the latency of the reverse lookup.
+    const bool early = cap_angular == 32 && na <= 64;
+    int4 idv[8];
+    int ip_early = 0;
+    if (early) {
+        ip_early = lane < na ? nb_j[lane] : i;
+        const int4* idrow = reinterpret_cast<const int4*>(ids + (size_t)ip_early * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) idv[q] = idrow[q];
+    }
+
     int KP = 1;
     while (KP < nR) KP <<= 1;
     const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
@@ -542,6 +551,20 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     const float scale = P->radial_scale;
     fx *= scale; fy *= scale; fz *= scale;
     // angular legs: lane e looks itself up in the records of angular neighbour e (rows are padded with -1)
+    if (early) {
+        int slot = -1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            slot = idv[q].x == i ? 4 * q : slot;
+            slot = idv[q].y == i ? 4 * q + 1 : slot;
+            slot = idv[q].z == i ? 4 * q + 2 : slot;
+            slot = idv[q].w == i ? 4 * q + 3 : slot;
+        }
+        if (lane < na && slot >= 0) {
+            const float4 f = leg_force[(size_t)ip_early * 32 + slot];
+            fx += f.x; fy += f.y; fz += f.z;
+        }
+    } else
     for (int e = lane; e < na; e += 64) {
         const int ip = nb_j[e];
         const int4* idrow = reinterpret_cast<const int4*>(ids + (size_t)ip * cap_angular);
