@@ -75,14 +75,16 @@ def main():
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
-    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv", "conformers"],
-                    help="aev: the headline metric (default); cfconv: BASELINE config 3; conformers: BASELINE config 4 "
-                         "(side measurements, same JSON shape)")
+    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv", "conformers", "neighbors"],
+                    help="aev: the headline metric (default); cfconv: BASELINE config 3; conformers: BASELINE config 4; "
+                         "neighbors: BASELINE config 5 (side measurements, same JSON shape)")
     args = ap.parse_args()
     if args.workload == "cfconv":
         return main_cfconv(args)
     if args.workload == "conformers":
         return main_conformers(args)
+    if args.workload == "neighbors":
+        return main_neighbors(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,6 +206,71 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_neighbors(args):
+    """BASELINE config 5: getNeighborPairs (cutoff 5.2 A, compact mode) + ANI-2x AEV on the same 100 000-atom
+    periodic box (uniform 0.1 atoms/A^3, seed 6).  The reference cannot run this size at all (O(N^2) pair index
+    overflows int32, getNeighborPairsCUDA.cu:129).  One step = one neighbour-pair list + one AEV forward+backward.
+    Side measurement (not the headline metric)."""
+    from nnpops_amd.capi import neighbor_pairs_forward
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    n = args.atoms if args.atoms != 10000 else 100000
+    cutoff, max_pairs = 5.2, int(32 * n)
+    pos, species, box = workloads.random_box(n, density=0.1, seed=6, n_species=7)
+    rf, af = workloads.ani2x_functions()
+    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=True, device=local_rank)
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    radial = torch.empty((n, sym.radial_width), device=dev)
+    angular = torch.empty((n, sym.angular_width), device=dev)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    g_rad = torch.randn(radial.shape, device=dev, generator=gen)
+    g_ang = torch.randn(angular.shape, device=dev, generator=gen)
+    grad = torch.empty((n, 3), device=dev)
+    sym.compute(tpos, tbox, radial, angular, check=True)
+    nb, dl, ds, npairs = neighbor_pairs_forward(tpos, cutoff, max_pairs, tbox)
+    found = int(npairs.item())
+    assert 0 < found < max_pairs
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        neighbor_pairs_forward(tpos, cutoff, max_pairs, tbox)
+        if ev: ev[1].record()
+        sym.compute(tpos, tbox, radial, angular, check=False)
+        if ev: ev[2].record()
+        sym.backprop(g_rad, g_ang, grad)
+        if ev: ev[3].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    step(ev)                                           # one extra, event-bracketed step for the phase split
+    torch.cuda.synchronize()
+    t_nb, t_fwd, t_bwd = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    nb_bytes = n * 12 + found * 24                      # SURVEY s8(d): positions in, (2 ints + 3 floats + 1 float) per pair out
+    aev_bytes = n * (16 + 2 * (sym.radial_width + sym.angular_width) * 4 + 12)
+    print(json.dumps({
+        "metric": "getNeighborPairs + ANI-2x AEV forward+backward evaluations/sec, 100k-atom periodic box, cutoff 5.2 A",
+        "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"getNeighborPairs(cutoff {cutoff}, max_num_pairs {max_pairs}) + ANI-2x AEV, {n} atoms periodic, "
+                               "0.1 atoms/A^3, 7 species", "atoms": n, "pairs_found": found},
+        "phases_ms": {"neighbor_pairs": round(t_nb, 4), "aev_forward": round(t_fwd, 4), "aev_backward": round(t_bwd, 4)},
+        "roofline": {"bound": "hbm", "kernel": "getNeighborPairs (3 launches + cell grid)", "achieved": round(nb_bytes / (t_nb * 1e-3) / 1e9, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb_bytes / (t_nb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "traffic": None, "algorithmic_bytes_per_launch": nb_bytes,
+                     "aev_step": {"algorithmic_bytes": aev_bytes,
+                                  "achieved": round(aev_bytes / ((t_fwd + t_bwd) * 1e-3) / 1e9, 2)}},
+    }), flush=True)
 
 
 def main_conformers(args):

@@ -31,6 +31,12 @@ namespace {
 
 template <typename T> struct Vec3 { T x, y, z; };
 
+// rows are scanned in blocks of kScanBlock (scan_rows below): offset of a row = offset inside its block + block prefix
+constexpr int kScanBlock = 1024;
+__device__ __forceinline__ long long first_slot(const int* __restrict__ row_offset, const int* __restrict__ block_prefix, int row) {
+    return (long long)row_offset[row] + block_prefix[row >> 10];
+}
+
 template <typename T>
 __device__ __forceinline__ Vec3<T> wrapped_delta(const T* __restrict__ pos, int row, int col, const T* __restrict__ box,
                                                  bool periodic) {
@@ -66,13 +72,15 @@ template <typename T, int PASS, bool ALL_SLOTS>
 __global__ __launch_bounds__(64) void pairs_allpairs(int N, const T* __restrict__ pos, const T* __restrict__ box,
                                                      int periodic, T cutoff2, long long num_slots,
                                                      int* __restrict__ row_count, const int* __restrict__ row_offset,
+                                                     const int* __restrict__ block_prefix, int* __restrict__ ticket,
                                                      int32_t* __restrict__ neighbors, T* __restrict__ deltas,
                                                      T* __restrict__ distances, int32_t* __restrict__ num_pairs) {
     const int row = blockIdx.x;
     const int lane = lane_id();
+    if (PASS == 0 && !ALL_SLOTS && row == 0 && lane == 0) *ticket = 0;     // the scan's ticket counter (workspace is not zeroed)
     long long base_slot = 0;
     if (ALL_SLOTS) base_slot = (long long)row * (row - 1) / 2;
-    else if (PASS == 1) base_slot = row_offset[row];
+    else if (PASS == 1) base_slot = first_slot(row_offset, block_prefix, row);
     int found = 0;
     for (int c0 = 0; c0 < row; c0 += 64) {
         const int col = c0 + lane;
@@ -103,84 +111,210 @@ __global__ __launch_bounds__(64) void pairs_allpairs(int N, const T* __restrict_
 }
 
 // ---- cell-grid search: one wave per atom ("row"), candidates = stencil atoms with a smaller id --------
-template <typename T, int PASS>
-__global__ __launch_bounds__(64) void pairs_cells(int N, const T* __restrict__ pos, const T* __restrict__ box, int periodic,
-                                                  T cutoff2, long long num_slots, const CellGrid* __restrict__ grid,
-                                                  const int* __restrict__ cell_start, const int* __restrict__ atom_cell,
-                                                  const int* __restrict__ sorted_atom, int* __restrict__ row_count,
-                                                  const int* __restrict__ row_offset, int32_t* __restrict__ neighbors,
-                                                  T* __restrict__ deltas, T* __restrict__ distances) {
-    const int row = blockIdx.x;
+// STAGE pass: walks the stencil once (flat candidate space, celllist.h), counts the row's pairs and parks them
+// in a per-row staging area {col, dx, dy, dz, dist}.  EMIT pass (after the scan over rows): copies the staged
+// row to its final offset -- no second distance computation.  A row with more than kStageCap pairs, or a box
+// too small for the stencil, is only counted by STAGE and recomputed by EMIT (walk_row with MODE = kEmit).
+constexpr int kStageCap = 64;
+constexpr int kCellThreshold = 8192;        // below this the N^2/2 scan is cheaper than building a grid
+enum { kStage = 0, kEmit = 1 };
+
+template <typename T> struct Staged { T dx, dy, dz, dist; };
+
+template <typename T, int MODE>
+__device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, const T* __restrict__ box, int periodic, T cutoff2,
+                                        long long num_slots, long long base_slot, const CellGrid& g,
+                                        const int* __restrict__ cell_start, const int* __restrict__ atom_cell,
+                                        const int* __restrict__ sorted_atom, const float4* __restrict__ sorted_pos,
+                                        int* __restrict__ st_col, Staged<T>* __restrict__ st_rec,
+                                        int32_t* __restrict__ neighbors, T* __restrict__ deltas, T* __restrict__ distances) {
     const int lane = lane_id();
-    const CellGrid g = *grid;
-    const long long base_slot = PASS == 1 ? row_offset[row] : 0;
     int found = 0;
-    // one chunk of up to 64 candidate columns
-    auto visit = [&](bool have, int col) {
+    auto visit = [&](bool have, int col, Vec3<T> d) {
         bool keep = false;
-        Vec3<T> d{0, 0, 0};
         T d2 = 0;
         if (have && col < row) {
-            d = wrapped_delta<T>(pos, row, col, box, periodic != 0);
+            if (periodic) {
+                const T s3 = round(d.z / box[8]);
+                d.x -= s3 * box[6]; d.y -= s3 * box[7]; d.z -= s3 * box[8];
+                const T s2 = round(d.y / box[4]);
+                d.x -= s2 * box[3]; d.y -= s2 * box[4];
+                const T s1 = round(d.x / box[0]);
+                d.x -= s1 * box[0];
+            }
             d2 = d.x * d.x + d.y * d.y + d.z * d.z;
             keep = !(d2 > cutoff2);
         }
         const unsigned long long m = __ballot(keep);
-        if (keep && PASS == 1) {
-            const long long slot = base_slot + found + prefix_popc(m);
-            if (slot < num_slots) {
-                neighbors[slot] = row;
-                neighbors[num_slots + slot] = col;
-                deltas[3 * slot] = d.x; deltas[3 * slot + 1] = d.y; deltas[3 * slot + 2] = d.z;
-                distances[slot] = sqrt(d2);
+        if (keep) {
+            const int rank = found + prefix_popc(m);
+            if (MODE == kStage) {
+                if (rank < kStageCap) {
+                    st_col[rank] = col;
+                    st_rec[rank] = Staged<T>{d.x, d.y, d.z, (T)sqrt(d2)};
+                }
+            } else {
+                const long long slot = base_slot + rank;
+                if (slot < num_slots) {
+                    neighbors[slot] = row;
+                    neighbors[num_slots + slot] = col;
+                    deltas[3 * slot] = d.x; deltas[3 * slot + 1] = d.y; deltas[3 * slot + 2] = d.z;
+                    distances[slot] = sqrt(d2);
+                }
             }
         }
         found += __popcll(m);
     };
+    const T xr = pos[3 * row], yr = pos[3 * row + 1], zr = pos[3 * row + 2];
+    auto from_col = [&](bool have, int col) {
+        Vec3<T> d{0, 0, 0};
+        if (have && col < row) d = Vec3<T>{xr - pos[3 * col], yr - pos[3 * col + 1], zr - pos[3 * col + 2]};
+        visit(have, col, d);
+    };
     if (!g.ok) {
         // the box is too small for the 27-cell stencil (fewer than 3 cells on an axis): scan every column
-        for (int c0 = 0; c0 < row; c0 += 64) visit(c0 + lane < row, c0 + lane);
-    } else {
-        const int c = atom_cell[row];
-        const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
-        for_each_stencil_range(g, cell_start, cx, cy, cz, [&](int begin, int end) {
-            for (int b0 = begin; b0 < end; b0 += 64) {
-                const int k = b0 + lane;
-                visit(k < end, k < end ? sorted_atom[k] : -1);
-            }
-        });
+        for (int c0 = 0; c0 < row; c0 += 64) from_col(c0 + lane < row, c0 + lane);
+        return found;
     }
-    if (PASS == 0 && lane == 0) row_count[row] = found;
+    const int c = atom_cell[row];
+    const Stencil st = gather_stencil(g, cell_start, c % g.nx, (c / g.nx) % g.ny, c / (g.nx * g.ny));
+    for (int base = 0; base < st.total; base += 64) {
+        const int k = base + lane;
+        const int slot = stencil_slot(st, min(k, st.total - 1));          // all lanes (ds_bpermute inside)
+        const bool have = k < st.total;
+        if (sizeof(T) == 4) {
+            // fp32: the grid's cell-ordered copy {x, y, z, id} is the same numbers, read coalesced
+            const float4 pj = sorted_pos[slot];
+            const int col = __float_as_int(pj.w) & kIdMask;
+            visit(have, col, Vec3<T>{xr - (T)pj.x, yr - (T)pj.y, zr - (T)pj.z});
+        } else {
+            from_col(have, sorted_atom[slot]);
+        }
+    }
+    return found;
 }
 
-// exclusive scan of row_count[0..N) -> row_offset[0..N], total -> num_pairs; one block of 1024 threads
-__global__ __launch_bounds__(1024) void scan_rows(int N, const int* __restrict__ row_count, int* __restrict__ row_offset,
-                                                  int32_t* __restrict__ num_pairs) {
-    __shared__ int wave_tot[16];
-    __shared__ int carry;
+template <typename T>
+__global__ __launch_bounds__(256) void pairs_cells_stage(int N, const T* __restrict__ pos, const T* __restrict__ box, int periodic,
+                                                         T cutoff2, const CellGrid* __restrict__ grid,
+                                                         const int* __restrict__ cell_start, const int* __restrict__ atom_cell,
+                                                         const int* __restrict__ sorted_atom, const float4* __restrict__ sorted_pos,
+                                                         int* __restrict__ st_col, Staged<T>* __restrict__ st_rec,
+                                                         int* __restrict__ row_count, int* __restrict__ ticket) {
+    const int row = wave_global_id();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;                  // the scan's ticket counter (workspace is not zeroed)
+    if (row >= N) return;
+    const CellGrid g = *grid;
+    const int found = walk_row<T, kStage>(row, pos, box, periodic, cutoff2, 0, 0, g, cell_start, atom_cell, sorted_atom, sorted_pos,
+                                          st_col + (size_t)row * kStageCap, st_rec + (size_t)row * kStageCap, nullptr, nullptr,
+                                          nullptr);
+    if (lane_id() == 0) row_count[row] = found;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairs_cells_emit(int N, const T* __restrict__ pos, const T* __restrict__ box, int periodic,
+                                                        T cutoff2, long long num_slots, const CellGrid* __restrict__ grid,
+                                                        const int* __restrict__ cell_start, const int* __restrict__ atom_cell,
+                                                        const int* __restrict__ sorted_atom, const float4* __restrict__ sorted_pos,
+                                                        const int* __restrict__ st_col, const Staged<T>* __restrict__ st_rec,
+                                                        const int* __restrict__ row_count, const int* __restrict__ row_offset,
+                                                        const int* __restrict__ block_prefix,
+                                                        int32_t* __restrict__ neighbors, T* __restrict__ deltas,
+                                                        T* __restrict__ distances) {
+    // unused tail of the output: -1 / NaN (CUDA.cu:137-139), written once instead of pre-filling every slot
+    {
+        const long long found = block_prefix[(N + kScanBlock - 1) / kScanBlock];
+        const T nan = std::numeric_limits<T>::quiet_NaN();
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        for (long long k = found + (long long)blockIdx.x * blockDim.x + threadIdx.x; k < num_slots; k += stride) {
+            neighbors[k] = -1;
+            neighbors[num_slots + k] = -1;
+            deltas[3 * k] = nan; deltas[3 * k + 1] = nan; deltas[3 * k + 2] = nan;
+            distances[k] = nan;
+        }
+    }
+    const int row = wave_global_id();
+    if (row >= N) return;
+    const int lane = lane_id();
+    const int n = row_count[row];
+    const long long base_slot = first_slot(row_offset, block_prefix, row);
+    const CellGrid g = *grid;
+    if (n > kStageCap || !g.ok) {
+        walk_row<T, kEmit>(row, pos, box, periodic, cutoff2, num_slots, base_slot, g, cell_start, atom_cell, sorted_atom, sorted_pos,
+                           nullptr, nullptr, neighbors, deltas, distances);
+        return;
+    }
+    if (lane < n) {
+        const long long slot = base_slot + lane;
+        if (slot < num_slots) {
+            const Staged<T> r = st_rec[(size_t)row * kStageCap + lane];
+            neighbors[slot] = row;
+            neighbors[num_slots + slot] = st_col[(size_t)row * kStageCap + lane];
+            deltas[3 * slot] = r.dx; deltas[3 * slot + 1] = r.dy; deltas[3 * slot + 2] = r.dz;
+            distances[slot] = r.dist;
+        }
+    }
+}
+
+// Exclusive scan of row_count[0..N) in one launch of ceil(N/1024) blocks: every block scans its 1024 rows
+// (row_offset = offset inside the block) and publishes its total; the block that finishes LAST (ticket counter,
+// nobody waits for anybody) scans the block totals into block_prefix[0..nb] and sets num_pairs.  The offset of
+// a row is row_offset[row] + block_prefix[row >> 10]  (first_slot() below).
+__global__ __launch_bounds__(kScanBlock) void scan_rows(int N, const int* __restrict__ row_count, int* __restrict__ row_offset,
+                                                        int* __restrict__ block_prefix, int* __restrict__ ticket,
+                                                        int32_t* __restrict__ num_pairs) {
+    __shared__ int wave_tot[kScanBlock / 64];
+    __shared__ bool last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x * kScanBlock + tid;
+    const int v = r < N ? row_count[r] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < kScanBlock / 64; w++) {
+        before += w < wave ? wave_tot[w] : 0;
+        total += wave_tot[w];
+    }
+    if (r < N) row_offset[r] = before + incl - v;
+    if (tid == 0) {
+        __hip_atomic_store(&block_prefix[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // the last block: exclusive scan of the block totals, in place (nb <= a few thousand: tiles of 1024)
+    const int nb = gridDim.x;
+    __shared__ int carry;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < N; base += 1024) {
-        const int r = base + tid;
-        const int v = r < N ? row_count[r] : 0;
-        int incl = v;
+    for (int base = 0; base < nb; base += kScanBlock) {
+        const int bq = base + tid;
+        const int t = bq < nb ? __hip_atomic_load(&block_prefix[bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int inc = t;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
+            const int up = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += up;
         }
-        if (lane == 63) wave_tot[wave] = incl;
+        if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
-        int wave_off = 0;
-        for (int w = 0; w < wave; w++) wave_off += wave_tot[w];
-        const int excl = carry + wave_off + incl - v;
-        if (r < N) row_offset[r] = excl;
+        int wb = 0;
+        for (int w = 0; w < wave; w++) wb += wave_tot[w];
+        const int excl = carry + wb + inc - t;
+        if (bq < nb) block_prefix[bq] = excl;
         __syncthreads();
-        if (tid == 1023) carry = excl + v;
+        if (tid == kScanBlock - 1) carry = excl + t;
         __syncthreads();
     }
-    if (tid == 0) { row_offset[N] = carry; num_pairs[0] = carry; }
+    if (tid == 0) { block_prefix[nb] = carry; num_pairs[0] = carry; }
 }
 
 template <typename T>
@@ -207,10 +341,11 @@ __global__ void pairs_backward(long long num_slots, const int32_t* __restrict__ 
     }
 }
 
-// workspace layout (bytes): row_count[N+1] | row_offset[N+1] | cell grid arrays | float positions
+// workspace layout (bytes): row_count[N+1] | row_offset[N+1] | cell grid arrays | float positions | row staging
 struct Workspace {
     int* row_count;
     int* row_offset;
+    int* block_prefix;    // [ceil(N/1024) + 1] + the scan's ticket counter behind it
     CellGrid* grid;
     int* cell_count;
     int* cell_start;
@@ -220,6 +355,8 @@ struct Workspace {
     int* sorted_atom;
     float4* sorted_pos;
     float* fpos;
+    int* st_col;          // [N][kStageCap]
+    void* st_rec;         // [N][kStageCap] Staged<T> (sized for double)
     int max_cells;
 };
 
@@ -233,6 +370,7 @@ size_t carve(Workspace* w, char* base, int N) {
     tmp.max_cells = max_cells;
     tmp.row_count = (int*)take(sizeof(int) * ((size_t)N + 1));
     tmp.row_offset = (int*)take(sizeof(int) * ((size_t)N + 1));
+    tmp.block_prefix = (int*)take(sizeof(int) * ((size_t)N / 1024 + 4));
     tmp.grid = (CellGrid*)take(sizeof(CellGrid));
     tmp.cell_count = (int*)take(sizeof(int) * (size_t)max_cells);
     tmp.cell_start = (int*)take(sizeof(int) * ((size_t)max_cells + 1));
@@ -242,6 +380,9 @@ size_t carve(Workspace* w, char* base, int N) {
     tmp.sorted_atom = (int*)take(sizeof(int) * (size_t)N);
     tmp.sorted_pos = (float4*)take(sizeof(float4) * (size_t)N);
     tmp.fpos = (float*)take(sizeof(float) * 3 * (size_t)N);
+    const bool staged = N >= kCellThreshold;          // only the cell-grid path stages rows
+    tmp.st_col = (int*)take(staged ? sizeof(int) * (size_t)N * kStageCap : 0);
+    tmp.st_rec = (void*)take(staged ? sizeof(Staged<double>) * (size_t)N * kStageCap : 0);
     if (w) *w = tmp;
     return off;
 }
@@ -256,24 +397,26 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
     const T cutoff2 = c * c;
     Workspace w;
     carve(&w, (char*)workspace, N);
-    if (num_slots > 0) {
+    const int nscan = div_up(N, kScanBlock);
+    int* ticket = w.block_prefix + nscan + 1;
+    // The cell grid pays off once the N^2/2 scan is the bigger cost.  A periodic box must be at least 3
+    // cells wide per axis for the stencil, which the caller's contract (box >= 2*cutoff) does not
+    // guarantee: the device checks, and rows fall back to scanning every column when it is not.
+    const bool use_cells = !all_slots && N >= kCellThreshold;
+    if (num_slots > 0 && !use_cells) {        // (the cell path writes the unused tail itself, once)
         const int tb = 256;
         hipLaunchKernelGGL(fill_unused<T>, dim3(div_up(num_slots, tb)), dim3(tb), 0, stream, num_slots, neighbors, deltas,
                            distances, num_pairs);
-    } else {
+    } else if (!use_cells) {
         NNPOPS_HIP_TRY(hipMemsetAsync(num_pairs, 0, sizeof(int32_t), stream));
     }
     if (N < 2) return NNPOPS_OK;
     if (all_slots) {
         hipLaunchKernelGGL((pairs_allpairs<T, 1, true>), dim3(N), dim3(64), 0, stream, N, pos, box, periodic, cutoff2, num_slots,
-                           w.row_count, w.row_offset, neighbors, deltas, distances, num_pairs);
+                           w.row_count, w.row_offset, w.block_prefix, ticket, neighbors, deltas, distances, num_pairs);
         NNPOPS_HIP_TRY(hipGetLastError());
         return NNPOPS_OK;
     }
-    // The cell grid pays off once the N^2/2 scan is the bigger cost.  A periodic box must be at least 3
-    // cells wide per axis for the stencil, which the caller's contract (box >= 2*cutoff) does not
-    // guarantee: the device checks, and rows fall back to scanning every column when it is not.
-    const bool use_cells = N >= 8192;
     if (use_cells) {
         const int tb = 256;
         const float* fpos = (const float*)pos;
@@ -295,17 +438,22 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
         const CellBuffers cb{w.grid, w.cell_count, w.cell_start, w.atom_cell, w.atom_rank, w.unsorted_atom, w.sorted_atom,
                              w.sorted_pos, w.max_cells};
         launch_cell_build(stream, N, fpos, fbox, periodic != 0, (float)cutoff, nullptr, cb);
-        hipLaunchKernelGGL((pairs_cells<T, 0>), dim3(N), dim3(64), 0, stream, N, pos, box, periodic, cutoff2, num_slots, w.grid,
-                           w.cell_start, w.atom_cell, w.sorted_atom, w.row_count, w.row_offset, neighbors, deltas, distances);
-        hipLaunchKernelGGL(scan_rows, dim3(1), dim3(1024), 0, stream, N, w.row_count, w.row_offset, num_pairs);
-        hipLaunchKernelGGL((pairs_cells<T, 1>), dim3(N), dim3(64), 0, stream, N, pos, box, periodic, cutoff2, num_slots, w.grid,
-                           w.cell_start, w.atom_cell, w.sorted_atom, w.row_count, w.row_offset, neighbors, deltas, distances);
+        const dim3 rgrid(div_up(N, 4)), rblock(256);       // one wave per row
+        Staged<T>* st_rec = (Staged<T>*)w.st_rec;
+        hipLaunchKernelGGL(pairs_cells_stage<T>, rgrid, rblock, 0, stream, N, pos, box, periodic, cutoff2, w.grid, w.cell_start,
+                           w.atom_cell, w.sorted_atom, w.sorted_pos, w.st_col, st_rec, w.row_count, ticket);
+        hipLaunchKernelGGL(scan_rows, dim3(nscan), dim3(kScanBlock), 0, stream, N, w.row_count, w.row_offset, w.block_prefix, ticket,
+                           num_pairs);
+        hipLaunchKernelGGL(pairs_cells_emit<T>, rgrid, rblock, 0, stream, N, pos, box, periodic, cutoff2, num_slots, w.grid,
+                           w.cell_start, w.atom_cell, w.sorted_atom, w.sorted_pos, w.st_col, st_rec, w.row_count, w.row_offset,
+                           w.block_prefix, neighbors, deltas, distances);
     } else {
         hipLaunchKernelGGL((pairs_allpairs<T, 0, false>), dim3(N), dim3(64), 0, stream, N, pos, box, periodic, cutoff2, num_slots,
-                           w.row_count, w.row_offset, neighbors, deltas, distances, num_pairs);
-        hipLaunchKernelGGL(scan_rows, dim3(1), dim3(1024), 0, stream, N, w.row_count, w.row_offset, num_pairs);
+                           w.row_count, w.row_offset, w.block_prefix, ticket, neighbors, deltas, distances, num_pairs);
+        hipLaunchKernelGGL(scan_rows, dim3(nscan), dim3(kScanBlock), 0, stream, N, w.row_count, w.row_offset, w.block_prefix, ticket,
+                           num_pairs);
         hipLaunchKernelGGL((pairs_allpairs<T, 1, false>), dim3(N), dim3(64), 0, stream, N, pos, box, periodic, cutoff2, num_slots,
-                           w.row_count, w.row_offset, neighbors, deltas, distances, num_pairs);
+                           w.row_count, w.row_offset, w.block_prefix, ticket, neighbors, deltas, distances, num_pairs);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;

@@ -1,0 +1,116 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the O(N^2) oracle cannot reach them
+in test time): config 5 = 100 000 atoms (getNeighborPairs at 5.2 A + ANI-2x AEV), config 3 = 10 000-atom CFConv.
+
+Properties used
+  * the cell-grid search and the all-pairs search (the reference's algorithm, run on the GPU) are independent
+    code paths: same pair set, same AEV within the parity tolerance;
+  * Newton's third law: the position gradient of any function of the AEV / of the convolution output sums to
+    zero over the atoms (translation invariance);
+  * the pair list is row-grouped, ascending, col < row, |delta| == distance <= cutoff, and every row sampled
+    agrees with a brute-force numpy scan of that row (bit-exact index sets).
+"""
+import numpy as np
+import pytest
+import torch
+
+from nnpops_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def box100k():
+    pos, species, box = workloads.random_box(100000, density=0.1, seed=6)
+    return pos, species, box
+
+
+def test_neighbor_pairs_100k(box100k):
+    from nnpops_amd.capi import neighbor_pairs_forward
+    pos, _, box = box100k
+    dev = torch.device("cuda:0")
+    cutoff, max_pairs = 5.2, 3_200_000
+    nb, dl, ds, n = neighbor_pairs_forward(torch.tensor(pos, device=dev), cutoff, max_pairs, torch.tensor(box, device=dev))
+    nb, dl, ds, n = nb.cpu().numpy(), dl.cpu().numpy(), ds.cpu().numpy(), int(n.item())
+    valid = nb[0] >= 0
+    assert n == int(valid.sum()) and 2_800_000 < n < max_pairs           # ~2.94e6 expected
+    assert np.all(valid[:n]) and not valid[n:].any()                     # compacted, padded with -1
+    assert np.all(np.isnan(ds[n:])) and np.all(nb[1][n:] == -1)
+    rows, cols = nb[0][:n], nb[1][:n]
+    assert np.all(rows > cols) and np.all(np.diff(rows) >= 0)
+    np.testing.assert_allclose(np.sqrt((dl[:n].astype(np.float64) ** 2).sum(1)), ds[:n], rtol=1e-6)
+    assert ds[:n].max() <= cutoff
+    # pair count per atom is symmetric information: every atom's degree from the list == brute force on samples
+    L = float(box[0, 0])
+    starts = np.searchsorted(rows, np.arange(100001))
+    rng = np.random.default_rng(0)
+    for row in rng.choice(100000, 300, replace=False):
+        d = pos[row].astype(np.float32) - pos[:row]
+        d -= np.round(d / np.float32(L)) * np.float32(L)
+        r = np.sqrt((d * d).sum(1))
+        want = np.nonzero(r <= np.float32(cutoff))[0]
+        got = np.sort(cols[starts[row]:starts[row + 1]])
+        assert np.array_equal(want, got), row
+
+
+def test_ani_100k_cells_equal_allpairs_and_forces_sum_to_zero(box100k):
+    from nnpops_amd.capi import AniSymmetryFunctions
+    pos, species, box = box100k
+    rf, af = workloads.ani2x_functions()
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    out = {}
+    for algorithm in (2, 1):                  # cell grid, then the reference's all-pairs scan on the GPU
+        sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+        sym.set_neighbor_algorithm(algorithm)
+        radial, angular = sym.compute(tpos, tbox)
+        if not out:
+            g_r = torch.randn(radial.shape, device=dev, generator=gen)
+            g_a = torch.randn(angular.shape, device=dev, generator=gen)
+        grad = sym.backprop(g_r, g_a)
+        out[algorithm] = (radial.clone(), angular.clone(), grad.clone())
+        del sym
+    (r2, a2, f2), (r1, a1, f1) = out[2], out[1]
+    assert torch.isfinite(r2).all() and torch.isfinite(a2).all() and torch.isfinite(f2).all()
+    torch.testing.assert_close(r2, r1, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(a2, a1, rtol=2e-5, atol=2e-6)
+    fmax = float(f1.abs().max())
+    assert float((f2 - f1).abs().max()) <= 1e-4 * fmax
+    # translation invariance: the net force vanishes (to accumulated rounding of 1e5 fp32 terms)
+    net = f2.double().sum(0).abs().max().item()
+    assert net <= 1e-3 * fmax, (net, fmax)
+    # every atom of a liquid at this density has neighbours: no empty AEV rows
+    assert bool((r2.abs().sum(1) > 0).all())
+
+
+def test_cfconv_10k_forces_sum_to_zero_and_match_vector_kernels(monkeypatch):
+    """Config 3 at full size: matrix-core kernels vs the vector kernels (independent code), and Newton's third law."""
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    n, W, G, cutoff = 10000, 128, 50, 5.0
+    pos, _, box = workloads.random_box(n, density=0.1, seed=3)
+    rng = np.random.default_rng(4)
+    w1 = (0.1 * rng.standard_normal((W, G))).astype(np.float32)
+    w2 = (0.1 * rng.standard_normal((W, W))).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(W)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(W)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    x = torch.tensor(rng.standard_normal((n, W)).astype(np.float32), device=dev)
+    gy = torch.tensor(rng.standard_normal((n, W)).astype(np.float32), device=dev)
+    nbrs = CFConvNeighbors(n, cutoff, periodic=True)
+    nbrs.build(tpos, tbox, check=True)
+    assert 250_000 < nbrs.num_pairs() < 275_000                         # ~2.6e5 half pairs
+    res = {}
+    for valu in ("0", "1"):
+        monkeypatch.setenv("NNPOPS_CFCONV_VALU", valu)
+        cf = CFConv(n, W, G, cutoff, 0.1, "ssp", w1, b1, w2, b2, periodic=True)
+        y = torch.empty_like(x)
+        cf.compute(nbrs, tpos, x, tbox, y)
+        gx, gpos = cf.backprop(nbrs, tpos, x, gy, tbox)
+        res[valu] = (y.clone(), gx.clone(), gpos.clone())
+    (y0, gx0, gp0), (y1, gx1, gp1) = res["0"], res["1"]
+    torch.testing.assert_close(y0, y1, rtol=1e-4, atol=1e-4 * float(y1.abs().max()))
+    torch.testing.assert_close(gx0, gx1, rtol=1e-4, atol=1e-4 * float(gx1.abs().max()))
+    fmax = float(gp1.abs().max())
+    assert float((gp0 - gp1).abs().max()) <= 1e-4 * fmax
+    assert gp0.double().sum(0).abs().max().item() <= 1e-3 * fmax
