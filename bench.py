@@ -74,10 +74,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nn-layout", default="grouped", choices=["grouped", "reference"],
+                    help="torchani workload: species-grouped GEMMs (default) or the reference's per-atom replicated weights")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
-    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv", "conformers", "neighbors"],
+    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv", "conformers", "neighbors", "torchani"],
                     help="aev: the headline metric (default); cfconv: BASELINE config 3; conformers: BASELINE config 4; "
-                         "neighbors: BASELINE config 5 (side measurements, same JSON shape)")
+                         "neighbors: BASELINE config 5; torchani: BASELINE config 2 (side measurements, same JSON shape)")
     args = ap.parse_args()
     if args.workload == "cfconv":
         return main_cfconv(args)
@@ -85,6 +87,8 @@ def main():
         return main_conformers(args)
     if args.workload == "neighbors":
         return main_neighbors(args)
+    if args.workload == "torchani":
+        return main_torchani(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -270,6 +274,63 @@ def main_neighbors(args):
                      "traffic": None, "algorithmic_bytes_per_launch": nb_bytes,
                      "aev_step": {"algorithmic_bytes": aev_bytes,
                                   "achieved": round(aev_bytes / ((t_fwd + t_bwd) * 1e-3) / 1e9, 2)}},
+    }), flush=True)
+
+
+def main_torchani(args):
+    """BASELINE config 2: OptimizedTorchANI (species converter + HIP AEV + BatchedNN + energy shifter) on a
+    2 001-atom periodic water box, fp32, 8 models with the ANI-2x layer widths and random weights (torchani and
+    its parameters are not available offline).  One step = energy forward + backward to the forces, through the
+    torch.ops / autograd surface exactly as a user calls it.  Side measurement (not the headline metric)."""
+    sys.path.insert(0, ROOT)
+    from NNPOps import OptimizedTorchANI
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    model = workloads.torchani_like_model(n_models=8, seed=2)
+    pos, species, box = workloads.water_box(667, seed=1)
+    numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=dev)
+    opt = OptimizedTorchANI(model, numbers.cpu())
+    if args.nn_layout == "reference":
+        opt.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="reference")
+    opt = opt.to(dev)
+    cell, pbc = torch.tensor(box, device=dev), torch.tensor([True, True, True], device=dev)
+    tpos = torch.tensor(pos, device=dev).unsqueeze(0).requires_grad_(True)
+    n = len(species)
+
+    def step():
+        tpos.grad = None
+        energy = opt((numbers, tpos), cell, pbc).energies
+        energy.sum().backward()
+        return energy
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        energy = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(energy).all()) and bool(torch.isfinite(tpos.grad).all())
+    # NN flops (SURVEY s8(d) config 2): 2 * models * sum over atoms of the MACs of its network; backward to the
+    # inputs costs the same again
+    macs = {s: 1008 * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}
+    flops_fwd = 2.0 * 8 * sum(macs[int(s)] for s in species)
+    nn_weight_bytes = sum(b.numel() * 4 for name, b in opt.neural_networks.named_buffers() if "layer" in name)
+    print(json.dumps({
+        "metric": "OptimizedTorchANI energy+forces evaluations/sec, 2001-atom periodic water box, 8 models, fp32",
+        "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"OptimizedTorchANI, {n}-atom periodic water box (667 H2O), ANI-2x AEV + 8 x ANI-2x-shaped networks, "
+                               f"random weights, BatchedNN layout = {args.nn_layout}", "atoms": n,
+                   "nn_weight_bytes": nn_weight_bytes},
+        "roofline": {"bound": "mfma", "kernel": "BatchedNN GEMMs (hipBLASLt via torch.matmul), forward + input-gradient backward",
+                     "achieved": round(2 * flops_fwd / elapsed * args.steps / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": round(2 * flops_fwd / elapsed * args.steps / 1e12 / 157.3, 5), "traffic": None,
+                     "note": "whole step time (AEV + NN + autograd overhead) against the NN's algorithmic flops; fp32 matrix peak"},
     }), flush=True)
 
 

@@ -118,3 +118,59 @@ def triclinic_box(n_atoms, seed=0, density=0.1, n_species=7):
     L = float(box[0, 0])
     box = np.array([[L, 0, 0], [0.15 * L, L, 0], [-0.05 * L, -0.1 * L, L]], dtype=np.float32)
     return pos, species, box
+
+
+# ---------------------------------------------------------------------------------------------
+# A stand-in for a TorchANI ANI-2x model object (torchani itself is not available offline): the same
+# attributes NNPOps reads from it (reference src/pytorch/SymmetryFunctions.py:75-86, BatchedNN.py:55-59,
+# EnergyShifter.py:34-45), random weights of the ANI-2x layer widths.
+# ---------------------------------------------------------------------------------------------
+Z_OF_SPECIES = (1, 6, 7, 8, 16, 9, 17)          # H C N O S F Cl, the ANI-2x species order
+ANI2X_WIDTHS = {"H": (256, 192, 160), "C": (224, 192, 160), "N": (192, 160, 128), "O": (192, 160, 128),
+                "S": (160, 128, 96), "F": (160, 128, 96), "Cl": (160, 128, 96)}
+
+
+def torchani_like_model(n_models=8, seed=2, self_energies=None):
+    """-> object with .species_converter, .aev_computer, .neural_networks (ModuleList of ModuleDicts of
+    Sequential(Linear, CELU, ... Linear)), .energy_shifter, shaped like torchani.models.ANI2x."""
+    import torch
+    from torch import nn
+    from types import SimpleNamespace
+
+    class SpeciesConverter(nn.Module):
+        def __init__(self):
+            super().__init__()
+            conv = torch.full((120,), -1, dtype=torch.long)
+            for s, z in enumerate(Z_OF_SPECIES):
+                conv[z] = s
+            self.register_buffer("conv_tensor", conv)
+
+        def forward(self, inp):
+            numbers, coords = inp
+            return SimpleNamespace(species=self.conv_tensor.to(numbers.device)[numbers], coordinates=coords)
+
+    class ANIModel(nn.ModuleDict):
+        pass
+
+    c, t = ANI2X, torch.tensor
+    aev_computer = SimpleNamespace(num_species=7, Rcr=c["Rcr"], Rca=c["Rca"],
+                                   EtaR=t(c["EtaR"]).view(-1, 1), ShfR=t(c["ShfR"]).view(1, -1),
+                                   EtaA=t(c["EtaA"]).view(-1, 1, 1, 1), Zeta=t(c["Zeta"]).view(1, -1, 1, 1),
+                                   ShfA=t(c["ShfA"]).view(1, 1, -1, 1), ShfZ=t(c["ShfZ"]).view(1, 1, 1, -1))
+    gen = torch.Generator().manual_seed(seed)
+    models = []
+    for _ in range(n_models):
+        nets = {}
+        for sym, (h1, h2, h3) in ANI2X_WIDTHS.items():
+            net = nn.Sequential(nn.Linear(1008, h1), nn.CELU(0.1), nn.Linear(h1, h2), nn.CELU(0.1), nn.Linear(h2, h3),
+                                nn.CELU(0.1), nn.Linear(h3, 1))
+            for layer in net:
+                if isinstance(layer, nn.Linear):                 # N(0, 1/sqrt(fan_in)) (SURVEY.md s8(d) config 2)
+                    layer.weight.data = torch.randn(layer.weight.shape, generator=gen) / math.sqrt(layer.in_features)
+                    layer.bias.data = 0.1 * torch.randn(layer.bias.shape, generator=gen)
+            nets[sym] = net
+        models.append(ANIModel(nets))
+    sae = torch.zeros(7, dtype=torch.float64) if self_energies is None else torch.as_tensor(self_energies, dtype=torch.float64)
+    shifter = SimpleNamespace(sae=lambda species: sae.to(species.device)[species].sum(dim=1))
+    return SimpleNamespace(species_converter=SpeciesConverter(), aev_computer=aev_computer,
+                           neural_networks=nn.ModuleList(models), energy_shifter=shifter)

@@ -49,3 +49,29 @@ def test_creating_an_evaluator_without_a_gpu_fails_loudly():
     rf, af = workloads.ani2x_functions()
     with pytest.raises(capi.NNPOpsHipError):
         capi.AniSymmetryFunctions(7, 5.1, 3.5, np.zeros(5, np.int32), rf, af)
+
+
+def test_species_grouped_nn_equals_per_atom_evaluation_cpu():
+    """Host-side logic of the species-grouped BatchedNN (pure tensor algebra, device agnostic): grouping,
+    padding of unequal layer widths, molecule batching and the model mean, against the obvious per-atom loop."""
+    from types import SimpleNamespace
+    from torch import nn
+    from nnpops_amd.BatchedNN import _SpeciesGroupedNN
+
+    class Conv:
+        def __call__(self, x):
+            return SimpleNamespace(species=x[0].unsqueeze(0))
+
+    torch.manual_seed(0)
+    widths = [(16, 12, 8), (14, 12, 8), (10, 8, 6)]
+    ensemble = nn.ModuleList([nn.ModuleList([nn.Sequential(nn.Linear(20, a), nn.CELU(0.1), nn.Linear(a, b), nn.CELU(0.1),
+                                                           nn.Linear(b, c), nn.CELU(0.1), nn.Linear(c, 1))
+                                             for a, b, c in widths]) for _ in range(3)])
+    species = torch.tensor([2, 0, 0, 1, 2, 2, 0])
+    module = _SpeciesGroupedNN(Conv(), ensemble, species)
+    assert module.group_sizes == [3, 1, 3] and module.atom_order.tolist() == [1, 2, 6, 3, 0, 4, 5]
+    aev = torch.randn(2, 7, 20)
+    got = module((species, aev)).energies
+    want = torch.stack([sum(model[int(s)](aev[b, i]).sum() for model in ensemble for i, s in enumerate(species)) / 3
+                        for b in range(2)])
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)

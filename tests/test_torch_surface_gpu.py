@@ -284,3 +284,62 @@ def test_batched_nn_and_optimized_torchani():
     # buffers keep the reference's names
     names = {k for k, _ in opt.neural_networks.named_buffers()}
     assert {"0.layer0_weights", "0.layer6_biases"} <= names
+
+
+def test_species_grouped_nn_matches_reference_layout_and_loads_its_state_dict():
+    """The default BatchedNN layout (one batched GEMM per species) against the reference's per-atom replicated
+    layout driven through torch.ops.NNPOpsBatchedNN.BatchedLinear: same energies, same AEV gradients; a state
+    dict in the reference's shapes loads into the grouped module; both script."""
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    model = workloads.torchani_like_model(n_models=3, seed=5)
+    pos, species, _ = workloads.water_box(30, seed=2)
+    species = np.concatenate([species, [1, 2, 4, 6, 5, 1]]).astype(np.int32)      # every ANI-2x species present
+    numbers = _numbers(species)
+    grouped = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu()).to(DEV)
+    reference = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="reference").to(DEV)
+    assert grouped[0].layer0_weights.shape == (7, 3, 256, 1008)
+    assert reference[0].layer0_weights.shape == (1, len(species), 3, 256, 1008)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    aev = torch.randn(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).abs()
+    a1 = aev.clone().requires_grad_(True)
+    a2 = aev.clone().requires_grad_(True)
+    e1 = grouped((sp, a1)).energies
+    e2 = reference((sp, a2)).energies
+    e1.sum().backward()
+    e2.sum().backward()
+    assert e1.shape == e2.shape == (1,)
+    torch.testing.assert_close(e1, e2, rtol=2e-5, atol=1e-4)
+    torch.testing.assert_close(a1.grad, a2.grad, rtol=1e-4, atol=1e-5 * float(a2.grad.abs().max()))
+    # interchange: reference-shaped state dict -> grouped module
+    blank = workloads.torchani_like_model(n_models=3, seed=99)
+    other = TorchANIBatchedNN(blank.species_converter, blank.neural_networks, numbers.cpu()).to(DEV)
+    assert not torch.allclose(other((sp, aev)).energies, e1.detach())
+    other.load_state_dict(reference.state_dict())
+    torch.testing.assert_close(other((sp, aev)).energies, e1.detach(), rtol=1e-6, atol=1e-6)
+    # TorchScript
+    scripted = torch.jit.script(grouped)
+    torch.testing.assert_close(scripted((sp, aev)).energies, e1.detach(), rtol=1e-6, atol=1e-6)
+
+
+def test_optimized_torchani_scripted_model_2000_atoms():
+    """BASELINE config 2 at full size (2 001-atom periodic water box, 8 models): the scripted OptimizedTorchANI
+    gives a finite energy, forces that sum to zero (translation invariance of the whole pipeline), and the
+    same numbers as the eager module."""
+    from NNPOps import OptimizedTorchANI
+    model = workloads.torchani_like_model(n_models=8, seed=2)
+    pos, species, box = workloads.water_box(667, seed=1)
+    numbers = _numbers(species)
+    opt = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True], device=DEV)
+    tpos = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+    energy = opt((numbers, tpos), cell, pbc).energies
+    energy.sum().backward()
+    forces = -tpos.grad[0]
+    assert torch.isfinite(energy).all() and torch.isfinite(forces).all()
+    assert float(forces.double().sum(0).abs().max()) <= 1e-3 * float(forces.abs().max())
+    scripted = torch.jit.script(opt)
+    tpos2 = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+    energy2 = scripted((numbers, tpos2), cell, pbc).energies
+    energy2.sum().backward()
+    torch.testing.assert_close(energy2, energy.detach(), rtol=1e-6, atol=1e-4)
+    torch.testing.assert_close(tpos2.grad, tpos.grad, rtol=1e-4, atol=1e-5 * float(tpos.grad.abs().max()))
