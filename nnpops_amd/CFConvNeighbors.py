@@ -1,5 +1,7 @@
 """CFConvNeighbors -- neighbour list of the continuous-filter convolution
 (reference src/pytorch/CFConvNeighbors.py:27-45)."""
+from typing import Optional
+
 import torch
 from torch import Tensor
 
@@ -15,5 +17,11 @@ class CFConvNeighbors(torch.nn.Module):
         self.holder = torch.classes.NNPOpsCFConvNeighbors.Holder(cutoff)
 
     @torch.jit.export
-    def build(self, positions: Tensor) -> None:
-        self.holder.build(positions)
+    def build(self, positions: Tensor, box: Optional[Tensor] = None) -> None:
+        """``box`` (3, 3, rows = lattice vectors in reduced form) is an extension: the reference's Python surface
+        is non-periodic although its core supports a box (src/schnet/CFConv.h:57).  A holder is periodic or not
+        for life, decided by its first build."""
+        if box is None:
+            self.holder.build(positions)
+        else:
+            self.holder.build_periodic(positions, box)

@@ -249,7 +249,19 @@ public:
         if (impl) nnpops_cfconv_neighbors_destroy(impl);
     }
 
-    void build(const Tensor& positions) {
+    void build(const Tensor& positions) { buildImpl(positions, nullptr); }
+
+    // Additive to the reference (whose binding is non-periodic, CFConvNeighbors.cpp:52,57,74, although its core
+    // supports a box, CFConv.h:57): the same list under periodic boundary conditions.  box: (3, 3), rows = vectors.
+    void buildPeriodic(const Tensor& positions, const Tensor& box) {
+        if (box.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"box\" has to be float32");
+        if (box.dim() != 2 || box.size(0) != 3 || box.size(1) != 3) throw std::runtime_error("The shape of \"box\" has to be (3, 3)");
+        require_device_tensor(box, "box");
+        const Tensor b = box.detach().contiguous();
+        buildImpl(positions, &b);
+    }
+
+    void buildImpl(const Tensor& positions, const Tensor* box) {
         if (positions.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"positions\" has to be float32");
         if (positions.dim() != 2) throw std::runtime_error("The shape of \"positions\" has to have 2 dimensions");
         if (positions.size(1) != 3) throw std::runtime_error("The size of the 2nd dimension of \"positions\" has to be 3");
@@ -257,18 +269,21 @@ public:
         if (!impl) {
             numAtoms = positions.size(0);
             device = positions.device();
-            // non-periodic at this level, like the reference binding (CFConvNeighbors.cpp:52,57,74)
-            if (nnpops_cfconv_neighbors_create(&impl, (int)numAtoms, (float)cutoff, 0, device.index()) != NNPOPS_OK)
+            periodic = box != nullptr;
+            if (nnpops_cfconv_neighbors_create(&impl, (int)numAtoms, (float)cutoff, periodic ? 1 : 0, device.index()) != NNPOPS_OK)
                 raise_last("NNPOpsCFConvNeighbors");
         }
         if (positions.size(0) != numAtoms) throw std::runtime_error("The size of the 2nd dimension of \"positions\" has changed");
         if (positions.device() != device) throw std::runtime_error("The device of \"positions\" has changed");
+        if (periodic != (box != nullptr)) throw std::runtime_error("The periodicity of \"neighbors\" has changed");
+        if (box && box->device() != device) throw std::runtime_error("The device of \"box\" has changed");
         const Tensor pos = positions.detach().contiguous();
         void* stream = current_stream(device);
         nnpops_cfconv_neighbors_set_stream(impl, stream);
         const bool capturing = stream_is_capturing(stream);
         for (int attempt = 0;; attempt++) {
-            if (nnpops_cfconv_neighbors_build(impl, pos.data_ptr<float>(), nullptr) != NNPOPS_OK) raise_last("CFConvNeighbors::build");
+            if (nnpops_cfconv_neighbors_build(impl, pos.data_ptr<float>(), box ? box->data_ptr<float>() : nullptr) != NNPOPS_OK)
+                raise_last("CFConvNeighbors::build");
             if (capturing) break;
             const int rc = nnpops_cfconv_neighbors_check(impl, nullptr);
             if (rc == NNPOPS_OK) break;
@@ -281,6 +296,7 @@ public:
 private:
     double cutoff;
     int64_t numAtoms = 0;
+    bool periodic = false;
     torch::Device device = torch::kCPU;
     nnpops_cfconv_neighbors_t impl = nullptr;
 };
@@ -290,6 +306,7 @@ TORCH_LIBRARY(NNPOpsCFConvNeighbors, m) {
     m.class_<Holder>("Holder")
         .def(torch::init<double>())
         .def("build", &Holder::build)
+        .def("build_periodic", &Holder::buildPeriodic)
         .def_pickle([](const HolderPtr& self) -> double { return self->getCutoff(); },
                     [](double cutoff) -> HolderPtr { return HolderPtr::make(cutoff); });
 }

@@ -343,3 +343,48 @@ def test_optimized_torchani_scripted_model_2000_atoms():
     energy2.sum().backward()
     torch.testing.assert_close(energy2, energy.detach(), rtol=1e-6, atol=1e-4)
     torch.testing.assert_close(tpos2.grad, tpos.grad, rtol=1e-4, atol=1e-5 * float(tpos.grad.abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["cubic", "triclinic"])
+def test_cfconv_module_periodic_extension(kind):
+    """CFConvNeighbors.build(positions, box): periodic boundary conditions at the Python surface (the reference's
+    surface is non-periodic, its core is not: src/schnet/CFConv.h:57) against the periodic oracle; scripted too."""
+    from NNPOps.CFConv import CFConv
+    from NNPOps.CFConvNeighbors import CFConvNeighbors
+    W, G, cutoff, sigma = 32, 12, 4.0, 0.4
+    if kind == "cubic":
+        pos, _, box = workloads.random_box(400, seed=51)
+    else:
+        pos, _, box = workloads.triclinic_box(350, seed=52)
+    n = len(pos)
+    w1, b1, w2, b2 = _cfconv_weights(G, W, 8)
+    x = torch.randn(n, W, generator=torch.Generator().manual_seed(9))
+    gy = torch.randn(n, W, generator=torch.Generator().manual_seed(10))
+
+    class Layer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.neighbors = CFConvNeighbors(cutoff)
+            self.conv = CFConv(sigma, "ssp", w1, b1, w2, b2)
+
+        def forward(self, positions, box, x):
+            self.neighbors.build(positions, box)
+            return self.conv(self.neighbors, positions, x)
+
+    layer = torch.jit.script(Layer())
+    tpos = torch.tensor(pos, device=DEV, requires_grad=True)
+    tx = x.to(DEV).requires_grad_(True)
+    out = layer(tpos, torch.tensor(box, device=DEV), tx)
+    (out * gy.to(DEV)).sum().backward()
+    core_w1 = w1.contiguous().view(-1).view(W, G).numpy()
+    onb = CFConvNeighborsOracle(n, cutoff, True)
+    onb.build(pos, box)
+    ocf = CFConvOracle(n, W, G, cutoff, sigma, "ssp", core_w1, b1.numpy(), w2.numpy(), b2.numpy(), periodic=True)
+    y_ref = ocf.forward(onb, pos, x.numpy(), box)
+    xg_ref, pg_ref = ocf.backward(onb, pos, x.numpy(), gy.numpy(), box)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), y_ref, rtol=2e-5, atol=2e-6 * np.abs(y_ref).max())
+    np.testing.assert_allclose(tx.grad.cpu().numpy(), xg_ref, rtol=2e-5, atol=2e-6 * np.abs(xg_ref).max())
+    assert np.abs(tpos.grad.cpu().numpy() - pg_ref).max() <= 1e-4 * np.abs(pg_ref).max()
+    # a holder is periodic or not for life
+    with pytest.raises(RuntimeError, match="periodicity"):
+        layer.neighbors.build(tpos.detach())
