@@ -399,80 +399,131 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
     const float mu_step = P.cutoff / (float)(G - 1);
     const float gscale = -0.5f * kLog2e * P.sigma_inv * P.sigma_inv;       // exp(-x^2/2) = exp2(gscale * (r - mu)^2)
 
-    for (int i = blockIdx.x * waves_per_block + wave; i < P.N; i += gridDim.x * waves_per_block) {
-        const int n = min(cnt[i], cap);
-        const float4* row = rows + (size_t)i * cap;
-        float oacc[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) oacc[cb] = 0.f;
-        for (int t0 = 0; t0 < n; t0 += 16) {
-            const int np = min(16, n - t0);
-            if (lane < 16) {
-                float r = 1.0f, fc = 0.f;
-                int j = i;
-                if (lane < np) {
-                    const float4 rec = row[t0 + lane];
-                    r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
-                    fc = 0.5f * cospif(r / P.cutoff) + 0.5f;                            // ref :301-303
-                    j = __float_as_int(rec.w) & kIdMask;
-                }
-                ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = __int_as_float(j);
-            }
-            wave_fence();
-            // inputs of my four result rows, requested now so that the two GEMMs hide the latency
-            float xv[NCB][4], fcq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int rr = grp * 4 + q;
-                const int j = __float_as_int(ps[32 + rr]);
-                fcq[q] = ps[16 + rr];
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) xv[cb][q] = x[(size_t)j * W + cb * 16 + col];
-            }
-            // ---- layer 1 ----
-            f32x4 acc[NCB];
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b1v[cb], b1v[cb], b1v[cb], b1v[cb]};
-            const float rp = ps[col];
-            for (int s = 0; s < Gp / 4; s++) {
-                const int g = 4 * s + grp;
-                const float d = rp - (float)g * mu_step;
-                const float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                   // ref :151-154
-                const float* wrow = s_w1t + g * W + col;
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) y1[(grp * 4 + q) * YS + cb * 16 + col] = activate_fast<ACT>(acc[cb][q]);
-            wave_fence();
-            // ---- layer 2 ----
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
-            for (int s = 0; s < W / 4; s++) {
-                const int k = 4 * s + grp;
-                const float a = y1[col * YS + k];
-                const float* wrow = s_w2t + k * W + col;
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) oacc[cb] += fcq[q] * acc[cb][q] * xv[cb][q];      // ref :175, :181
-            wave_fence();
-        }
+    // Every wave owns a CONTIGUOUS run of atoms and walks the concatenation of their neighbour rows in tiles of
+    // 16: a tile may straddle atoms (rows carry their owner), so only the last tile of a wave is ragged -- with one
+    // tile sequence per atom, 52 +- 7 neighbours wasted 19 % of every matrix-core cycle on padding rows.
+    const int total_waves = gridDim.x * waves_per_block;
+    const int chunk = (P.N + total_waves - 1) / total_waves;
+    const int a0 = min((blockIdx.x * waves_per_block + wave) * chunk, P.N), a1 = min(a0 + chunk, P.N);
+    auto flush = [&](int owner, float (&sum)[NCB]) {        // fold the four row groups, write the owner's output row
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) {
-            float v = oacc[cb];
+            float v = sum[cb];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (grp == 0) out[(size_t)i * W + cb * 16 + col] = v;
+            if (grp == 0) out[(size_t)owner * W + cb * 16 + col] = v;
         }
+    };
+    float oacc[NCB];                                        // partial output row of atom `carry`
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) oacc[cb] = 0.f;
+    for (int a = a0; a < a1; a++)                           // atoms without neighbours never own a tile row
+        if (min(cnt[a], cap) == 0) flush(a, oacc);
+    int carry = -1;
+    int a_cur = a0, used = 0;                               // next unread row: number `used` of atom a_cur
+    for (;;) {
+        while (a_cur < a1 && used >= min(cnt[a_cur], cap)) { a_cur++; used = 0; }      // wave-uniform
+        if (a_cur >= a1) break;
+        int my_atom = a_cur, my_e = used + (lane & 15);     // lanes 0..15: locate row `lane` of this tile
+        while (my_atom < a1) {
+            const int n = min(cnt[my_atom], cap);
+            if (my_e < n) break;
+            my_e -= n;
+            my_atom++;
+        }
+        if (lane < 16) {
+            float r = 1.0f, fc = 0.f;
+            int j = a0, owner = -1;
+            if (my_atom < a1) {
+                const float4 rec = rows[(size_t)my_atom * cap + my_e];
+                r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+                fc = 0.5f * cospif(r / P.cutoff) + 0.5f;                            // ref :301-303
+                j = __float_as_int(rec.w) & kIdMask;
+                owner = my_atom;
+            }
+            ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = __int_as_float(j); ps[48 + lane] = __int_as_float(owner);
+        }
+        // where the next tile starts: one past row 15 (lane 15 knows), or the end of the run
+        const int atom15 = __shfl(my_atom, 15, 64), e15 = __shfl(my_e, 15, 64);
+        a_cur = atom15; used = e15 + 1;                     // (atom15 == a1 ends the loop at its top)
+        wave_fence();
+        // inputs of my four result rows, requested now so that the two GEMMs hide the latency
+        float xv[NCB][4], fcq[4];
+        int own[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int rr = grp * 4 + q;
+            const int j = __float_as_int(ps[32 + rr]);
+            fcq[q] = ps[16 + rr];
+            own[q] = __float_as_int(ps[48 + rr]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) xv[cb][q] = x[(size_t)j * W + cb * 16 + col];
+        }
+        const int o_lo = __float_as_int(ps[48]);            // row 0 always exists
+        int o_hi = o_lo;
+#pragma unroll
+        for (int r15 = 1; r15 < 16; r15++) o_hi = max(o_hi, __float_as_int(ps[48 + r15]));      // owners ascend; -1 = padding
+        // ---- layer 1 ----
+        f32x4 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b1v[cb], b1v[cb], b1v[cb], b1v[cb]};
+        const float rp = ps[col];
+        for (int s = 0; s < Gp / 4; s++) {
+            const int g = 4 * s + grp;
+            const float d = rp - (float)g * mu_step;
+            const float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                   // ref :151-154
+            const float* wrow = s_w1t + g * W + col;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) y1[(grp * 4 + q) * YS + cb * 16 + col] = activate_fast<ACT>(acc[cb][q]);
+        wave_fence();
+        // ---- layer 2 ----
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+        for (int s = 0; s < W / 4; s++) {
+            const int k = 4 * s + grp;
+            const float a = y1[col * YS + k];
+            const float* wrow = s_w2t + k * W + col;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
+        }
+        // ---- output: rows are summed into their owner (ref :175, :181); padding rows have fc = 0 ----
+        if (carry >= 0 && carry != o_lo) {                  // the previous tile ended exactly on an atom boundary
+            flush(carry, oacc);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) oacc[cb] = 0.f;
+        }
+        if (o_lo == o_hi) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) oacc[cb] += fcq[q] * acc[cb][q] * xv[cb][q];
+        } else {
+            for (int o = o_lo; o <= o_hi; o++) {            // wave-uniform; atoms in between without rows get zeros (again)
+                float part[NCB];
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    part[cb] = o == o_lo ? oacc[cb] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) part[cb] += own[q] == o ? fcq[q] * acc[cb][q] * xv[cb][q] : 0.f;
+                }
+                if (o < o_hi) {
+                    flush(o, part);
+                } else {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) oacc[cb] = part[cb];
+                }
+            }
+        }
+        carry = o_hi;
+        wave_fence();
     }
+    if (carry >= 0) flush(carry, oacc);
 }
-
 
 // Single-instruction transcendentals for the matrix-core kernels (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp):
 // the 2 x 16 x W activations of a tile would otherwise cost as much issue time as its MFMAs.
