@@ -192,23 +192,29 @@ __device__ __forceinline__ void decode_triple(int NB, const AtomGroups& G, int t
 // =============================================================================================
 // Neighbour build.
 // =============================================================================================
-// Appends the lanes flagged in_a / in_ro to the two ends of a row (ballot compaction keeps scan
-// order); the row is mirrored in LDS (`stage`, same layout) for the radial sums and the species sort
-// that follow the scan in the same kernel.
-__device__ __forceinline__ void append_to_row(float4* __restrict__ row, int cap, float4* stage, bool in_a,
-                                              bool in_ro, float dx, float dy, float dz, int word, int& na, int& nro) {
+// Appends the lanes flagged in_a / in_ro to the two ends of the row being assembled in LDS (`stage`, same layout
+// as the global row; ballot compaction keeps scan order).  The global row is written once, coalesced, after
+// the scan (flush_row): the radial sums and the species sort that follow work from the LDS copy.
+__device__ __forceinline__ void append_to_row(int cap, float4* stage, bool in_a, bool in_ro, float dx, float dy, float dz,
+                                              int word, int& na, int& nro) {
     const unsigned long long ma = __ballot(in_a), mro = __ballot(in_ro);
     const float4 rec = make_float4(dx, dy, dz, __int_as_float(word));
     if (in_a) {
         const int slot = na + prefix_popc(ma);
-        if (slot < cap) { row[slot] = rec; stage[slot] = rec; }
+        if (slot < cap) stage[slot] = rec;
     }
     if (in_ro) {
         const int slot = nro + prefix_popc(mro);
-        if (slot < cap) { row[cap - 1 - slot] = rec; stage[cap - 1 - slot] = rec; }
+        if (slot < cap) stage[cap - 1 - slot] = rec;
     }
     na += __popcll(ma);
     nro += __popcll(mro);
+}
+
+__device__ __forceinline__ void flush_row(float4* __restrict__ row, const float4* stage, int cap, int na, int nro) {
+    const int front = min(na, cap), back = min(nro, cap - front);
+    for (int e = lane_id(); e < cap; e += 64)
+        if (e < front || e >= cap - back) row[e] = stage[e];
 }
 
 // After the scan: sort the staged angular neighbours by species (stable), evaluate everything that
@@ -379,12 +385,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
             in_r = r2 < rcr2;
             in_a = in_r && (r2 < rca2);
         }
-        append_to_row(row, cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
+        append_to_row(cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
     }
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
+    flush_row(row, stage, cap, na, nro);
     radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
                      tri + (size_t)i * triples_capacity(capA), G);
@@ -433,11 +440,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     int na = 0, nro = 0;
     const Stencil st = gather_stencil(g, cell_start, cx, cy, cz);
     // (stencil_slot reads other lanes' registers: every lane calls it, out-of-range lanes with a clamped index)
-    float4 pj = sorted_pos[stencil_slot(st, min(lane, max(st.total - 1, 0)))];
+    const int last = max(st.total - 1, 0);
+    float4 pj = sorted_pos[stencil_slot(st, min(lane, last))];
     for (int base = 0; base < ((dbg & 256) ? 0 : st.total); base += 64) {
         const int k = base + lane;
         const float4 cur = pj;
-        const int next_slot = stencil_slot(st, min(k + 64, st.total - 1));
+        const int next_slot = stencil_slot(st, min(k + 64, last));
         if (base + 64 < st.total) pj = sorted_pos[next_slot];                                   // next batch in flight
         bool in_r = false, in_a = false;
         int word = 0;
@@ -452,12 +460,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                 in_a = in_r && (r2 < rca2);
             }
         }
-        append_to_row(row, cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
+        append_to_row(cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
     }
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
+    flush_row(row, stage, cap, na, nro);
     if (!(dbg & 64)) radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
     if (dbg & 128) return;
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
