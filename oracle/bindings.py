@@ -34,6 +34,9 @@ def build_oracle(with_ref=True, quiet=True):
     subprocess.check_call(["make", "-C", _HERE, "all"], stdout=out)
     if with_ref and os.path.isdir("/root/reference/src/ani"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=out)
+        # the reference's own C++ test suites against the HIP library (needs nnpops_amd/libnnpops_hip.so)
+        if os.path.exists(os.path.join(os.path.dirname(_HERE.rstrip("/")), "nnpops_amd", "libnnpops_hip.so")):
+            subprocess.check_call(["make", "-C", _HERE, "ref_tests"], stdout=out)
 
 
 def have_ref():
