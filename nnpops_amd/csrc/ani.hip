@@ -434,7 +434,7 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));      // clean slate for the next build
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
     // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
-    h->tile = std::min(32, std::max(8, (st[kStatMaxAngular] + 3) / 4 * 4));
+    h->tile = std::min(32, std::max(8, st[kStatMaxAngular]));      // exact: every row of LDS saved is occupancy
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
     if (st[kStatOverflow] & 4) {          // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins

@@ -932,16 +932,19 @@ template <int NFRP, int NFZP>
 __host__ __device__ inline size_t ang_bwd_lds_bytes(int capA, int NB, int tile) {
     size_t b = (size_t)capA * (2 * sizeof(float4) + 4 * sizeof(float));
     b += (size_t)NB * NFRP * NFZP * sizeof(float);
-    b += (size_t)3 * tile * (tile + 1) * sizeof(float);
+    b += (size_t)2 * tile * (tile + 1) * sizeof(float);      // pair matrix of {alpha, beta}
     return b;
 }
 
-// Forces of one triple on its two leg atoms (Fp, Fq), given the scaled upstream-gradient block.
+// Forces of one triple on its two leg atoms, given the scaled upstream-gradient block, as three scalars:
+//     F_p = alpha_p * A + beta * B,      F_q = alpha_q * B + beta * A        (A, B = displacements of the legs)
+// -- the pair matrix then holds two floats per entry instead of a vector, which is what lets 15 instead of 11
+// waves share a CU's LDS (the kernel is latency bound at that occupancy: time x waves is constant).
 template <bool TORCHANI, int NFRP, int NFZP>
 __device__ __forceinline__ void triple_forces(const float4& A, const float4& A2, const float4& B, const float4& B2,
                                               const float* Gb, const float (&frc)[NFRP], const float (&frs)[NFRP],
                                               const float (&fre)[NFRP], const float (&zz)[NFZP], const float (&zc)[NFZP],
-                                              const float (&zs)[NFZP], float (&Fp)[3], float (&Fq)[3]) {
+                                              const float (&zs)[NFZP], float& alpha_p, float& alpha_q, float& beta) {
     const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
     float R[NFRP], dR[NFRP];
 #pragma unroll
@@ -989,12 +992,10 @@ __device__ __forceinline__ void triple_forces(const float4& A, const float4& A2,
     const float dadd = -damp * fast_rcp(g.s) * iprod * t3;
     const float ka = dot * A2.z * A2.z, kb = dot * B2.z * B2.z;
     const float s1 = t1 * A2.z, s2 = t2 * B2.z;
-    Fp[0] = s1 * A.x + dadd * (B.x - ka * A.x);
-    Fp[1] = s1 * A.y + dadd * (B.y - ka * A.y);
-    Fp[2] = s1 * A.z + dadd * (B.z - ka * A.z);
-    Fq[0] = s2 * B.x + dadd * (A.x - kb * B.x);
-    Fq[1] = s2 * B.y + dadd * (A.y - kb * B.y);
-    Fq[2] = s2 * B.z + dadd * (A.z - kb * B.z);
+    // F_p = s1 A + dadd (B - ka A),  F_q = s2 B + dadd (A - kb B)
+    alpha_p = s1 - dadd * ka;
+    alpha_q = s2 - dadd * kb;
+    beta = dadd;
 }
 
 template <bool TORCHANI, int NFRP, int NFZP>
@@ -1020,9 +1021,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float* facc = (float*)cursor;         cursor += (size_t)capA * 4 * sizeof(float);   // per-slot force accumulators
     float* grow = (float*)cursor;         cursor += (size_t)NB * BLK * sizeof(float);   // scaled upstream gradient row
-    float* Mx = (float*)cursor;           cursor += (size_t)tile * tstride * sizeof(float);
-    float* My = (float*)cursor;           cursor += (size_t)tile * tstride * sizeof(float);
-    float* Mz = (float*)cursor;
+    float2* M = (float2*)cursor;          // [tile][tile + 1] {alpha of the row's slot, beta} per ordered pair
 
     int n, nro;
     clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
@@ -1091,30 +1090,37 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
             const int next_word = (t + 64 < T) ? tri[t + 64] : 0;
             if (t < T) {
                 const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;
-                float Fp[3], Fq[3];
+                float ap, aq, bt;
                 triple_forces<TORCHANI, NFRP, NFZP>(recA[p], recB[p], recA[q], recB[q], grow + bucket * BLK, frc, frs, fre,
-                                                    zz, zc, zs, Fp, Fq);
-                Mx[p * tstride + q] = Fp[0]; My[p * tstride + q] = Fp[1]; Mz[p * tstride + q] = Fp[2];
-                Mx[q * tstride + p] = Fq[0]; My[q * tstride + p] = Fq[1]; Mz[q * tstride + p] = Fq[2];
+                                                    zz, zc, zs, ap, aq, bt);
+                M[p * tstride + q] = make_float2(ap, bt);
+                M[q * tstride + p] = make_float2(aq, bt);
             }
             word = next_word;
         }
         wave_fence();
-        // row sums: lane (e, half) adds up to 16 columns of row e; halves folded by one shuffle
+        // row sums: lane (e, half) walks up to 16 columns of row e; halves folded by one shuffle
+        //   F_e = (sum_x alpha[e][x]) * A_e + sum_x beta[e][x] * A_x
         const int e = lane & 31, half = lane >> 5;
-        float fx = 0.f, fy = 0.f, fz = 0.f;
+        float fx = 0.f, fy = 0.f, fz = 0.f, as = 0.f;
         if (e < n && !(dbg & 2)) {
             const int x0 = half * 16, x1 = min(n, x0 + 16);
-            const float* mx = Mx + e * tstride;
-            const float* my = My + e * tstride;
-            const float* mz = Mz + e * tstride;
+            const float2* m = M + e * tstride;
 #pragma unroll 4
             for (int x = x0; x < x1; x++) {
+                const float2 ab = m[x];
+                const float4 Ax = recA[x];
                 const bool use = x != e;
-                fx += use ? mx[x] : 0.f;
-                fy += use ? my[x] : 0.f;
-                fz += use ? mz[x] : 0.f;
+                as += use ? ab.x : 0.f;
+                const float b = use ? ab.y : 0.f;
+                fx += b * Ax.x; fy += b * Ax.y; fz += b * Ax.z;
             }
+        }
+        as += __shfl_xor(as, 32, 64);
+        if (e < n) {
+            const float4 Ae = recA[e];
+            const float own = half == 0 ? as : 0.f;          // counted once
+            fx += own * Ae.x; fy += own * Ae.y; fz += own * Ae.z;
         }
         fx += __shfl_xor(fx, 32, 64); fy += __shfl_xor(fy, 32, 64); fz += __shfl_xor(fz, 32, 64);
         if (half == 0 && e < n) { facc[e * 4] = fx; facc[e * 4 + 1] = fy; facc[e * 4 + 2] = fz; }
@@ -1138,32 +1144,35 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                         const float4 A2 = recB[p], B2 = recB[q];
                         const int sa = __float_as_int(A2.w) >> kTagShift, sb = __float_as_int(B2.w) >> kTagShift;
                         const int bucket = sa * S - (sa * (sa - 1)) / 2 + (sb - sa);      // sorted: sa <= sb, ref :39-43
-                        float Fp[3], Fq[3];
+                        float ap, aq, bt;
                         triple_forces<TORCHANI, NFRP, NFZP>(recA[p], A2, recA[q], B2, grow + bucket * BLK, frc, frs, fre, zz,
-                                                            zc, zs, Fp, Fq);
-                        if (pass == 0) {
-                            Mx[pl * tstride + ql] = Fp[0]; My[pl * tstride + ql] = Fp[1]; Mz[pl * tstride + ql] = Fp[2];
-                        }
-                        if (diag || pass == 1) {
-                            Mx[ql * tstride + pl] = Fq[0]; My[ql * tstride + pl] = Fq[1]; Mz[ql * tstride + pl] = Fq[2];
-                        }
+                                                            zc, zs, ap, aq, bt);
+                        if (pass == 0) M[pl * tstride + ql] = make_float2(ap, bt);
+                        if (diag || pass == 1) M[ql * tstride + pl] = make_float2(aq, bt);
                     }
                     wave_fence();
                     const int e = lane & 31, half = lane >> 5;
-                    const int rows = (diag || pass == 0) ? np : nq;
+                    const bool p_rows = diag || pass == 0;                 // rows are slots of the p block
+                    const int rows = p_rows ? np : nq;
                     const int cols = diag ? np : (pass == 0 ? nq : np);
-                    float fx = 0.f, fy = 0.f, fz = 0.f;
+                    const int row0 = p_rows ? p0 : q0, col0 = diag ? p0 : (pass == 0 ? q0 : p0);
+                    float fx = 0.f, fy = 0.f, fz = 0.f, as = 0.f;
                     if (e < rows) {
                         const int x0 = half * 16, x1 = min(cols, x0 + 16);
                         for (int x = x0; x < x1; x++) {
                             if (diag && x == e) continue;
-                            fx += Mx[e * tstride + x]; fy += My[e * tstride + x]; fz += Mz[e * tstride + x];
+                            const float2 ab = M[e * tstride + x];
+                            const float4 Ax = recA[col0 + x];
+                            as += ab.x;
+                            fx += ab.y * Ax.x; fy += ab.y * Ax.y; fz += ab.y * Ax.z;
                         }
                     }
+                    as += __shfl_xor(as, 32, 64);
                     fx += __shfl_xor(fx, 32, 64); fy += __shfl_xor(fy, 32, 64); fz += __shfl_xor(fz, 32, 64);
                     if (half == 0 && e < rows) {
-                        const int slot = ((diag || pass == 0) ? p0 : q0) + e;
-                        facc[slot * 4] += fx; facc[slot * 4 + 1] += fy; facc[slot * 4 + 2] += fz;
+                        const int slot = row0 + e;
+                        const float4 Ae = recA[slot];
+                        facc[slot * 4] += fx + as * Ae.x; facc[slot * 4 + 1] += fy + as * Ae.y; facc[slot * 4 + 2] += fz + as * Ae.z;
                     }
                     wave_fence();
                 }
