@@ -51,6 +51,7 @@ struct nnpops_ani {
     int cap = 0;                    // row capacity (angular + radial-only neighbours)
     int cap_angular = 0;            // LDS capacity of the angular kernels
     int tile = 32;                  // pair-matrix edge of the angular backward kernel (<= 32, sized in check())
+    bool compact_bwd = false;       // check() saw no atom with more than `tile` angular neighbours: compact LDS layout
     bool computed = false;
     int debug = 0;                  // kernel ablation bits from $NNPOPS_ANI_DEBUG (timing experiments only)
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
@@ -158,7 +159,7 @@ template <bool TA, int NFRP, int NFZP>
 int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float* out) {
     const int N = h->hp.N;
     const size_t lds = forward ? ang_fwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB)
-                               : ang_bwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, h->tile);
+                               : ang_bwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, h->tile, h->compact_bwd);
     if (lds > 160 * 1024)
         return fail(NNPOPS_ERR_UNSUPPORTED, "angular kernel needs %zu bytes of LDS per wave (> 160 KiB)", lds);
     const int lds_wave = (int)((lds + 15) & ~(size_t)15);
@@ -175,7 +176,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->tile, h->d_recA,
                            h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->d_leg_force, h->d_centre_force, h->debug,
-                           lds_wave);
+                           lds_wave, (int)h->compact_bwd);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
@@ -435,6 +436,7 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
     // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
     h->tile = std::min(32, std::max(8, st[kStatMaxAngular]));      // exact: every row of LDS saved is occupancy
+    h->compact_bwd = st[kStatMaxAngular] <= h->tile && h->tile >= 16;     // (tiny tiles: nothing to gain, and the fallback needs room)
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
     if (st[kStatOverflow] & 4) {          // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins

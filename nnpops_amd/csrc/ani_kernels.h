@@ -929,11 +929,17 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
 // its triples straight from the builder's word list; an atom that outgrows the tile is processed
 // tile pair by tile pair (enumerating pairs itself, off-diagonal tiles in two passes).
 // ---------------------------------------------------------------------------------------------
+// `compact`: no atom of the system has more than `tile` angular neighbours (the host knows from check()), so the
+// tile-pair fallback cannot run: beta is stored once per unordered pair and the per-slot force accumulators
+// reuse the gradient block's space.
 template <int NFRP, int NFZP>
-__host__ __device__ inline size_t ang_bwd_lds_bytes(int capA, int NB, int tile) {
-    size_t b = (size_t)capA * (2 * sizeof(float4) + 4 * sizeof(float));
+__host__ __device__ inline size_t ang_bwd_lds_bytes(int capA, int NB, int tile, bool compact) {
+    size_t b = (size_t)capA * 2 * sizeof(float4);
+    if (!compact) b += (size_t)capA * 4 * sizeof(float);
     b += (size_t)NB * NFRP * NFZP * sizeof(float);
-    b += (size_t)2 * tile * (tile + 1) * sizeof(float);      // pair matrix of {alpha, beta}
+    if (compact) b += ((size_t)tile * (tile + 1) + (size_t)tile * (tile - 1) / 2) * sizeof(float);   // alpha square + beta triangle
+    else b += (size_t)2 * tile * (tile + 1) * sizeof(float);                                        // {alpha, beta} square
+    b = std::max(b, (size_t)capA * (2 * sizeof(float4) + 4 * sizeof(float)) + (size_t)NB * NFRP * NFZP * sizeof(float));
     return b;
 }
 
@@ -1009,7 +1015,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                                                            const float* __restrict__ angular_grad,
                                                            float4* __restrict__ leg_force,      // [N][capA]
                                                            float4* __restrict__ centre_force,   // [N]
-                                                           int dbg, int lds_per_wave) {
+                                                           int dbg, int lds_per_wave, int compact) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int i = wave_global_id(), lane = lane_id();
     const int S = P->S, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
@@ -1020,9 +1026,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     char* cursor = lds_raw + (size_t)wave_in_group() * lds_per_wave;
     float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
-    float* facc = (float*)cursor;         cursor += (size_t)capA * 4 * sizeof(float);   // per-slot force accumulators
+    float* facc = (float*)cursor;         // per-slot forces; compact layout: the space of `grow`, dead by then
+    if (!compact) cursor += (size_t)capA * 4 * sizeof(float);
     float* grow = (float*)cursor;         cursor += (size_t)NB * BLK * sizeof(float);   // scaled upstream gradient row
-    float2* M = (float2*)cursor;          // [tile][tile + 1] {alpha of the row's slot, beta} per ordered pair
+    float2* M = (float2*)cursor;          // tile-pair fallback: [tile][tile + 1] {alpha of the row's slot, beta} per ordered pair
+    float* Ma = (float*)cursor;           // common path: alpha[tile][tile + 1] ...
+    float* Mb = Ma + tile * tstride;      // ... and beta, once per unordered pair (p < q), triangular
 
     int n, nro;
     clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
@@ -1065,7 +1074,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                 for (int m = lane; m < nA; m += 64) grow[bk * BLK + P->c_of_m[m]] = g[bk * nA + m] * P->scale_m[m];
         }
     }
-    for (int q = lane; q < n * 4; q += 64) facc[q] = 0.f;
+    if (!compact)                                          // (only the tile-pair fallback accumulates into facc)
+        for (int q = lane; q < n * 4; q += 64) facc[q] = 0.f;
     load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
     if (dbg & 16) return;                                  // ablation: prologue only
 
@@ -1084,6 +1094,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     }
     wave_fence();
 
+    float* fsum = facc;                                    // where the per-slot forces end up
     if (n <= tile) {
         // ---------------- common case: one tile, triples from the builder's list ----------------
         for (int base = 0; base < T && !(dbg & 1); base += 64) {
@@ -1094,27 +1105,33 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                 float ap, aq, bt;
                 triple_forces<TORCHANI, NFRP, NFZP>(recA[p], recB[p], recA[q], recB[q], grow + bucket * BLK, frc, frs, fre,
                                                     zz, zc, zs, ap, aq, bt);
-                M[p * tstride + q] = make_float2(ap, bt);
-                M[q * tstride + p] = make_float2(aq, bt);
+                Ma[p * tstride + q] = ap;
+                Ma[q * tstride + p] = aq;
+                Mb[p * (2 * tile - p - 1) / 2 + (q - p - 1)] = bt;            // p < q: once per unordered pair
             }
             word = next_word;
         }
         wave_fence();
         // row sums: lane (e, half) walks up to 16 columns of row e; halves folded by one shuffle
-        //   F_e = (sum_x alpha[e][x]) * A_e + sum_x beta[e][x] * A_x
+        //   F_e = (sum_x alpha[e][x]) * A_e + sum_x beta{e,x} * A_x
         const int e = lane & 31, half = lane >> 5;
         float fx = 0.f, fy = 0.f, fz = 0.f, as = 0.f;
         if (e < n && !(dbg & 2)) {
             const int x0 = half * 16, x1 = min(n, x0 + 16);
-            const float2* m = M + e * tstride;
+            const float* ma = Ma + e * tstride;
+            // index of beta{e,x} in the triangle: x < e: x(2T-x-1)/2 + e-x-1 (grows by T-x-2 per step), x > e: base_e + x-e-1
+            int below = x0 * (2 * tile - x0 - 1) / 2 + (e - x0 - 1);
+            const int above0 = e * (2 * tile - e - 1) / 2 - e - 1;
 #pragma unroll 4
             for (int x = x0; x < x1; x++) {
-                const float2 ab = m[x];
-                const float4 Ax = recA[x];
                 const bool use = x != e;
-                as += use ? ab.x : 0.f;
-                const float b = use ? ab.y : 0.f;
+                const int bi = x < e ? below : above0 + x;
+                const float al = ma[x];
+                const float b = use ? Mb[use ? bi : 0] : 0.f;
+                const float4 Ax = recA[x];
+                as += use ? al : 0.f;
                 fx += b * Ax.x; fy += b * Ax.y; fz += b * Ax.z;
+                below += tile - x - 2;
             }
         }
         as += __shfl_xor(as, 32, 64);
@@ -1128,11 +1145,22 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
         wave_fence();
     } else {
         // ---------------- an atom larger than the pair matrix: tile pairs ----------------
-        const int nblk = (n + tile - 1) / tile;
+        // (compact layout: the host did not expect this atom -- it appeared after the last check().  Still exact:
+        // the accumulators move to the end of the matrix region and the tile shrinks to what is left.)
+        int ft = tile;
+        if (compact) {
+            const int region = tile * tstride + tile * (tile - 1) / 2;
+            fsum = Ma + region - capA * 4;
+            while (2 * ft * (ft + 1) > region - capA * 4) ft--;
+            for (int q = lane; q < n * 4; q += 64) fsum[q] = 0.f;
+            wave_fence();
+        }
+        const int fs = ft + 1;
+        const int nblk = (n + ft - 1) / ft;
         for (int PB = 0; PB < nblk; PB++) {
             for (int QB = PB; QB < nblk; QB++) {
-                const int p0 = PB * tile, q0 = QB * tile;
-                const int np = min(tile, n - p0), nq = min(tile, n - q0);
+                const int p0 = PB * ft, q0 = QB * ft;
+                const int np = min(ft, n - p0), nq = min(ft, n - q0);
                 const bool diag = PB == QB;
                 const int Tt = diag ? (np * (np - 1)) / 2 : np * nq;
                 const int npass = diag ? 1 : 2;           // off-diagonal: forces on the p block, then on the q block
@@ -1148,8 +1176,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                         float ap, aq, bt;
                         triple_forces<TORCHANI, NFRP, NFZP>(recA[p], A2, recA[q], B2, grow + bucket * BLK, frc, frs, fre, zz,
                                                             zc, zs, ap, aq, bt);
-                        if (pass == 0) M[pl * tstride + ql] = make_float2(ap, bt);
-                        if (diag || pass == 1) M[ql * tstride + pl] = make_float2(aq, bt);
+                        if (pass == 0) M[pl * fs + ql] = make_float2(ap, bt);
+                        if (diag || pass == 1) M[ql * fs + pl] = make_float2(aq, bt);
                     }
                     wave_fence();
                     const int e = lane & 31, half = lane >> 5;
@@ -1162,7 +1190,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                         const int x0 = half * 16, x1 = min(cols, x0 + 16);
                         for (int x = x0; x < x1; x++) {
                             if (diag && x == e) continue;
-                            const float2 ab = M[e * tstride + x];
+                            const float2 ab = M[e * fs + x];
                             const float4 Ax = recA[col0 + x];
                             as += ab.x;
                             fx += ab.y * Ax.x; fy += ab.y * Ax.y; fz += ab.y * Ax.z;
@@ -1173,7 +1201,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                     if (half == 0 && e < rows) {
                         const int slot = row0 + e;
                         const float4 Ae = recA[slot];
-                        facc[slot * 4] += fx + as * Ae.x; facc[slot * 4 + 1] += fy + as * Ae.y; facc[slot * 4 + 2] += fz + as * Ae.z;
+                        fsum[slot * 4] += fx + as * Ae.x; fsum[slot * 4 + 1] += fy + as * Ae.y; fsum[slot * 4 + 2] += fz + as * Ae.z;
                     }
                     wave_fence();
                 }
@@ -1187,7 +1215,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     float cx = 0.f, cy = 0.f, cz = 0.f;
     float4* out = leg_force + (size_t)i * capA;
     for (int e = lane; e < n; e += 64) {
-        const float fx = facc[e * 4], fy = facc[e * 4 + 1], fz = facc[e * 4 + 2];
+        const float fx = fsum[e * 4], fy = fsum[e * 4 + 1], fz = fsum[e * 4 + 2];
         out[e] = make_float4(fx, fy, fz, 0.f);
         cx -= fx; cy -= fy; cz -= fz;
     }

@@ -167,6 +167,35 @@ def test_forces_bitwise_reproducible():
         assert np.array_equal(r, runs[0][0]) and np.array_equal(a, runs[0][1]) and np.array_equal(g, runs[0][2])
 
 
+def test_denser_frame_after_the_last_check_is_still_exact():
+    """check() sizes the angular backward's LDS pair matrix to the busiest atom it has seen (compact layout).  A later
+    frame evaluated WITHOUT a check (graph replay, check=False) may hold a busier atom: the kernel must notice per
+    atom and fall back to tile pairs inside the space it has, not corrupt anything."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1500, seed=24)
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True)
+    dev = torch.device("cuda:0")
+    sym.compute(torch.tensor(pos, device=dev), torch.tensor(box, device=dev))          # with check: sizes the matrix
+    _, max_a = sym.neighbor_stats()
+    shrink = np.float32(0.93)                                                            # ~24 % denser: busier atoms
+    pos2, box2 = pos * shrink, box * shrink
+    oracle = AniOracle(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True)
+    r_ref, a_ref = oracle.forward(pos2, box2)
+    busiest = int((np.linalg.norm(a_ref.reshape(len(pos), -1), axis=1) > 0).sum())      # (sanity: everyone has triples)
+    assert busiest == len(pos)
+    rng = np.random.default_rng(2)
+    wr = rng.standard_normal(r_ref.shape).astype(np.float32)
+    wa = rng.standard_normal(a_ref.shape).astype(np.float32)
+    g_ref = oracle.backward(wr, wa)
+    radial, angular = sym.compute(torch.tensor(pos2, device=dev), torch.tensor(box2, device=dev), check=False)
+    grad = sym.backprop(torch.tensor(wr, device=dev), torch.tensor(wa, device=dev))
+    _, max_b = sym.neighbor_stats()
+    assert max_b > max_a and max_b <= 32, (max_a, max_b)       # the scenario really happened, rows did not overflow
+    np.testing.assert_allclose(angular.cpu().numpy(), a_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
+    assert np.abs(grad.cpu().numpy() - g_ref).max() <= FORCE_RTOL * np.abs(g_ref).max()
+
+
 def test_single_atom_and_isolated_atoms():
     rf, af = workloads.ani2x_functions()
     pos = np.array([[0, 0, 0], [30, 0, 0], [0, 30, 0]], dtype=np.float32)
