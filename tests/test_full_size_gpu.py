@@ -114,3 +114,30 @@ def test_cfconv_10k_forces_sum_to_zero_and_match_vector_kernels(monkeypatch):
     fmax = float(gp1.abs().max())
     assert float((gp0 - gp1).abs().max()) <= 1e-4 * fmax
     assert gp0.double().sum(0).abs().max().item() <= 1e-3 * fmax
+
+
+def test_headline_workload_against_the_oracle_at_full_size():
+    """The benchmark's own frame (10 000 atoms, periodic, 7 species uniform, seed 100) element by element against the
+    CPU oracle (O(N^2), a few seconds): AEV rtol 2e-5 / atol 2e-6, energy 1e-5, forces 1e-4 of the largest component."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    from oracle import AniOracle
+    pos, species, box = workloads.random_box(10000, density=0.1, seed=100, n_species=7)
+    rf, af = workloads.ani2x_functions()
+    oracle = AniOracle(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True)
+    r_ref, a_ref = oracle.forward(pos, box)
+    rng = np.random.default_rng(0)
+    wr = rng.standard_normal(r_ref.shape).astype(np.float32)
+    wa = rng.standard_normal(a_ref.shape).astype(np.float32)
+    g_ref = oracle.backward(wr, wa)
+    dev = torch.device("cuda:0")
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+    radial, angular = sym.compute(torch.tensor(pos, device=dev), torch.tensor(box, device=dev))
+    grad = sym.backprop(torch.tensor(wr, device=dev), torch.tensor(wa, device=dev))
+    r, a, g = radial.cpu().numpy(), angular.cpu().numpy(), grad.cpu().numpy()
+    np.testing.assert_allclose(r, r_ref, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(a, a_ref, rtol=2e-5, atol=2e-6)
+    e_ref = float((r_ref.astype(np.float64) * wr).sum() + (a_ref.astype(np.float64) * wa).sum())
+    e = float((r.astype(np.float64) * wr).sum() + (a.astype(np.float64) * wa).sum())
+    scale = float(np.abs(r_ref.astype(np.float64) * wr).sum() + np.abs(a_ref.astype(np.float64) * wa).sum())
+    assert abs(e - e_ref) <= 1e-5 * scale
+    assert np.abs(g - g_ref).max() <= 1e-4 * np.abs(g_ref).max()
