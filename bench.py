@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="torchani workload: replay the step as one captured HIP graph")
     ap.add_argument("--nn-layout", default="grouped", choices=["grouped", "reference"],
                     help="torchani workload: species-grouped GEMMs (default) or the reference's per-atom replicated weights")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
@@ -305,7 +306,9 @@ def main_torchani(args):
     if args.nn_layout == "reference":
         opt.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="reference")
     opt = opt.to(dev)
-    cell, pbc = torch.tensor(box, device=dev), torch.tensor([True, True, True], device=dev)
+    # (pbc stays on the host: the wrapper reads it with .tolist(), reference SymmetryFunctions.py:113, which on a
+    # device tensor is a synchronising copy and cannot be captured)
+    cell, pbc = torch.tensor(box, device=dev), torch.tensor([True, True, True])
     tpos = torch.tensor(pos, device=dev).unsqueeze(0).requires_grad_(True)
     n = len(species)
 
@@ -318,11 +321,39 @@ def main_torchani(args):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        energy = step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    if args.graph:
+        # the whole energy+forces step as one HIP graph (the AEV holder skips its capacity check while capturing;
+        # capacities were calibrated by the warm-up steps above): removes the ~70 host launches per step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        tpos.grad = None
+        with torch.cuda.graph(graph):
+            g_energy = opt((numbers, tpos), cell, pbc).energies
+            g_forces = torch.autograd.grad(g_energy.sum(), tpos)[0]
+        torch.cuda.synchronize()
+        eager_e = step().detach().clone()
+        eager_g = tpos.grad.detach().clone()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(g_energy, eager_e, rtol=1e-6, atol=1e-4) and torch.allclose(g_forces, eager_g, rtol=1e-4, atol=1e-5)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        energy = g_energy
+        tpos.grad = g_forces
+    else:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            energy = step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(energy).all()) and bool(torch.isfinite(tpos.grad).all())
     # NN flops: 2 * models * sum over atoms of the MACs of its network; backward to the
     # inputs costs the same again
@@ -335,7 +366,7 @@ def main_torchani(args):
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"OptimizedTorchANI, {n}-atom periodic water box (667 H2O), ANI-2x AEV + 8 x ANI-2x-shaped networks, "
-                               f"random weights, BatchedNN layout = {args.nn_layout}", "atoms": n,
+                               f"random weights, BatchedNN layout = {args.nn_layout}" + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
                    "nn_weight_bytes": nn_weight_bytes},
         "roofline": {"bound": "mfma", "kernel": "BatchedNN GEMMs (hipBLASLt via torch.matmul), forward + input-gradient backward",
                      "achieved": round(2 * flops_fwd / elapsed * args.steps / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",

@@ -388,3 +388,43 @@ def test_cfconv_module_periodic_extension(kind):
     # a holder is periodic or not for life
     with pytest.raises(RuntimeError, match="periodicity"):
         layer.neighbors.build(tpos.detach())
+
+
+def test_optimized_torchani_step_replays_as_one_graph():
+    """Energy + forces of OptimizedTorchANI captured once and replayed on NEW positions (what an MD loop does): the
+    AEV holder does no host round trip while capturing, the cell histogram is re-zeroed by the kernels themselves,
+    so the replay must equal an eager evaluation of the new frame."""
+    from NNPOps import OptimizedTorchANI
+    model = workloads.torchani_like_model(n_models=2, seed=3)
+    pos, species, box = workloads.water_box(400, seed=7)              # 1 200 atoms: cell-grid path
+    numbers = _numbers(species)
+    opt = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True])     # host pbc: .tolist() cannot be captured
+    static_pos = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+
+    def eager(p):
+        q = p.detach().clone().requires_grad_(True)
+        e = opt((numbers, q), cell, pbc).energies
+        return e.detach().clone(), torch.autograd.grad(e.sum(), q)[0]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):                                             # calibrates neighbour capacities, warms allocators
+            e = opt((numbers, static_pos), cell, pbc).energies
+            torch.autograd.grad(e.sum(), static_pos)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_e = opt((numbers, static_pos), cell, pbc).energies
+        g_f = torch.autograd.grad(g_e.sum(), static_pos)[0]
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        new = (pos + rng.normal(0, 0.05, pos.shape)).astype(np.float32)
+        with torch.no_grad():
+            static_pos.copy_(torch.tensor(new, device=DEV).unsqueeze(0))
+        graph.replay()
+        torch.cuda.synchronize()
+        e_ref, f_ref = eager(static_pos)
+        torch.testing.assert_close(g_e, e_ref, rtol=1e-6, atol=1e-4)
+        torch.testing.assert_close(g_f, f_ref, rtol=1e-4, atol=1e-5 * float(f_ref.abs().max()))
