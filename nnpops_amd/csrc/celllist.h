@@ -354,6 +354,63 @@ __device__ __forceinline__ int stencil_slot(const Stencil& S, int k) {
     return k + __builtin_amdgcn_ds_bpermute(r << 2, S.delta);
 }
 
+// Half-list variant: a consumer that wants only partners with a SMALLER atom id (getNeighborPairs: col < row)
+// need not look at the others at all.  Inside a cell the sorted arrays ascend in atom id (order_cells /
+// order_binned rank by id), so the partners of `row` in a cell are a PREFIX of that cell's run: 27 lanes
+// binary-search their cell for the first id >= row, and the flat candidate space is the concatenation of
+// the 27 prefixes -- half the candidates of the full stencil, none of them rejected for their id.
+constexpr int kStencilCells = 27;
+struct PrefixStencil {
+    int pre[kStencilCells];       // first flat index of cell r            (wave-uniform: SGPRs)
+    int delta;                    // lane r: begin_r - pre[r]
+    int total;
+};
+
+__device__ __forceinline__ PrefixStencil gather_prefix_stencil(const CellGrid& g, const int* __restrict__ cell_start,
+                                                               const int* __restrict__ sorted_atom, int cx, int cy, int cz,
+                                                               int row) {
+    const int lane = lane_id();
+    int begin = 0, count = 0;
+    if (lane < kStencilCells) {
+        int z = cz + lane / 9 - 1, y = cy + (lane / 3) % 3 - 1, x = cx + lane % 3 - 1;
+        bool live = true;
+        if (g.periodic) { z = (z + g.nz) % g.nz; y = (y + g.ny) % g.ny; x = (x + g.nx) % g.nx; }
+        else live = z >= 0 && z < g.nz && y >= 0 && y < g.ny && x >= 0 && x < g.nx;
+        if (live) {
+            const int c = (z * g.ny + y) * g.nx + x;
+            begin = cell_start[c];
+            int lo = begin, hi = cell_start[c + 1];               // first slot in [lo, hi) whose id is >= row
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sorted_atom[mid] < row) lo = mid + 1;
+                else hi = mid;
+            }
+            count = lo - begin;
+        }
+    }
+    int incl = count;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {                               // 27 live lanes: five steps
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const int excl = incl - count;
+    PrefixStencil S;
+#pragma unroll
+    for (int r = 0; r < kStencilCells; r++) S.pre[r] = __builtin_amdgcn_readlane(excl, r);
+    S.delta = begin - excl;
+    S.total = __builtin_amdgcn_readlane(incl, kStencilCells - 1);
+    return S;
+}
+
+// (all lanes must call, like stencil_slot)
+__device__ __forceinline__ int stencil_slot(const PrefixStencil& S, int k) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < kStencilCells; q++) r += k >= S.pre[q] ? 1 : 0;
+    return k + __builtin_amdgcn_ds_bpermute(r << 2, S.delta);
+}
+
 // Called by the kernel that consumes the grid (all of its threads, before any early exit): leaves the
 // histogram of the two-kernel build zeroed for the next build.  `hist` may be NULL (five-kernel path).
 __device__ __forceinline__ void clear_cell_histogram(int* __restrict__ hist) {

@@ -177,7 +177,8 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
         return found;
     }
     const int c = atom_cell[row];
-    const Stencil st = gather_stencil(g, cell_start, c % g.nx, (c / g.nx) % g.ny, c / (g.nx * g.ny));
+    // only partners with a smaller id: the prefix of every stencil cell (celllist.h), half the candidates of the full walk
+    const PrefixStencil st = gather_prefix_stencil(g, cell_start, sorted_atom, c % g.nx, (c / g.nx) % g.ny, c / (g.nx * g.ny), row);
     for (int base = 0; base < st.total; base += 64) {
         const int k = base + lane;
         const int slot = stencil_slot(st, min(k, st.total - 1));          // all lanes (ds_bpermute inside)

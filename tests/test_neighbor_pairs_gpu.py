@@ -138,3 +138,18 @@ def test_large_system_cell_grid(periodic):
         assert want == got, row
     # distances consistent with deltas
     np.testing.assert_allclose(np.sqrt((dl[valid] ** 2).sum(1)), ds[valid], rtol=1e-6)
+
+
+def test_large_system_cell_grid_float64_matches_float32_pairs():
+    """The fp64 instance of the cell-grid path (gathers positions instead of reading the grid's fp32 copy): same pair
+    list as the fp32 instance on the same frame, distances to double precision of the double positions."""
+    from nnpops_amd import workloads
+    pos, _, box = workloads.random_box(12000, seed=23)
+    nb32, _, _, n32 = _run(pos, 5.0, 400000, box, torch.float32)
+    nb64, dl64, ds64, n64 = _run(pos.astype(np.float64), 5.0, 400000, box.astype(np.float64), torch.float64)
+    assert n32 == n64 and np.array_equal(nb32, nb64)              # no pair sits within fp32 rounding of the cutoff here
+    L = float(box[0, 0])
+    d = pos[nb64[0][:n64]].astype(np.float64) - pos[nb64[1][:n64]].astype(np.float64)
+    d -= np.round(d / L) * L
+    np.testing.assert_allclose(dl64[:n64], d, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ds64[:n64], np.sqrt((d * d).sum(1)), rtol=1e-14)
