@@ -102,24 +102,28 @@ __global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, 
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
     float4* row = rows + (size_t)i * cap;
     int n = 0;
-    for_each_stencil_range(g, cell_start, cx, cy, cz, [&](int begin, int end) {
-        for (int base = begin; base < end; base += 64) {
-            const int k = base + lane;
-            bool keep = false;
-            int j = -1;
-            float dx = 0.f, dy = 0.f, dz = 0.f;
-            if (k < end) {
-                const float4 pj = sorted_pos[k];
-                j = __float_as_int(pj.w) & kIdMask;
-                if (j != i) {
-                    dx = pj.x - me.x; dy = pj.y - me.y; dz = pj.z - me.z;
-                    min_image<PERIODIC>(dx, dy, dz, b);
-                    keep = dx * dx + dy * dy + dz * dz < cutoff2;
-                }
+    // the 27-cell stencil as one flat candidate space (celllist.h): full iterations, next batch's load in flight
+    const Stencil st = gather_stencil(g, cell_start, cx, cy, cz);
+    const int last = max(st.total - 1, 0);
+    float4 pj = sorted_pos[stencil_slot(st, min(lane, last))];
+    for (int base = 0; base < st.total; base += 64) {
+        const int k = base + lane;
+        const float4 cur = pj;
+        const int next_slot = stencil_slot(st, min(k + 64, last));              // (every lane: ds_bpermute inside)
+        if (base + 64 < st.total) pj = sorted_pos[next_slot];
+        bool keep = false;
+        int j = -1;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (k < st.total) {
+            j = __float_as_int(cur.w) & kIdMask;
+            if (j != i) {
+                dx = cur.x - me.x; dy = cur.y - me.y; dz = cur.z - me.z;
+                min_image<PERIODIC>(dx, dy, dz, b);
+                keep = dx * dx + dy * dy + dz * dz < cutoff2;
             }
-            append(row, cap, keep, dx, dy, dz, j, n);
         }
-    });
+        append(row, cap, keep, dx, dy, dz, j, n);
+    }
     if (lane == 0) cnt[i] = n;
 }
 
