@@ -529,18 +529,21 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
     if (carry >= 0) flush(carry, oacc);
 }
 
-// Single-instruction transcendentals for the matrix-core kernels (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp):
-// the 2 x 16 x W activations of a tile would otherwise cost as much issue time as its MFMAs.
+// Activations of the matrix-core kernels: single-instruction transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32,
+// ~1 ulp) -- the 2 x 16 x W activations of a tile would otherwise cost as much issue time as its MFMAs.  For the
+// shifted softplus the host has folded log2(e) into W1, b1 and ln(2) into W2 (nnpops_cfconv_create), so with
+// s' = log2(e) s coming out of layer 1:   y' = log2((2^s' + 1) / 2) = y / ln 2,   dy/ds = 2^s' / (2^s' + 1),
+// and layer 2 computes (ln2 W2) y' = W2 y; the d/dr path is scaled the same way (dS1' dy/ds = log2(e) dS1 dy/ds).
 template <int ACT>
 __device__ __forceinline__ float activate_fast(float s) {
-    if (ACT == 0) return (1.0f / kLog2e) * fast_log2(0.5f * fast_exp2(kLog2e * s) + 0.5f);       // ref :163
+    if (ACT == 0) return fast_log2(0.5f * fast_exp2(s) + 0.5f);                                   // ref :163
     return tanhf(s);
 }
 template <int ACT>
 __device__ __forceinline__ void activate_d_fast(float s, float& y, float& dy) {
     if (ACT == 0) {
-        const float e = fast_exp2(kLog2e * s);
-        y = (1.0f / kLog2e) * fast_log2(0.5f * e + 0.5f);
+        const float e = fast_exp2(s);
+        y = fast_log2(0.5f * e + 0.5f);
         dy = e * fast_rcp(e + 1.0f);                                                              // ref :254-257
     } else {
         const float th = tanhf(s);
@@ -745,6 +748,9 @@ struct nnpops_cfconv {
     int device = 0;
     hipStream_t stream = nullptr;
     float *d_w1t = nullptr, *d_b1 = nullptr, *d_w2t = nullptr, *d_b2 = nullptr;
+    // shifted softplus on the matrix-core path: log2(e) folded into layer 1 and ln(2) into W2, so that the
+    // activation is exp2 / fma / log2 with no scaling multiplies (see activate_fast)
+    float *d_w1t_s = nullptr, *d_b1_s = nullptr, *d_w2t_s = nullptr;
     int blocks = 256;
     bool force_valu = false;        // $NNPOPS_CFCONV_VALU=1: keep the matrix cores out (A/B timing, debugging)
 };
@@ -946,6 +952,19 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
         hipMemcpy(h->d_b1, b1, (size_t)W * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_b2, b2, (size_t)W * 4, hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail(NNPOPS_ERR_HIP, "weight upload failed"));
+    if (activation == 0) {
+        std::vector<float> w1s(w1t), w2s(w2t), b1s(b1, b1 + W);
+        for (float& v : w1s) v *= kLog2e;
+        for (float& v : b1s) v *= kLog2e;
+        for (float& v : w2s) v *= 1.0f / kLog2e;
+        if ((rc = dev_alloc(&h->d_w1t_s, w1s.size()))) return cleanup(rc);
+        if ((rc = dev_alloc(&h->d_w2t_s, w2s.size()))) return cleanup(rc);
+        if ((rc = dev_alloc(&h->d_b1_s, (size_t)W))) return cleanup(rc);
+        if (hipMemcpy(h->d_w1t_s, w1s.data(), w1s.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_w2t_s, w2s.data(), w2s.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_b1_s, b1s.data(), (size_t)W * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(NNPOPS_ERR_HIP, "weight upload failed"));
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->blocks = prop.multiProcessorCount;
     if (const char* e = std::getenv("NNPOPS_CFCONV_VALU")) h->force_valu = std::atoi(e) != 0;
@@ -957,6 +976,7 @@ int nnpops_cfconv_destroy(nnpops_cfconv_t h) {
     if (!h) return NNPOPS_OK;
     DeviceGuard guard(h->device);
     dev_free(h->d_w1t); dev_free(h->d_w2t); dev_free(h->d_b1); dev_free(h->d_b2);
+    dev_free(h->d_w1t_s); dev_free(h->d_w2t_s); dev_free(h->d_b1_s);
     delete h;
     return NNPOPS_OK;
 }
@@ -1000,8 +1020,8 @@ int launch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const flo
     if (lds > 64 * 1024)
         NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int blocks = std::max(1, std::min(h->blocks, div_up(h->p.N, wpb)));
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1t, h->d_b1, h->d_w2t, h->d_b2,
-                       nb->d_rows, nb->d_cnt, nb->cap, x, out);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * wpb), lds, h->stream, h->p, ACT == 0 ? h->d_w1t_s : h->d_w1t,
+                       ACT == 0 ? h->d_b1_s : h->d_b1, ACT == 0 ? h->d_w2t_s : h->d_w2t, h->d_b2, nb->d_rows, nb->d_cnt, nb->cap, x, out);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
@@ -1016,8 +1036,9 @@ int launch_backward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const fl
     if (lds > 64 * 1024)
         NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int blocks = std::max(1, std::min(h->blocks, div_up(h->p.N, wpb)));
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1t, h->d_b1, h->d_w2t, h->d_b2,
-                       nb->d_rows, nb->d_cnt, nb->cap, x, gout, xgrad, pos_grad);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * wpb), lds, h->stream, h->p, ACT == 0 ? h->d_w1t_s : h->d_w1t,
+                       ACT == 0 ? h->d_b1_s : h->d_b1, ACT == 0 ? h->d_w2t_s : h->d_w2t, h->d_b2, nb->d_rows, nb->d_cnt, nb->cap, x, gout,
+                       xgrad, pos_grad);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
