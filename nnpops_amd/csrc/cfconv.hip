@@ -374,6 +374,32 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_kernel(
 // Result layout of the instruction: D[row = 4*(l >> 4) + reg][col = l & 15].
 // ---------------------------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// One dense layer of a 16-row tile on the matrix core: acc[cb] += A(16 x 4*ksteps) * B(4*ksteps x 16) for the NCB
+// column blocks.  a_lane / b_lane point at this lane's operands of K step 0; a K step advances A by 4 floats and B
+// by 4 rows of W floats.  The operands of step s + 1 are requested BEFORE the MFMAs of step s are issued (explicit
+// double buffer): left to itself the compiler reuses one register pair for B and waits for LDS every two MFMAs.
+template <int NCB, int W>
+__device__ __forceinline__ void mfma_layer(const float* a_lane, const float* b_lane, int ksteps, f32x4 (&acc)[NCB]) {
+    float a_cur = a_lane[0], b_cur[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) b_cur[cb] = b_lane[cb * 16];
+#pragma unroll 2
+    for (int s = 0; s < ksteps; s++) {
+        const int nx = min(s + 1, ksteps - 1);                 // (the last step re-reads itself: no branch in the loop)
+        const float a_nxt = a_lane[4 * nx];
+        float b_nxt[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) b_nxt[cb] = b_lane[(size_t)4 * nx * W + cb * 16];
+        __builtin_amdgcn_sched_barrier(0);                     // the requests above stay above the MFMAs below
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[cb], acc[cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) b_cur[cb] = b_nxt[cb];
+    }
+}
 template <int ACT> __device__ __forceinline__ float activate_fast(float s);
 
 __host__ __device__ inline size_t mfma_weight_floats(int W, int G) { return (size_t)W * W + (size_t)((G + 3) & ~3) * W; }
@@ -424,22 +450,27 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
     for (int a = a0; a < a1; a++)                           // atoms without neighbours never own a tile row
         if (min(cnt[a], cap) == 0) flush(a, oacc);
     int carry = -1;
-    int a_cur = a0, used = 0;                               // next unread row: number `used` of atom a_cur
-    for (;;) {
-        while (a_cur < a1 && used >= min(cnt[a_cur], cap)) { a_cur++; used = 0; }      // wave-uniform
-        if (a_cur >= a1) break;
-        int my_atom = a_cur, my_e = used + (lane & 15);     // lanes 0..15: locate row `lane` of this tile
-        while (my_atom < a1) {
-            const int n = min(cnt[my_atom], cap);
-            if (my_e < n) break;
-            my_e -= n;
-            my_atom++;
+    // Locating the 16 rows of a tile (a walk over the atoms' counts) and fetching their records is a chain of
+    // dependent global loads: it is done for the NEXT tile while the matrix cores work on the current one.
+    auto request = [&](int start_atom, int start_row, int& atom, int& e, float4& rec) {
+        atom = start_atom;
+        e = start_row + (lane & 15);                        // lanes 0..15 (the others mirror them)
+        while (atom < a1) {
+            const int n = min(cnt[atom], cap);
+            if (e < n) break;
+            e -= n;
+            atom++;
         }
+        rec = atom < a1 ? rows[(size_t)atom * cap + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int my_atom, my_e;
+    float4 rec;
+    request(a0, 0, my_atom, my_e, rec);
+    while (__shfl(my_atom, 0, 64) < a1) {                   // row 0 of the tile exists (wave-uniform)
         if (lane < 16) {
             float r = 1.0f, fc = 0.f;
             int j = a0, owner = -1;
             if (my_atom < a1) {
-                const float4 rec = rows[(size_t)my_atom * cap + my_e];
                 r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
                 fc = 0.5f * cospif(r / P.cutoff) + 0.5f;                            // ref :301-303
                 j = __float_as_int(rec.w) & kIdMask;
@@ -447,9 +478,10 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
             }
             ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = __int_as_float(j); ps[48 + lane] = __int_as_float(owner);
         }
-        // where the next tile starts: one past row 15 (lane 15 knows), or the end of the run
-        const int atom15 = __shfl(my_atom, 15, 64), e15 = __shfl(my_e, 15, 64);
-        a_cur = atom15; used = e15 + 1;                     // (atom15 == a1 ends the loop at its top)
+        // the next tile starts one past row 15 (lane 15 knows): request it now
+        int next_atom, next_e;
+        float4 next_rec;
+        request(__shfl(my_atom, 15, 64), __shfl(my_e, 15, 64) + 1, next_atom, next_e, next_rec);
         wave_fence();
         // inputs of my four result rows, requested now so that the two GEMMs hide the latency
         float xv[NCB][4], fcq[4];
@@ -488,13 +520,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
         // ---- layer 2 ----
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
-        for (int s = 0; s < W / 4; s++) {
-            const int k = 4 * s + grp;
-            const float a = y1[col * YS + k];
-            const float* wrow = s_w2t + k * W + col;
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
-        }
+        mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, acc);
         // ---- output: rows are summed into their owner (ref :175, :181); padding rows have fc = 0 ----
         if (carry >= 0 && carry != o_lo) {                  // the previous tile ended exactly on an atom boundary
             flush(carry, oacc);
@@ -524,6 +550,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_forward_mfma(
             }
         }
         carry = o_hi;
+        my_atom = next_atom; my_e = next_e; rec = next_rec;
         wave_fence();
     }
     if (carry >= 0) flush(carry, oacc);
@@ -650,14 +677,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
             // ---- layer 2 on Y1 ----
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
-#pragma unroll 4
-            for (int s = 0; s < W / 4; s++) {
-                const int k = 4 * s + grp;
-                const float a = y1[col * YS + k];
-                const float* wrow = s_w2t + k * W + col;
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], acc[cb], 0, 0, 0);
-            }
+            mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, acc);
             wave_fence();
             // ---- refill the tile with dY1, layer 2 again ----
 #pragma unroll
@@ -668,14 +688,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
                     dacc[cb][q] = 0.f;
                 }
             wave_fence();
-#pragma unroll 4
-            for (int s = 0; s < W / 4; s++) {
-                const int k = 4 * s + grp;
-                const float a = y1[col * YS + k];
-                const float* wrow = s_w2t + k * W + col;
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[cb * 16], dacc[cb], 0, 0, 0);
-            }
+            mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, dacc);
             // ---- epilogue: my four rows of the tile ----
 #pragma unroll
             for (int q = 0; q < 4; q++) {
