@@ -34,7 +34,7 @@ def _random_geometry(rng, n, kind, density):
     return (pos + shift).astype(np.float32), box
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(52))        # seeds >= 40: dense systems (row / record capacities grow, >32 angular neighbours)
 def test_ani_random_configuration(seed):
     from nnpops_amd.capi import AniSymmetryFunctions
     rng = np.random.default_rng(1000 + seed)
@@ -51,7 +51,7 @@ def test_ani_random_configuration(seed):
     kind = ["vacuum", "cubic", "triclinic"][seed % 3]
     torchani = bool(rng.integers(0, 2))
     n = int(rng.integers(2, 60)) if kind == "vacuum" else int(rng.integers(150, 500))
-    density = float(rng.uniform(0.04, 0.11))
+    density = float(rng.uniform(0.04, 0.11)) if seed < 40 else float(rng.uniform(0.16, 0.24))
     pos, box = _random_geometry(rng, n, kind, density)
     n = len(pos)
     species = rng.integers(0, S, size=n).astype(np.int32)
@@ -158,3 +158,32 @@ def test_neighbor_pairs_random_configuration(seed):
         assert len(got) == min(num, nb.shape[1]) and len(set(got)) == len(got) and set(got) <= true_pairs
         if num <= nb.shape[1]:
             assert set(got) == true_pairs
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ani_batched_molecules_random(seed):
+    """nnpops_ani_set_molecules: a random batch of independent molecules in one handle equals the oracle molecule by
+    molecule (atoms of different molecules must never see each other, whatever their coordinates)."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rng = np.random.default_rng(4000 + seed)
+    rf, af = workloads.ani2x_functions()
+    sizes = [int(rng.integers(1, 70)) for _ in range(int(rng.integers(2, 12)))]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pos = np.concatenate([workloads.conformer(k, seed=int(rng.integers(1 << 30)))[0] for k in sizes]).astype(np.float32)
+    species = rng.integers(0, 7, size=len(pos)).astype(np.int32)       # all molecules sit on top of each other in space
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=False)
+    sym.set_molecules(offsets)
+    dev = torch.device("cuda:0")
+    radial, angular = sym.compute(torch.tensor(pos, device=dev), None)
+    wr = rng.standard_normal(tuple(radial.shape)).astype(np.float32)
+    wa = rng.standard_normal(tuple(angular.shape)).astype(np.float32)
+    grad = sym.backprop(torch.tensor(wr, device=dev), torch.tensor(wa, device=dev))
+    r, a, g = radial.cpu().numpy(), angular.cpu().numpy(), grad.cpu().numpy()
+    for m in range(len(sizes)):
+        lo, hi = offsets[m], offsets[m + 1]
+        oracle = AniOracle(7, 5.1, 3.5, species[lo:hi], rf, af, periodic=False)
+        r_ref, a_ref = oracle.forward(pos[lo:hi], None)
+        g_ref = oracle.backward(wr[lo:hi], wa[lo:hi])
+        np.testing.assert_allclose(r[lo:hi], r_ref, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(a[lo:hi], a_ref, rtol=2e-5, atol=2e-6)
+        assert np.abs(g[lo:hi] - g_ref).max() <= 1e-4 * max(float(np.abs(g_ref).max()), 1e-6)
