@@ -55,6 +55,7 @@ struct nnpops_ani {
     bool computed = false;
     int debug = 0;                  // kernel ablation bits from $NNPOPS_ANI_DEBUG (timing experiments only)
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
+    bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
     size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {};
@@ -360,6 +361,7 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
     const size_t lds_b = (size_t)lds_bw * wpg_b;
     const dim3 agrid(div_up(N, wpg_b)), ablock(64 * wpg_b);
     const bool use_cells = !h->d_segment && (h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled));
+    h->last_used_cells = use_cells;
     if (use_cells) {
         KernelTimer timer(h, NNPOPS_ANI_K_CELL_GRID);
         const CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank,
@@ -417,7 +419,7 @@ int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* 
     KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD);
     hipLaunchKernelGGL(ani_radial_backward, agrid, ablock, lds_r, h->stream, h->d_params, h->d_species, h->d_nbr, h->cap,
                        h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->d_ids, h->d_leg_force, h->d_centre_force,
-                       position_deriv, lds_rw);
+                       h->last_used_cells ? h->d_sorted_atom : nullptr, position_deriv, lds_rw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;

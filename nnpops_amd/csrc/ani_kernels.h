@@ -489,11 +489,17 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
                                                           const int* __restrict__ ids,
                                                           const float4* __restrict__ leg_force,
                                                           const float4* __restrict__ centre_force,
+                                                          const int* __restrict__ order,     // atoms in cell order, or NULL
                                                           float* __restrict__ pos_grad, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float* lds = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
-    const int i = wave_global_id(), lane = lane_id();
-    if (i >= P->N) return;
+    const int lane = lane_id();
+    // This kernel gathers rows of its atom's NEIGHBOURS (gradient rows, id rows, leg forces).  Atoms are walked in
+    // cell order, an XCD-contiguous stretch per XCD, so that those rows are fetched into one L2 instead of eight.
+    const int w = order ? xcd_contiguous_wave_id() : wave_global_id();
+    if (w >= P->N) return;
+    int i = order ? order[w] : w;
+    if ((unsigned)i >= (unsigned)P->N) i = w;              // (a void grid build leaves no valid order: stay in bounds)
     const int S = P->S, nR = P->nR, width = S * nR;
     float* g_own = lds;                       // [S*nR] this atom's gradient row
     float* nb_r = g_own + width;              // [cap]

@@ -71,6 +71,18 @@ __device__ __forceinline__ void wave_fence() {
 __device__ __forceinline__ int wave_in_group() { return threadIdx.x >> 6; }
 __device__ __forceinline__ int wave_global_id() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
 
+// XCD-aware work order.  MI355X deals workgroups round-robin to its 8 XCDs (workgroup g runs on XCD g % 8), each
+// with a private L2.  When neighbouring work items share data (atoms adjacent in cell order gather the same rows),
+// give every XCD a CONTIGUOUS eighth of the ordered work instead of every eighth item: otherwise all eight L2s end
+// up fetching everything.  Returns the position of this wave in the ordered sequence (a bijection on
+// [0, gridDim.x * waves_per_group)).
+__device__ __forceinline__ int xcd_contiguous_wave_id() {
+    const int g = blockIdx.x, nwg = gridDim.x, xcd = g & 7;
+    int start = 0;
+    for (int c = 0; c < xcd; c++) start += (nwg - c + 7) >> 3;          // workgroups that land on the XCDs before mine
+    return (start + (g >> 3)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+}
+
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ int prefix_popc(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
