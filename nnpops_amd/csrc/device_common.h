@@ -1,8 +1,9 @@
 // device_common.h -- helpers shared by the gfx950 kernels of libnnpops_hip.so.
 //
 // Written for CDNA4 only: 64-lane wavefronts are assumed everywhere (no warp-32 idioms, no
-// portability macros).  Single-wave workgroups are used by the per-atom kernels, so
-// __syncthreads() there is a wave-local LDS fence.
+// portability macros).  The per-atom kernels run one atom per WAVE, 1-4 waves per workgroup, each
+// wave with a private LDS slice: waves never talk to each other, so there are no block barriers,
+// only wave_fence() below.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -58,11 +59,10 @@ __device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (NNPOPS_WAVE - 1); }
 
-// The per-atom kernels run one atom per WAVE and several waves per workgroup (each with its own LDS
-// slice): 10 000 single-wave workgroups cost ~6.5 us of pure dispatch per kernel on MI355X, four waves
-// per workgroup cut that by ~4x.  Waves of a group never talk to each other, so there are no block
-// barriers -- only this wave-local fence between LDS producer and consumer phases (LDS operations of one
-// wave execute in order; the fence stops the compiler from reordering them).
+// The wave-local fence between LDS producer and consumer phases of one wave (LDS operations of a wave execute
+// in order; the fence stops the compiler from reordering them).  kWavesPerGroup is the LARGEST workgroup the
+// per-atom kernels are launched with; the host picks 1, 2 or 4 waves per group so that LDS-limited occupancy is
+// not lowered by the grouping (ani.hip: waves_per_group).
 constexpr int kWavesPerGroup = 4;
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
