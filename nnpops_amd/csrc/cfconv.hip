@@ -15,7 +15,7 @@
 //     deterministic.  Every pair is therefore evaluated from both ends; the filter network is the
 //     same function of r on either side, so this doubles its flops in exchange for removing
 //     2W atomics per pair and all cross-wave traffic.
-//   * widths that are a multiple of 16 (16 ... 128: every SchNet in use) run the two dense layers on the
+//   * widths that are a multiple of 16 (16, 32, ... 128: every SchNet in use) run the two dense layers on the
 //     MATRIX CORES: 16 pairs of one atom x W filters per tile, v_mfma_f32_16x16x4_f32 (exact fp32),
 //     weights resident in LDS, 8 waves per CU (cfconv_forward_mfma / cfconv_backward_mfma below).
 //   * other widths use the vector kernel: one wave per atom, lane = filter channel(s) (up to two per
@@ -37,8 +37,8 @@ namespace {
 
 constexpr int kPairTile = 8;
 constexpr int kMaxWavesPerBlock = 8;
-constexpr int kMaxWidth = 128;
-constexpr int kMaxGauss = 128;
+constexpr int kMaxWidth = 512;      // <= 128: weights resident in LDS (matrix-core or vector kernels); above: streamed
+constexpr int kMaxGauss = 256;
 enum { kStOverflow = 0, kStMaxRow = 1, kStPairs = 2, kStWordsN = 4 };
 
 // ---------------------------------------------------------------------------------------------
@@ -192,7 +192,9 @@ __host__ __device__ inline size_t conv_wave_floats(int W, int G, bool backward) 
 }
 
 // CPL = channels per lane (1: W <= 64, 2: W <= 128).  BACKWARD adds the d/dr path and the two gradients.
-template <int ACT, int CPL, bool BACKWARD>
+// WLDS = false: the weights do not fit in LDS next to one wave's tiles (W > 128): they are read through the
+// caches instead.  Same arithmetic, a functional path for unusually wide layers, not a tuned one.
+template <int ACT, int CPL, bool BACKWARD, bool WLDS = true>
 __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_kernel(
     ConvParams P, const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
     const float* __restrict__ b2, const float4* __restrict__ rows, const int* __restrict__ cnt, int cap,
@@ -202,19 +204,21 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int W = P.W, G = P.G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* s_w2t = lds;                                   // [W][W]   s_w2t[b*W + a] = w2[a][b]
-    float* s_w1t = s_w2t + (size_t)W * W;                 // [G][W]   s_w1t[g*W + a] = w1[a][g]
+    const float* s_w2t = WLDS ? lds : w2t;                // [W][W]   s_w2t[b*W + a] = w2[a][b]
+    const float* s_w1t = WLDS ? lds + (size_t)W * W : w1t;   // [G][W]   s_w1t[g*W + a] = w1[a][g]
     const int waves_per_block = blockDim.x >> 6;
-    float* wv = lds + conv_weight_floats(W, G) + (size_t)wave * conv_wave_floats(W, G, BACKWARD);
+    float* wv = lds + (WLDS ? conv_weight_floats(W, G) : 0) + (size_t)wave * conv_wave_floats(W, G, BACKWARD);
     float* ps = wv;                                       // [8][8] per-pair scalars: r, fc, dfc, j, 1/r, dx, dy, dz
     float* gam = ps + 64;                                 // [G][8]
     float* y1b = gam + (size_t)G * kPairTile;             // [W][8]
     float* dgam = y1b + (size_t)W * kPairTile;            // [G][8]  (backward only)
     float* dy1b = dgam + (size_t)G * kPairTile;           // [W][8]  (backward only)
 
-    for (int q = tid; q < W * W; q += blockDim.x) s_w2t[q] = w2t[q];
-    for (int q = tid; q < G * W; q += blockDim.x) s_w1t[q] = w1t[q];
-    __syncthreads();
+    if (WLDS) {
+        for (int q = tid; q < W * W; q += blockDim.x) lds[q] = w2t[q];
+        for (int q = tid; q < G * W; q += blockDim.x) lds[(size_t)W * W + q] = w1t[q];
+        __syncthreads();
+    }
 
     int ch[CPL];
     bool live[CPL];
@@ -1004,16 +1008,16 @@ int nnpops_cfconv_set_stream(nnpops_cfconv_t h, void* stream) {
 
 namespace {
 
-template <int ACT, int CPL, bool BWD>
+template <int ACT, int CPL, bool BWD, bool WLDS = true>
 int launch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out, float* pos_grad) {
     // as many waves per workgroup as fit next to the shared weights in 160 KiB of LDS
     const size_t budget = 156 * 1024 / sizeof(float);
-    const size_t wfl = conv_weight_floats(h->p.W, h->p.G), per_wave = conv_wave_floats(h->p.W, h->p.G, BWD);
+    const size_t wfl = WLDS ? conv_weight_floats(h->p.W, h->p.G) : 0, per_wave = conv_wave_floats(h->p.W, h->p.G, BWD);
     if (wfl + per_wave > budget)
-        return fail(NNPOPS_ERR_UNSUPPORTED, "CFConv weights (%zu floats) do not fit in LDS", wfl);
+        return fail(NNPOPS_ERR_UNSUPPORTED, "CFConv tiles (%zu floats) do not fit in LDS", wfl + per_wave);
     const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
     const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
-    auto k = cfconv_kernel<ACT, CPL, BWD>;
+    auto k = cfconv_kernel<ACT, CPL, BWD, WLDS>;
     if (lds > 64 * 1024)
         NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int blocks = std::max(1, std::min(h->blocks, div_up(h->p.N, wpb)));
@@ -1063,8 +1067,11 @@ int dispatch_backward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const 
     switch (h->p.W) {
         case 16:  return launch_backward_mfma<ACT, 1>(h, nb, x, gout, xgrad, pos_grad);
         case 32:  return launch_backward_mfma<ACT, 2>(h, nb, x, gout, xgrad, pos_grad);
+        case 48:  return launch_backward_mfma<ACT, 3>(h, nb, x, gout, xgrad, pos_grad);
         case 64:  return launch_backward_mfma<ACT, 4>(h, nb, x, gout, xgrad, pos_grad);
+        case 80:  return launch_backward_mfma<ACT, 5>(h, nb, x, gout, xgrad, pos_grad);
         case 96:  return launch_backward_mfma<ACT, 6>(h, nb, x, gout, xgrad, pos_grad);
+        case 112: return launch_backward_mfma<ACT, 7>(h, nb, x, gout, xgrad, pos_grad);
         case 128: return launch_backward_mfma<ACT, 8>(h, nb, x, gout, xgrad, pos_grad);
         default: handled = false; return NNPOPS_OK;
     }
@@ -1077,8 +1084,11 @@ int dispatch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const f
     switch (h->p.W) {
         case 16:  return launch_forward_mfma<ACT, 1>(h, nb, x, out);
         case 32:  return launch_forward_mfma<ACT, 2>(h, nb, x, out);
+        case 48:  return launch_forward_mfma<ACT, 3>(h, nb, x, out);
         case 64:  return launch_forward_mfma<ACT, 4>(h, nb, x, out);
+        case 80:  return launch_forward_mfma<ACT, 5>(h, nb, x, out);
         case 96:  return launch_forward_mfma<ACT, 6>(h, nb, x, out);
+        case 112: return launch_forward_mfma<ACT, 7>(h, nb, x, out);
         case 128: return launch_forward_mfma<ACT, 8>(h, nb, x, out);
         default: handled = false; return NNPOPS_OK;
     }
@@ -1098,10 +1108,24 @@ int dispatch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x,
                                             : dispatch_backward_mfma<1>(h, nb, x, gout, out, pos_grad, handled);
         if (handled) return rc;
     }
-    const bool two = h->p.W > 64;
-    if (h->p.activation == 0)
-        return two ? launch_conv<0, 2, BWD>(h, nb, x, gout, out, pos_grad) : launch_conv<0, 1, BWD>(h, nb, x, gout, out, pos_grad);
-    return two ? launch_conv<1, 2, BWD>(h, nb, x, gout, out, pos_grad) : launch_conv<1, 1, BWD>(h, nb, x, gout, out, pos_grad);
+    // vector kernels: weights in LDS when they fit beside one wave's tiles, else streamed through the caches
+    const size_t budget = 156 * 1024 / sizeof(float);
+    const bool fits = conv_weight_floats(h->p.W, h->p.G) + conv_wave_floats(h->p.W, h->p.G, BWD) <= budget && h->p.W <= 128;
+    if (fits) {
+        const bool two = h->p.W > 64;
+        if (h->p.activation == 0)
+            return two ? launch_conv<0, 2, BWD>(h, nb, x, gout, out, pos_grad) : launch_conv<0, 1, BWD>(h, nb, x, gout, out, pos_grad);
+        return two ? launch_conv<1, 2, BWD>(h, nb, x, gout, out, pos_grad) : launch_conv<1, 1, BWD>(h, nb, x, gout, out, pos_grad);
+    }
+    const int cpl = div_up(h->p.W, 64);
+    if (h->p.activation == 0) {
+        if (cpl <= 2) return launch_conv<0, 2, BWD, false>(h, nb, x, gout, out, pos_grad);
+        if (cpl <= 4) return launch_conv<0, 4, BWD, false>(h, nb, x, gout, out, pos_grad);
+        return launch_conv<0, 8, BWD, false>(h, nb, x, gout, out, pos_grad);
+    }
+    if (cpl <= 2) return launch_conv<1, 2, BWD, false>(h, nb, x, gout, out, pos_grad);
+    if (cpl <= 4) return launch_conv<1, 4, BWD, false>(h, nb, x, gout, out, pos_grad);
+    return launch_conv<1, 8, BWD, false>(h, nb, x, gout, out, pos_grad);
 }
 
 int check_pair(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb) {

@@ -69,7 +69,7 @@ def test_water18_golden(golden_dir, tag):
     np.testing.assert_allclose(y, g[f"{tag}_output"], rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("W,G", [(128, 50), (96, 50), (64, 25), (32, 16), (16, 7), (100, 50), (5, 3)])
+@pytest.mark.parametrize("W,G", [(128, 50), (112, 40), (96, 50), (80, 33), (64, 25), (48, 20), (32, 16), (16, 7), (100, 50), (5, 3)])
 @pytest.mark.parametrize("act", ["ssp", "tanh"])
 def test_random_cluster(W, G, act):
     pos, _ = workloads.conformer(120, seed=W + G)
@@ -83,6 +83,14 @@ def test_vector_kernels_at_matrix_widths(monkeypatch):
     pos, _ = workloads.conformer(90, seed=77)
     _case(pos, None, 128, 50, 5.0, 0.1, "ssp", seed=5)
     _case(pos, None, 64, 25, 5.0, 0.1, "tanh", seed=6)
+
+
+@pytest.mark.parametrize("W,G,act", [(192, 70, "ssp"), (256, 130, "tanh"), (130, 20, "ssp")])
+def test_wide_layers_stream_their_weights(W, G, act):
+    """Beyond W = 128 the weights no longer fit in LDS next to a wave's tiles: the vector kernel then reads them through
+    the caches (a functional path -- the reference accepts any width, so does the drop-in)."""
+    pos, _ = workloads.conformer(70, seed=W)
+    _case(pos, None, W, G, 4.5, 0.2, act, seed=W + 1)
 
 
 def test_periodic_box_cells():

@@ -80,7 +80,7 @@ def test_ani_random_configuration(seed):
 def test_cfconv_random_configuration(seed):
     from nnpops_amd.capi import CFConv, CFConvNeighbors
     rng = np.random.default_rng(2000 + seed)
-    W = int(rng.choice([1, 3, 8, 16, 24, 32, 48, 64, 80, 96, 100, 128]))
+    W = int(rng.choice([1, 3, 8, 16, 24, 32, 48, 64, 80, 96, 100, 112, 128, 160, 256]))
     G = int(rng.integers(2, 65))
     act = ["ssp", "tanh"][seed % 2]
     cutoff = float(rng.uniform(2.5, 6.0))
