@@ -141,3 +141,65 @@ def test_headline_workload_against_the_oracle_at_full_size():
     scale = float(np.abs(r_ref.astype(np.float64) * wr).sum() + np.abs(a_ref.astype(np.float64) * wa).sum())
     assert abs(e - e_ref) <= 1e-5 * scale
     assert np.abs(g - g_ref).max() <= 1e-4 * np.abs(g_ref).max()
+
+
+def test_ani_one_million_atoms_sampled_against_local_clusters():
+    """1 000 000 atoms in one periodic box (10 GB of neighbour data: the layout is N x capacity, nothing is N^2).  Checked
+    (i) by cutting the Rcr-neighbourhood of sampled atoms out of the box -- minimum-image shifts applied -- and running
+    the oracle on that small vacuum cluster: the central atom's AEV row must equal the row of the big system (an atom's
+    AEV depends on nothing else); (ii) net force zero, everything finite."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    from oracle import AniOracle
+    n = 1_000_000
+    pos, species, box = workloads.random_box(n, density=0.1, seed=77)
+    rf, af = workloads.ani2x_functions()
+    dev = torch.device("cuda:0")
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+    radial, angular = sym.compute(torch.tensor(pos, device=dev), torch.tensor(box, device=dev))
+    gen = torch.Generator(device=dev).manual_seed(5)
+    g_r = torch.randn(radial.shape, device=dev, generator=gen)
+    g_a = torch.randn(angular.shape, device=dev, generator=gen)
+    grad = sym.backprop(g_r, g_a)
+    assert bool(torch.isfinite(radial).all()) and bool(torch.isfinite(angular).all()) and bool(torch.isfinite(grad).all())
+    fmax = float(grad.abs().max())
+    assert float(grad.double().sum(0).abs().max()) <= 1e-2 * fmax          # 1e6 fp32 terms
+    L = float(box[0, 0])
+    rng = np.random.default_rng(3)
+    sample = rng.choice(n, 24, replace=False)
+    rows_r = radial[torch.tensor(sample, device=dev)].cpu().numpy()
+    rows_a = angular[torch.tensor(sample, device=dev)].cpu().numpy()
+    for k, i in enumerate(sample):
+        d = pos - pos[i]
+        d -= np.round(d / np.float32(L)) * np.float32(L)
+        near = np.nonzero((d * d).sum(1) < np.float32(5.1 * 5.1 * 1.02))[0]
+        near = np.concatenate([[i], near[near != i]])
+        cluster = (pos[i] + d[near]).astype(np.float32)                       # the neighbourhood, unwrapped around atom i
+        oracle = AniOracle(7, 5.1, 3.5, species[near], rf, af, periodic=False)
+        r_ref, a_ref = oracle.forward(cluster, None)
+        np.testing.assert_allclose(rows_r[k], r_ref[0], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(rows_a[k], a_ref[0], rtol=2e-5, atol=2e-6)
+
+
+def test_neighbor_pairs_one_million_atoms():
+    """getNeighborPairs at 1 000 000 atoms (29.5 M pairs, 0.7 GB of output): count, ordering, distances and 100 rows
+    brute-forced with numpy.  The reference stops at ~65 000 atoms (int32 pair index)."""
+    from nnpops_amd.capi import neighbor_pairs_forward
+    n, cutoff, max_pairs = 1_000_000, 5.2, 32_000_000
+    pos, _, box = workloads.random_box(n, density=0.1, seed=78)
+    dev = torch.device("cuda:0")
+    nb, dl, ds, num = neighbor_pairs_forward(torch.tensor(pos, device=dev), cutoff, max_pairs, torch.tensor(box, device=dev))
+    num = int(num.item())
+    assert 28_000_000 < num < max_pairs
+    rows, cols = nb[0, :num], nb[1, :num]
+    assert bool((rows > cols).all()) and bool((rows[1:] >= rows[:-1]).all()) and bool((nb[0, num:] == -1).all())
+    assert bool(torch.isnan(ds[num:]).all()) and float(ds[:num].max()) <= cutoff
+    torch.testing.assert_close(dl[:num].double().pow(2).sum(1).sqrt().float(), ds[:num], rtol=1e-6, atol=0)
+    starts = torch.searchsorted(rows.contiguous(), torch.arange(n + 1, device=dev, dtype=rows.dtype)).cpu().numpy()
+    cols_h = cols.cpu().numpy()
+    L = np.float32(box[0, 0])
+    rng = np.random.default_rng(4)
+    for row in rng.choice(n, 100, replace=False):
+        d = pos[row] - pos[:row]
+        d -= np.round(d / L) * L
+        want = np.nonzero(np.sqrt((d * d).sum(1)) <= np.float32(cutoff))[0]
+        assert np.array_equal(want, np.sort(cols_h[starts[row]:starts[row + 1]])), row
