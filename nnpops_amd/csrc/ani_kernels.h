@@ -230,7 +230,7 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     auto emit = [&](const float4& r4, int rank) {
         const float r = sqrtf(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);
         float sn, cs;
-        sincospif(r / rca, &sn, &cs);                      // fc = (cos(pi r/Rc)+1)/2, ref :381-387
+        sincospi_unit(r / rca, sn, cs);                    // fc = (cos(pi r/Rc)+1)/2, ref :381-387
         recA[rank] = make_float4(r4.x, r4.y, r4.z, r);
         recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi / rca) * sn, 1.0f / r, r4.w);
         ids[rank] = __float_as_int(r4.w) & kIdMask;        // compact copy for the backward gather's reverse lookup
@@ -312,7 +312,9 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
         const float4 rec = e < na ? stage[e] : stage[cap - 1 - (e - na)];
         const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         nb_r[e] = r;
-        nb_fc[e] = 0.5f * cospif(r / rcr) + 0.5f;
+        float sn_unused, cs;
+        sincospi_unit(r / rcr, sn_unused, cs);
+        nb_fc[e] = 0.5f * cs + 0.5f;
         nb_sp[e] = __float_as_int(rec.w) >> kTagShift;
     }
     wave_fence();
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
         const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         const float rinv = 1.0f / r;
         float sn, cs;
-        sincospif(r / rcr, &sn, &cs);
+        sincospi_unit(r / rcr, sn, cs);
         nb_r[e] = r;
         nb_fc[e] = 0.5f * cs + 0.5f;
         nb_dfc[e] = -(0.5f * kPi / rcr) * sn;

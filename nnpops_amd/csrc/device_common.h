@@ -103,6 +103,24 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// sin(pi x) and cos(pi x) for x in [0, 1] -- the argument of the cosine cutoff, r / Rc.  With y = x - 1/2:
+// cos(pi x) = -sin(pi y), sin(pi x) = cos(pi y), |y| <= 1/2, each a short polynomial in y^2 (least-squares fit
+// on Chebyshev nodes, |error| <= 2e-7 absolute in fp32 Horner form -- the reference's own cosf(r * pi / Rc) is no
+// closer to the exact value, its argument being rounded twice).  ~20 instructions for the pair; the library's
+// sincospif is ~80, and the per-neighbour stages run it for every neighbour of every atom.
+__device__ __forceinline__ void sincospi_unit(float x, float& s, float& c) {
+    const float y = x - 0.5f, u = y * y;
+    float ps = -0.00702838646247983f, pc = 0.0018400056287646294f;
+    ps = fmaf(ps, u, 0.08205040544271469f);   pc = fmaf(pc, u, -0.025776328518986702f);
+    ps = fmaf(ps, u, -0.5992522239685059f);   pc = fmaf(pc, u, 0.23532544076442719f);
+    ps = fmaf(ps, u, 2.5501632690429688f);    pc = fmaf(pc, u, -1.3352622985839844f);
+    ps = fmaf(ps, u, -5.167712688446045f);    pc = fmaf(pc, u, 4.058712005615234f);
+    ps = fmaf(ps, u, 3.1415927410125732f);    pc = fmaf(pc, u, -4.934802055358887f);
+    pc = fmaf(pc, u, 1.0f);
+    c = -ps * y;                               // cos(pi x) = -sin(pi y)
+    s = pc;                                    // sin(pi x) =  cos(pi y)
+}
+
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kPi = 3.14159265358979323846f;
 
