@@ -225,14 +225,14 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
                                                  int* __restrict__ ids, int capA, int* __restrict__ tri, const AtomGroups& G) {
     const int lane = lane_id();
     const int S = P->S, NB = P->NB;
-    const float rca = P->rca;
+    const float inv_rca = 1.0f / P->rca;
     for (int bk = lane; bk < NB; bk += 64) { G.ba[bk] = P->bkt_a[bk]; G.bb[bk] = P->bkt_b[bk]; }
     auto emit = [&](const float4& r4, int rank) {
-        const float r = sqrtf(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);
+        const float r = fast_sqrt(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);       // ~1 ulp, like everything downstream
         float sn, cs;
-        sincospi_unit(r / rca, sn, cs);                    // fc = (cos(pi r/Rc)+1)/2, ref :381-387
+        sincospi_unit(r * inv_rca, sn, cs);                // fc = (cos(pi r/Rc)+1)/2, ref :381-387
         recA[rank] = make_float4(r4.x, r4.y, r4.z, r);
-        recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi / rca) * sn, 1.0f / r, r4.w);
+        recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi * inv_rca) * sn, fast_rcp(r), r4.w);
         ids[rank] = __float_as_int(r4.w) & kIdMask;        // compact copy for the backward gather's reverse lookup
     };
     if (n <= 64) {
@@ -307,13 +307,13 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
     float* nb_fc = nb_r + cap;               // [cap]
     int* nb_sp = (int*)(nb_fc + cap);        // [cap]
     const int total = na + nro;
-    const float rcr = P->rcr;
+    const float inv_rcr = 1.0f / P->rcr;
     for (int e = lane; e < total; e += 64) {
         const float4 rec = e < na ? stage[e] : stage[cap - 1 - (e - na)];
-        const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+        const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         nb_r[e] = r;
         float sn_unused, cs;
-        sincospi_unit(r / rcr, sn_unused, cs);
+        sincospi_unit(r * inv_rcr, sn_unused, cs);
         nb_fc[e] = 0.5f * cs + 0.5f;
         nb_sp[e] = __float_as_int(rec.w) >> kTagShift;
     }
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     clamp_counts(cnt_a[i], cnt_ro[i], cap, cap_angular, na, nro);
     const int total = na + nro;
     const float4* row = nbr + (size_t)i * cap;
-    const float rcr = P->rcr;
+    const float inv_rcr = 1.0f / P->rcr;
     const int si = species[i];
 
     const float* gi = radial_grad + (size_t)i * width;
@@ -525,13 +525,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     for (int e = lane; e < total; e += 64) {
         const float4 rec = e < na ? row[e] : row[cap - 1 - (e - na)];
         const int word = __float_as_int(rec.w);
-        const float r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
-        const float rinv = 1.0f / r;
+        const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+        const float rinv = fast_rcp(r);
         float sn, cs;
-        sincospi_unit(r / rcr, sn, cs);
+        sincospi_unit(r * inv_rcr, sn, cs);
         nb_r[e] = r;
         nb_fc[e] = 0.5f * cs + 0.5f;
-        nb_dfc[e] = -(0.5f * kPi / rcr) * sn;
+        nb_dfc[e] = -(0.5f * kPi * inv_rcr) * sn;
         nb_ux[e] = rec.x * rinv; nb_uy[e] = rec.y * rinv; nb_uz[e] = rec.z * rinv;
         nb_sp[e] = word >> kTagShift;
         nb_j[e] = word & kIdMask;
