@@ -61,6 +61,7 @@ struct AniParams {
     int c_of_m[kMaxAngularFns];      // function m -> slot a*NFZP+z inside a padded canonical bucket block
     int bkt_a[kMaxBuckets];          // bucket b -> its species pair (A <= B), upper-triangular row-major
     int bkt_b[kMaxBuckets];          //                                                          ref :39-43
+    int* bucket_offsets;             // [N][NB + 1] device array the builders fill: offsets of the buckets in an atom's triple list
 };
 
 // status words reported by nnpops_ani_check
@@ -222,7 +223,8 @@ __device__ __forceinline__ void flush_row(float4* __restrict__ row, const float4
 // and the bucket-major triple list.  Runs once per atom per evaluation; forward and backward reuse it.
 __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P, const float4* stage, int n,
                                                  float4* __restrict__ recA, float4* __restrict__ recB,
-                                                 int* __restrict__ ids, int capA, int* __restrict__ tri, const AtomGroups& G) {
+                                                 int* __restrict__ ids, int capA, int* __restrict__ tri,
+                                                 int* __restrict__ boff_out, const AtomGroups& G) {
     const int lane = lane_id();
     const int S = P->S, NB = P->NB;
     const float inv_rca = 1.0f / P->rca;
@@ -280,6 +282,7 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     }
     for (int e = n + lane; e < capA; e += 64) ids[e] = -1;    // the gather scans whole rows: no stale ids behind the list
     const int T = build_bucket_offsets(NB, G);
+    for (int bk = lane; bk <= NB; bk += 64) boff_out[bk] = G.boff[bk];       // for the forward kernel's chunked view
     int steps = 0;
     while ((1 << steps) < NB) steps++;
     for (int t = lane; t < T; t += 64) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     flush_row(row, stage, cap, na, nro);
     radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
-                     tri + (size_t)i * triples_capacity(capA), G);
+                     tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G);
 }
 
 // Cell-grid search (celllist.h): one wave per atom walks the 3x3x3 stencil of its cell; candidates
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     if (!(dbg & 64)) radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
     if (dbg & 128) return;
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
-                     tri + (size_t)i * triples_capacity(capA), G);
+                     tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G);
 }
 
 // =============================================================================================
@@ -895,6 +898,196 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
             const bool tail_ends_here = has_tail && next_head != tb;
             row_add<NFZP>(row + (head_ends_here ? hb : NB) * BLK + a2 * NFZP, total);
             row_add<NFZP>(row + (tail_ends_here ? tb : NB) * BLK + a2 * NFZP, acc);
+        }
+        wave_fence();
+    }
+
+    // ---------------- epilogue: canonical LDS row -> reference column order, coalesced rows ----------------
+    float* out = angular + (size_t)i * NB * nA;
+    if (dbg & 4) return;
+    if (nA <= 32) {                                        // two buckets per pass
+        const int m = lane & 31, half = lane >> 5;
+        const bool live = m < nA;
+        const int c = live ? P->c_of_m[m] : 0;             // canonical slot a*NFZP+z of function m
+        const float sc = live ? P->scale_m[m] : 0.f;
+        for (int bk0 = half; bk0 < NB; bk0 += 16) {        // 8 LDS reads in flight, then 8 coalesced stores
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int bk = bk0 + 2 * k;
+                v[k] = (live && bk < NB) ? row[bk * BLK + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int bk = bk0 + 2 * k;
+                if (live && bk < NB) out[bk * nA + m] = v[k] * sc;
+            }
+        }
+    } else {
+        for (int bk = 0; bk < NB; bk++)
+            for (int m = lane; m < nA; m += 64) out[bk * nA + m] = row[bk * BLK + P->c_of_m[m]] * P->scale_m[m];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Angular forward, chunked view (the default when NB <= 64).
+//
+// Same phase 1 as above, but the triples are visited through a PADDED view of the builder's list: every bucket is
+// rounded up to whole chunks of CH = NFRP triples (the builder publishes the bucket offsets; padding slots produce
+// zero factors).  A stream's chunk then belongs to ONE bucket, and phase 2 collapses to: accumulate the chunk
+// (32 FMAs per lane), add up adjacent streams that hold the same bucket (a 3-step segmented scan over the streams,
+// shuffles only), one read-modify-write of the LDS row by the last stream of each bucket.  No run detection, no
+// head/tail bookkeeping, no dummy stores.  Costs ~40 % more phase-1 slots for a many-species system (5.5 triples
+// per bucket padded to 8) and nothing for water; phase 2 drops from ~270 to ~75 vector instructions per batch.
+// ---------------------------------------------------------------------------------------------
+template <int NFRP, int NFZP>
+__host__ __device__ inline size_t ang_fwd_chunked_lds_bytes(int capA, int NB) {
+    using L = FwdLayout<NFRP, NFZP>;
+    const int max_chunks = (capA * (capA - 1) / 2) / L::CH + NB + 1;
+    size_t b = (size_t)capA * 2 * sizeof(float4);
+    b += (size_t)NB * L::BLK * sizeof(float);
+    b += (size_t)L::NSTREAM * L::SR * sizeof(float) + (size_t)64 * NFZP * sizeof(float);
+    b += (size_t)(2 * (NB + 1) + max_chunks + 3) / 4 * 4 * sizeof(int);        // bucket offsets, chunk starts, chunk -> bucket
+    return b;
+}
+
+template <bool TORCHANI, int NFRP, int NFZP>
+__global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunked(
+    const AniParams* __restrict__ P, int cap, int capA, const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
+    const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro, float* __restrict__ angular,
+    int dbg, int lds_per_wave) {
+    using L = FwdLayout<NFRP, NFZP>;
+    constexpr int CH = L::CH, NSTREAM = L::NSTREAM, SR = L::SR, BLK = L::BLK;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int i = wave_global_id(), lane = lane_id();
+    const int NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
+    if (i >= P->N || (dbg & 32)) return;
+
+    char* cursor = lds_raw + (size_t)wave_in_group() * lds_per_wave;
+    float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float* row = (float*)cursor;          cursor += (size_t)NB * BLK * sizeof(float);
+    float* facR = (float*)cursor;         cursor += (size_t)NSTREAM * SR * sizeof(float);
+    float* facZ = (float*)cursor;         cursor += (size_t)64 * NFZP * sizeof(float);
+    int* boff = (int*)cursor;             // [NB + 1] first triple of bucket b in the builder's list
+    int* cstart = boff + NB + 1;          // [NB + 1] first chunk of bucket b in the padded view
+    int* cbkt = cstart + NB + 1;          // [chunks] bucket of chunk c
+
+    int n, nro;
+    clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+    const int* tri = tri_g + (size_t)i * triples_capacity(capA);
+    // bucket offsets -> chunks per bucket -> chunk starts (wave scan; NB <= 64)
+    const int* boff_g = P->bucket_offsets + (size_t)i * (NB + 1);
+    const int my_lo = lane <= NB ? boff_g[lane] : 0;
+    const int my_hi = lane < NB ? boff_g[lane + 1] : my_lo;
+    load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
+    const int rowlen = NB * BLK;
+    for (int q = lane; q < rowlen; q += 64) row[q] = 0.f;
+    const int my_chunks = n >= 2 ? (my_hi - my_lo + CH - 1) / CH : 0;
+    int incl = my_chunks;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const int my_first = incl - my_chunks;
+    if (lane <= NB) { boff[lane] = my_lo; cstart[lane] = my_first; }
+    for (int c = 0; c < my_chunks; c++) cbkt[my_first + c] = lane;        // (lanes >= NB have no chunks)
+    const int chunks = __shfl(incl, 63, 64);
+    if (dbg & 16) return;
+
+    float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP];
+#pragma unroll
+    for (int a = 0; a < NFRP; a++) { frc[a] = a < nFR ? P->fr_c[a] : 0.f; frs[a] = a < nFR ? P->fr_rs[a] : 0.f; }
+#pragma unroll
+    for (int z = 0; z < NFZP; z++) {
+        zz[z] = z < nFZ ? P->fz_zeta[z] : 1.f;
+        zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
+        zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
+    }
+    wave_fence();
+
+    const int a2 = lane & (NFRP - 1), stream = lane / NFRP;
+    // triple of (chunk, slot) in the builder's list, or -1 for padding
+    auto triple_of = [&](int chunk, int u) {
+        if (chunk >= chunks) return -1;
+        const int b = cbkt[chunk];
+        const int t = boff[b] + (chunk - cstart[b]) * CH + u;
+        return t < boff[b + 1] ? t : -1;
+    };
+    int t_mine = triple_of(lane / CH, lane % CH);
+    int word = t_mine >= 0 ? tri[t_mine] : 0;
+    for (int cb = 0; cb < chunks; cb += NSTREAM) {
+        // ---------------- phase 1: lane = (chunk, slot) ----------------
+        const int t_next = triple_of(cb + NSTREAM + lane / CH, lane % CH);
+        const int next_word = t_next >= 0 ? tri[t_next] : 0;              // next batch in flight
+        float* dstR = facR + (lane / CH) * SR + (lane % CH) * NFRP;
+        if (t_mine >= 0 && !(dbg & 1)) {
+            const int p = word & 0xff, q = (word >> 8) & 0xff;
+            const float4 A = recA[p], B = recA[q];
+            const float4 A2 = recB[p], B2 = recB[q];
+            const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
+#pragma unroll
+            for (int a = 0; a < NFRP; a += 4) {
+                float4 v;
+                float sh;
+                sh = g.rbar - frs[a];     v.x = fast_exp2(frc[a] * sh * sh);
+                sh = g.rbar - frs[a + 1]; v.y = fast_exp2(frc[a + 1] * sh * sh);
+                sh = g.rbar - frs[a + 2]; v.z = fast_exp2(frc[a + 2] * sh * sh);
+                sh = g.rbar - frs[a + 3]; v.w = fast_exp2(frc[a + 3] * sh * sh);
+                *reinterpret_cast<float4*>(dstR + a) = v;
+            }
+            float zv[NFZP];
+#pragma unroll
+            for (int z = 0; z < NFZP; z++) {
+                const float x = fmaxf(1.0f + (g.c * zc[z] + g.s * zs[z]), 1e-30f);   // 1 + cos(theta - ths)
+                zv[z] = g.fcfc * fast_exp2(zz[z] * fast_log2(x));
+            }
+#pragma unroll
+            for (int z = 0; z < NFZP; z += 4)
+                *reinterpret_cast<float4*>(facZ + lane * NFZP + z) = make_float4(zv[z], zv[z + 1], zv[z + 2], zv[z + 3]);
+        } else {                                                           // padding: contributes nothing
+#pragma unroll
+            for (int z = 0; z < NFZP; z += 4)
+                *reinterpret_cast<float4*>(facZ + lane * NFZP + z) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < NFRP; a += 4) *reinterpret_cast<float4*>(dstR + a) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        word = next_word;
+        t_mine = t_next;
+        wave_fence();
+        // ---------------- phase 2: lane = (stream, a), one bucket per stream ----------------
+        if (!(dbg & 2)) {
+            const int chunk = cb + stream;
+            const int bs = chunk < chunks ? cbkt[chunk] : -1;
+            const float* srcR = facR + stream * SR + a2;
+            float acc[NFZP];
+#pragma unroll
+            for (int z = 0; z < NFZP; z++) acc[z] = 0.f;
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const float R = srcR[u * NFRP];
+                const float* Z = facZ + (stream * CH + u) * NFZP;
+#pragma unroll
+                for (int z = 0; z < NFZP; z += 4) {
+                    const float4 z4 = *reinterpret_cast<const float4*>(Z + z);
+                    acc[z] += R * z4.x; acc[z + 1] += R * z4.y; acc[z + 2] += R * z4.z; acc[z + 3] += R * z4.w;
+                }
+            }
+            // streams holding the same bucket are adjacent: segmented inclusive scan over the streams
+#pragma unroll
+            for (int off = NFRP; off < 64; off <<= 1) {
+                const int ub = __shfl_up(bs, off, 64);
+                const bool take = lane >= off && ub == bs;
+#pragma unroll
+                for (int z = 0; z < NFZP; z++) {
+                    const float up = __shfl_up(acc[z], off, 64);
+                    acc[z] += take ? up : 0.f;
+                }
+            }
+            const int nb_next = __shfl_down(bs, NFRP, 64);
+            const bool closes = bs >= 0 && (stream == NSTREAM - 1 || nb_next != bs);   // last stream of its bucket in this batch
+            if (closes) row_add<NFZP>(row + bs * BLK + a2 * NFZP, acc);
         }
         wave_fence();
     }

@@ -196,6 +196,23 @@ def test_denser_frame_after_the_last_check_is_still_exact():
     assert np.abs(grad.cpu().numpy() - g_ref).max() <= FORCE_RTOL * np.abs(g_ref).max()
 
 
+@pytest.mark.parametrize("kernel", ["0", "1"])
+@pytest.mark.parametrize("kind", ["water", "seven_species", "dense"])
+def test_both_angular_forward_kernels(monkeypatch, kernel, kind):
+    """The handle picks one of two angular forward kernels from the species composition (chunked view of the triple
+    list for few well-filled species pairs, run merging for many equally likely species); $NNPOPS_ANI_FORWARD forces
+    either, and both must pass on every kind of system."""
+    monkeypatch.setenv("NNPOPS_ANI_FORWARD", kernel)
+    rf, af = workloads.ani2x_functions()
+    if kind == "water":
+        pos, species, box = workloads.water_box(350, seed=31)
+    elif kind == "seven_species":
+        pos, species, box = workloads.random_box(1100, seed=32)
+    else:
+        pos, species, box = workloads.random_box(900, density=0.2, seed=33)       # > 32 angular neighbours: records grow
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
+
+
 def test_single_atom_and_isolated_atoms():
     rf, af = workloads.ani2x_functions()
     pos = np.array([[0, 0, 0], [30, 0, 0], [0, 30, 0]], dtype=np.float32)
