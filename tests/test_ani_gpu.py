@@ -268,3 +268,37 @@ def test_batched_molecules_match_per_molecule_oracle():
         np.testing.assert_allclose(a[lo:hi], a_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
         g_ref = o.backward(np.ascontiguousarray(wr[lo:hi]), np.ascontiguousarray(wa[lo:hi]))
         assert np.abs(grad[lo:hi] - g_ref).max() <= FORCE_RTOL * np.abs(g_ref).max()
+
+
+def test_handles_release_their_device_memory():
+    """200 create / compute / backprop / (capacity growth) / destroy cycles of the ANI and CFConv handles leave the
+    device's free memory where it was (the handles own ~20 device buffers each, some reallocated by check())."""
+    import gc
+    from nnpops_amd.capi import AniSymmetryFunctions, CFConv, CFConvNeighbors
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1200, density=0.2, seed=41)          # dense: rows and records grow
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    w1 = np.zeros((32, 8), np.float32); w2 = np.zeros((32, 32), np.float32); b = np.zeros(32, np.float32)
+    x = torch.zeros((len(pos), 32), device=dev)
+
+    def cycle():
+        sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+        radial, angular = sym.compute(tpos, tbox)
+        sym.backprop(torch.ones_like(radial), torch.ones_like(angular))
+        nb = CFConvNeighbors(len(pos), 5.0, periodic=True)
+        nb.build(tpos, tbox, check=True)
+        cf = CFConv(len(pos), 32, 8, 5.0, 0.3, "ssp", w1, b, w2, b, periodic=True)
+        y = torch.empty_like(x)
+        cf.compute(nb, tpos, x, tbox, y)
+        del sym, nb, cf
+
+    for _ in range(3):
+        cycle()
+    gc.collect(); torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(200):
+        cycle()
+    gc.collect(); torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)          # allow allocator granularity, not 200 leaked handles
