@@ -144,13 +144,7 @@ def main():
     torch.cuda.synchronize()
     # what an event pair reports for an EMPTY bracket on this stream (marker processing, not kernel time): the
     # per-kernel figures below are net of it, which is what makes them agree with rocprofv3's kernel durations
-    empties = []
-    for _ in range(20):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()
-        torch.cuda.synchronize()
-        empties.append(e0.elapsed_time(e1) * 1e-3)
-    event_overhead = sorted(empties)[len(empties) // 2]                     # seconds
+    event_overhead = sym.timing_overhead()                                 # seconds
     sym.enable_timing(True, only=[dominant])
     t0 = time.perf_counter()
     for _ in range(args.steps):

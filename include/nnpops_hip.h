@@ -112,6 +112,9 @@ enum {
 };
 int nnpops_ani_enable_timing(nnpops_ani_t h, int enable);
 int nnpops_ani_get_timing(nnpops_ani_t h, double* total_ms, int* launches);
+/* What an event pair reports for an EMPTY bracket on the handle's stream (median of 21, milliseconds; blocks):
+ * subtract it from a per-launch average to compare with a profiler's kernel durations. */
+int nnpops_ani_timing_overhead(nnpops_ani_t h, double* ms);
 
 /* ------------------------------------------------------------------------------------------
  * SchNet continuous-filter convolution (replaces CFConvNeighbors / CFConv and their Cuda* subclasses)

@@ -38,6 +38,7 @@ SIGNATURES = {
     "nnpops_ani_set_molecules": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "nnpops_ani_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "nnpops_ani_timing_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
     "nnpops_cfconv_neighbors_destroy": (C.c_int, [C.c_void_p]),
     "nnpops_cfconv_neighbors_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -208,6 +209,12 @@ class AniSymmetryFunctions:
         cnt = (C.c_int * len(self.KERNELS))()
         _check(self._lib.nnpops_ani_get_timing(self._h, ms, cnt))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS)}
+
+    def timing_overhead(self):
+        """Seconds an event pair reports for an empty bracket on this handle's stream (blocks)."""
+        ms = C.c_double(0)
+        _check(self._lib.nnpops_ani_timing_overhead(self._h, C.byref(ms)))
+        return 1e-3 * ms.value
 
     def neighbor_stats(self):
         """(max neighbours within Rcr, max neighbours within Rca) of the last compute; blocks."""

@@ -73,8 +73,9 @@ struct KernelTimer {
         if (!(h->timing_mask >> id & 1)) return;
         if (h->ev_used[id] == h->ev_start[id].size()) {
             hipEvent_t a, b;
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
+            // timing-only events: no system-scope fence (and L2 write-back) when they complete
+            (void)hipEventCreateWithFlags(&a, hipEventDisableSystemFence);
+            (void)hipEventCreateWithFlags(&b, hipEventDisableSystemFence);
             h->ev_start[id].push_back(a);
             h->ev_stop[id].push_back(b);
         }
@@ -506,6 +507,28 @@ int nnpops_ani_enable_timing(nnpops_ani_t h, int enable) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
     h->timing_mask = enable == 1 ? ~0u : (unsigned)enable >> 1;      // 1: all kernels; else bit (id + 1) selects kernel id
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) h->ev_used[k] = 0;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_timing_overhead(nnpops_ani_t h, double* ms) {
+    NNPOPS_REQUIRE(h != nullptr && ms, "NULL argument");
+    DeviceGuard guard(h->device);
+    hipEvent_t a, b;
+    NNPOPS_HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableSystemFence));
+    NNPOPS_HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableSystemFence));
+    std::vector<float> samples;
+    for (int k = 0; k < 21; k++) {                          // an EMPTY bracket, same events, same stream
+        NNPOPS_HIP_TRY(hipEventRecord(a, h->stream));
+        NNPOPS_HIP_TRY(hipEventRecord(b, h->stream));
+        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+        float t = 0;
+        NNPOPS_HIP_TRY(hipEventElapsedTime(&t, a, b));
+        samples.push_back(t);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    std::sort(samples.begin(), samples.end());
+    *ms = samples[samples.size() / 2];
     return NNPOPS_OK;
 }
 
