@@ -7,27 +7,33 @@
 //   and the analytic position gradients of both                                                              (ref :196-353)
 //
 // How it is laid out for CDNA4 (a new design, not the reference's CUDA launch shapes):
-//   * one single-wave workgroup (64 lanes) per centre atom; everything an atom needs lives in that
-//     wave's LDS slice.
-//   * the NEIGHBOUR BUILD does all the geometry and all the integer bookkeeping, once per
-//     evaluation, and leaves behind streaming-friendly arrays; the forward and backward kernels
-//     that follow are pure load + arithmetic:
+//   * one WAVE (64 lanes) per centre atom, 1-4 waves per workgroup; everything an atom needs lives in that
+//     wave's LDS slice, waves never talk to each other (wave_fence() only).
+//   * the NEIGHBOUR BUILD does all the geometry and all the integer bookkeeping, once per evaluation -- and the
+//     radial AEV while the row is in LDS -- and leaves behind streaming-friendly arrays; the kernels that follow
+//     are pure load + arithmetic:
 //       rows  [N][cap]     16-byte records {dx, dy, dz, (species<<24)|atom} of every neighbour within
 //                          Rcr: angular ones (r < Rca) packed from the front, radial-only from the back;
 //       recA  [N][capA]    {dx, dy, dz, r}                    angular neighbours SORTED BY SPECIES
 //       recB  [N][capA]    {fc, dfc/dr, 1/r, (species<<24)|atom}
+//       ids   [N][capA]    atom ids in record order, -1 padded (reverse lookup of the backward gather)
 //       tri   [N][capT]    the atom's n(n-1)/2 neighbour pairs in bucket-major order, one word
 //                          p | q<<8 | bucket<<16 (bucket = species-pair block of the output row)
+//       bucket_offsets [N][NB+1]   first triple of every bucket (chunked forward kernel)
 //   * the angular functions factor as R_a(rbar) x Z_z(theta) (8 x 4 for ANI-2x): a triple costs
 //     nFR exp2 + nFZ (log2+exp2) instead of nA (powf+cosf+expf).
-//   * no LDS float atomics anywhere: ds_add_f32 costs ~3 cycles per active lane on gfx950
-//     (tools/ubench/lds_atomic.hip); every LDS accumulation below has exactly one owner.
+//   * no float atomics anywhere, LDS or global: ds_add_f32 costs ~3 cycles per active lane on gfx950
+//     (tools/ubench/lds_atomic.hip); every accumulation below has exactly one owner, results are bitwise
+//     reproducible.
 //   * forward, per batch of 64 triples: phase 1 lane = triple computes the 12 factors into LDS;
-//     phase 2 lane = (stream, a) contracts them into the atom's LDS output row.
-//   * backward: lane = triple; leg-atom forces go to an LDS pair matrix (one writer per entry), row
-//     sums give per-slot forces, then one global atomic per neighbour component.
-//   * radial backward is owner-computes (each atom walks its full row, reading both gradient
-//     rows), so it needs no atomics and also initialises position_deriv.
+//     phase 2 lane = (stream, a) contracts them into the atom's LDS output row.  Two kernels: run merging
+//     (many equally likely species) and a chunked view of the triple list (few well-filled species pairs).
+//   * backward: lane = triple; the force of a triple on its legs is alpha_p A + beta B / alpha_q B + beta A, the
+//     scalars go to an LDS pair matrix (one writer per entry), row sums give per-slot forces, which are PARKED
+//     in leg_force / centre_force ...
+//   * ... and gathered by the radial backward kernel, which is owner-computes (each atom walks its full row,
+//     reading both gradient rows, then looks itself up in its angular neighbours' id rows) and is the only
+//     writer of position_deriv.
 #pragma once
 
 #include "celllist.h"
