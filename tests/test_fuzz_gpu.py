@@ -6,6 +6,8 @@ vacuum / cubic / triclinic box, atom count and density -- and is checked to the 
 The point is the corners the fixed tests do not name: one species, a single angular function, nR not a power of two,
 padded factor counts (3 x 5, 7 x 3 ...), atoms with zero / one / many neighbours in the same system.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,6 +17,9 @@ from oracle import AniOracle, CFConvNeighborsOracle, CFConvOracle
 from oracle.neighbors_oracle import neighbor_pairs_oracle
 
 pytestmark = pytest.mark.gpu
+
+# more seeds for a soak run:  NNPOPS_FUZZ_SCALE=10 python -m pytest tests/test_fuzz_gpu.py -m gpu
+SCALE = max(1, int(os.environ.get("NNPOPS_FUZZ_SCALE", "1")))
 
 
 def _random_geometry(rng, n, kind, density):
@@ -34,7 +39,7 @@ def _random_geometry(rng, n, kind, density):
     return (pos + shift).astype(np.float32), box
 
 
-@pytest.mark.parametrize("seed", range(52))        # seeds >= 40: dense systems (row / record capacities grow, >32 angular neighbours)
+@pytest.mark.parametrize("seed", list(range(52)) + list(range(100, 100 + 52 * (SCALE - 1))))        # seeds 40..51 (and 1 in 4 of the soak seeds): dense systems (row / record capacities grow, >32 angular neighbours)
 def test_ani_random_configuration(seed):
     from nnpops_amd.capi import AniSymmetryFunctions
     rng = np.random.default_rng(1000 + seed)
@@ -51,7 +56,8 @@ def test_ani_random_configuration(seed):
     kind = ["vacuum", "cubic", "triclinic"][seed % 3]
     torchani = bool(rng.integers(0, 2))
     n = int(rng.integers(2, 60)) if kind == "vacuum" else int(rng.integers(150, 500))
-    density = float(rng.uniform(0.04, 0.11)) if seed < 40 else float(rng.uniform(0.16, 0.24))
+    dense = 40 <= seed < 52 or (seed >= 100 and seed % 4 == 0)
+    density = float(rng.uniform(0.16, 0.24)) if dense else float(rng.uniform(0.04, 0.11))
     pos, box = _random_geometry(rng, n, kind, density)
     n = len(pos)
     species = rng.integers(0, S, size=n).astype(np.int32)
@@ -76,7 +82,7 @@ def test_ani_random_configuration(seed):
     assert np.abs(g - g_ref).max() <= 1e-4 * max(fmax, 1e-6)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_cfconv_random_configuration(seed):
     from nnpops_amd.capi import CFConv, CFConvNeighbors
     rng = np.random.default_rng(2000 + seed)
@@ -119,7 +125,7 @@ def test_cfconv_random_configuration(seed):
     assert np.abs(gpos.cpu().numpy() - pg_ref).max() <= 1e-4 * max(float(np.abs(pg_ref).max()), 1e-6)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_neighbor_pairs_random_configuration(seed):
     from nnpops_amd.capi import neighbor_pairs_forward
     rng = np.random.default_rng(3000 + seed)
@@ -160,7 +166,7 @@ def test_neighbor_pairs_random_configuration(seed):
             assert set(got) == true_pairs
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_ani_batched_molecules_random(seed):
     """nnpops_ani_set_molecules: a random batch of independent molecules in one handle equals the oracle molecule by
     molecule (atoms of different molecules must never see each other, whatever their coordinates)."""
