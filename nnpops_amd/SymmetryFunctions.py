@@ -40,6 +40,13 @@ class TorchANISymmetryFunctions(torch.nn.Module):
             lists["Zeta"], lists["ShfA"], lists["ShfZ"], [int(s) for s in species])
         self.triu_index = torch.tensor([0])      # kept for TorchScript compatibility with torchani.AEVComputer users
 
+    @torch.jit.export
+    def set_check_interval(self, interval: int) -> None:
+        """Extension: verify the neighbour-buffer capacities (one host round trip) only on every ``interval``-th call
+        instead of every call; 0 = only on the first.  Between checks an overflow goes unnoticed, exactly as inside a
+        captured graph -- for production loops at known density (cf. ``check_errors`` of ``getNeighborPairs``)."""
+        self.holder.set_check_interval(interval)
+
     def forward(self, species_positions: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
                 pbc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """(species, positions[1, N, 3]) -> (species, aev[1, N, S*nR + S(S+1)/2*nA])"""

@@ -81,6 +81,14 @@ public:
         if (impl) nnpops_ani_destroy(impl);
     }
 
+    // Additive: how often forward() pays the host round trip that verifies the neighbour capacities (and grows them).
+    // 1 (default) = every call, k = every k-th call, 0 = only the first.  Between checks an overflow goes unnoticed, as
+    // inside a captured graph -- for production loops whose densities are known (cf. getNeighborPairs' checkErrors).
+    void setCheckInterval(int64_t interval) {
+        if (interval < 0) throw std::runtime_error("The check interval has to be >= 0");
+        checkInterval = interval;
+    }
+
     tensor_list forward(const Tensor& positions, const c10::optional<Tensor>& cellOpt) {
         // same checks, same messages as the reference (SymmetryFunctions.cpp:76-99)
         if (positions.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"positions\" has to be float32");
@@ -136,6 +144,11 @@ public:
                                    radial.data_ptr<float>(), angular.data_ptr<float>()) != NNPOPS_OK)
                 raise_last("NNPOpsANISymmetryFunctions::forward");
             if (capturing) break;                     // no host synchronisation inside a graph capture
+            // (additive knob, like getNeighborPairs' checkErrors: the capacity check costs a host round trip;
+            // interval k checks every k-th call, 0 never again after the first)
+            const bool due = calls == 0 || (checkInterval > 0 && calls % checkInterval == 0);
+            calls++;
+            if (!due && attempt == 0) break;
             const int rc = nnpops_ani_check(impl, nullptr, nullptr);
             if (rc == NNPOPS_OK) break;
             if (rc != NNPOPS_ERR_CAPACITY || attempt > 8) raise_last("NNPOpsANISymmetryFunctions::forward");
@@ -202,6 +215,8 @@ private:
     bool periodic = false;
     int64_t numRadial = 0, numAngular = 0;
     nnpops_ani_t impl = nullptr;
+    int64_t checkInterval = 1;      // capacity check every k-th forward (0: only the first); see setCheckInterval
+    int64_t calls = 0;
 };
 
 class AutogradFunctions : public torch::autograd::Function<AutogradFunctions> {
@@ -230,6 +245,7 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
                          const std::vector<double>&, const std::vector<int64_t>&>())
         .def("forward", &Holder::forward)
         .def("backward", &Holder::backward)
+        .def("set_check_interval", &Holder::setCheckInterval)
         .def_pickle([](const HolderPtr& self) -> std::string { return Holder::serialize(self); },
                     [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
     m.def("operation", operation);

@@ -428,3 +428,22 @@ def test_optimized_torchani_step_replays_as_one_graph():
         e_ref, f_ref = eager(static_pos)
         torch.testing.assert_close(g_e, e_ref, rtol=1e-6, atol=1e-4)
         torch.testing.assert_close(g_f, f_ref, rtol=1e-4, atol=1e-5 * float(f_ref.abs().max()))
+
+
+def test_capacity_check_interval_knob():
+    """set_check_interval(k): results are unchanged (the check only verifies), scripted modules expose it, a negative
+    interval is refused."""
+    from NNPOps.SymmetryFunctions import TorchANISymmetryFunctions
+    pos, species, box = workloads.water_box(120, seed=5)
+    module = TorchANISymmetryFunctions(FakeConverter(), fake_aev_computer(), _numbers(species).cpu()).to(DEV)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    tpos = torch.tensor(pos, device=DEV).unsqueeze(0)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True])
+    ref = module((sp, tpos), cell, pbc)[1].clone()
+    scripted = torch.jit.script(module)
+    for interval in (0, 3, 1):
+        scripted.set_check_interval(interval)
+        for _ in range(4):
+            assert torch.equal(scripted((sp, tpos), cell, pbc)[1], ref)
+    with pytest.raises(RuntimeError, match="interval"):
+        module.set_check_interval(-1)
