@@ -78,6 +78,14 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
 /* radial_deriv / angular_deriv: device, shapes as the outputs above; position_deriv: device
  * [num_atoms][3], fully overwritten.  Must follow a compute() on the same handle. */
 int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* angular_deriv, float* position_deriv);
+/* The same two calls for AEV / gradient arrays whose rows are embedded in wider rows: row i of the radial part
+ * starts at radial + i * radial_ld (floats), likewise angular; 0 = dense.  Lets a caller keep ONE [num_atoms][W_r + W_a]
+ * array (radial = aev, angular = aev + W_r, both strides W_r + W_a) -- the layout TorchANI's AEVComputer returns --
+ * without a concatenation copy forward and a split copy backward. */
+int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const float* box, float* radial, int radial_ld,
+                               float* angular, int angular_ld);
+int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int radial_ld, const float* angular_deriv,
+                                int angular_ld, float* position_deriv);
 /* Blocks on the handle's stream and reports whether the last compute() overflowed a neighbour
  * buffer (NNPOPS_ERR_CAPACITY; the handle has then already grown its buffers, so simply call
  * compute() again).  max_radial_neighbors / max_angular_neighbors (host, may be NULL) receive the

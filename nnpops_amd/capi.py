@@ -33,6 +33,8 @@ SIGNATURES = {
     "nnpops_ani_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nnpops_ani_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_ani_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_ani_compute_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "nnpops_ani_backprop_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "nnpops_ani_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nnpops_ani_set_neighbor_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_ani_set_molecules": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

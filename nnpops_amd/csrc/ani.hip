@@ -57,6 +57,7 @@ struct nnpops_ani {
     bool computed = false;
     int debug = 0;                  // kernel ablation bits from $NNPOPS_ANI_DEBUG (timing experiments only)
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
+    int ld_radial = 0, ld_angular = 0;   // row strides (floats) of the AEV / gradient arrays of the call in progress
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
@@ -175,12 +176,12 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         auto k = h->chunked_forward ? ani_angular_forward_chunked<TA, NFRP, NFZP> : ani_angular_forward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB,
-                           h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->debug, lds_wave);
+                           h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, h->debug, lds_wave);
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->tile, h->d_recA,
-                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->d_leg_force, h->d_centre_force, h->debug,
+                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, h->debug,
                            lds_wave, (int)h->compact_bwd);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
@@ -370,7 +371,19 @@ int nnpops_ani_set_neighbor_algorithm(nnpops_ani_t h, int algorithm) {
 }
 
 int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box, float* radial, float* angular) {
+    return nnpops_ani_compute_strided(h, positions, box, radial, 0, angular, 0);
+}
+
+int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const float* box, float* radial, int radial_ld,
+                               float* angular, int angular_ld) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    {
+        const int wr = h->hp.S * h->hp.nR, wa = h->hp.NB * h->hp.nA;
+        NNPOPS_REQUIRE((radial_ld == 0 || radial_ld >= wr) && (angular_ld == 0 || angular_ld >= wa),
+                       "row strides must be 0 (dense) or at least the row widths (%d, %d)", wr, wa);
+        h->ld_radial = radial_ld ? radial_ld : wr;
+        h->ld_angular = angular_ld ? angular_ld : wa;
+    }
     NNPOPS_REQUIRE(positions && radial && angular, "NULL device pointer");
     NNPOPS_REQUIRE(!h->hp.periodic || box, "periodic handle needs box vectors");
     DeviceGuard guard(h->device);
@@ -402,19 +415,19 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
         if (per)
             hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist, h->debug);
+                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist, h->debug);
         else
             hipLaunchKernelGGL(ani_neighbors_cells<false>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, lds_bw, h->d_hist, h->debug);
+                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist, h->debug);
     } else if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, radial, lds_bw);
+                           h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw);
     else
         hipLaunchKernelGGL(ani_neighbors_allpairs<false>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, radial, lds_bw);
+                           h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
 
@@ -427,7 +440,19 @@ int nnpops_ani_compute(nnpops_ani_t h, const float* positions, const float* box,
 }
 
 int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* angular_deriv, float* position_deriv) {
+    return nnpops_ani_backprop_strided(h, radial_deriv, 0, angular_deriv, 0, position_deriv);
+}
+
+int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int radial_ld, const float* angular_deriv,
+                                int angular_ld, float* position_deriv) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    {
+        const int wr = h->hp.S * h->hp.nR, wa = h->hp.NB * h->hp.nA;
+        NNPOPS_REQUIRE((radial_ld == 0 || radial_ld >= wr) && (angular_ld == 0 || angular_ld >= wa),
+                       "row strides must be 0 (dense) or at least the row widths (%d, %d)", wr, wa);
+        h->ld_radial = radial_ld ? radial_ld : wr;
+        h->ld_angular = angular_ld ? angular_ld : wa;
+    }
     NNPOPS_REQUIRE(radial_deriv && angular_deriv && position_deriv, "NULL device pointer");
     NNPOPS_REQUIRE(h->computed, "backprop() must follow compute() (ANISymmetryFunctions.h:83-84)");
     DeviceGuard guard(h->device);
@@ -445,7 +470,7 @@ int nnpops_ani_backprop(nnpops_ani_t h, const float* radial_deriv, const float* 
     {
     KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD);
     hipLaunchKernelGGL(ani_radial_backward, agrid, ablock, lds_r, h->stream, h->d_params, h->d_species, h->d_nbr, h->cap,
-                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->d_ids, h->d_leg_force, h->d_centre_force,
+                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
                        h->last_used_cells ? h->d_sorted_atom : nullptr, position_deriv, lds_rw);
     }
     NNPOPS_HIP_TRY(hipGetLastError());

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
                                                              float4* __restrict__ recB, int* __restrict__ ids,
                                                              int* __restrict__ tri,
                                                              int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
-                                                             float* __restrict__ radial, int lds_per_wave) {
+                                                             float* __restrict__ radial, int ld_radial, int lds_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
     flush_row(row, stage, cap, na, nro);
-    radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
+    radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
                      tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G);
 }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
                                                           int* __restrict__ status, float* __restrict__ radial,
-                                                          int lds_per_wave, int* __restrict__ cell_hist, int dbg) {
+                                                          int ld_radial, int lds_per_wave, int* __restrict__ cell_hist, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
     flush_row(row, stage, cap, na, nro);
-    if (!(dbg & 64)) radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * P->S * P->nR);
+    if (!(dbg & 64)) radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);
     if (dbg & 128) return;
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
                      tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
                                                           const float4* __restrict__ nbr, int cap, int cap_angular,
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
-                                                          const float* __restrict__ radial_grad,
+                                                          const float* __restrict__ radial_grad, int ld_radial,
                                                           const int* __restrict__ ids,
                                                           const float4* __restrict__ leg_force,
                                                           const float4* __restrict__ centre_force,
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     const float inv_rcr = 1.0f / P->rcr;
     const int si = species[i];
 
-    const float* gi = radial_grad + (size_t)i * width;
+    const float* gi = radial_grad + (size_t)i * ld_radial;
     for (int q = lane; q < width; q += 64) g_own[q] = gi[q];
     for (int e = lane; e < total; e += 64) {
         const float4 rec = e < na ? row[e] : row[cap - 1 - (e - na)];
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
             const float sh = nb_r[e] - rs;
             const float ex = fast_exp2(ck * sh * sh);
             const float dvdr = (nb_dfc[e] - nb_fc[e] * 2.f * eta * sh) * ex;
-            const float dedv = g_own[nb_sp[e] * nR + k] + radial_grad[(size_t)nb_j[e] * width + si * nR + k];
+            const float dedv = g_own[nb_sp[e] * nR + k] + radial_grad[(size_t)nb_j[e] * ld_radial + si * nR + k];
             const float sc = dedv * dvdr;
             fx -= sc * nb_ux[e]; fy -= sc * nb_uy[e]; fz -= sc * nb_uz[e];
         }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
                                                           const int* __restrict__ tri_g,
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
-                                                          float* __restrict__ angular, int dbg, int lds_per_wave) {
+                                                          float* __restrict__ angular, int ld_angular, int dbg, int lds_per_wave) {
     using L = FwdLayout<NFRP, NFZP>;
     constexpr int CH = L::CH, NSTREAM = L::NSTREAM, SR = L::SR, BLK = L::BLK;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
     }
 
     // ---------------- epilogue: canonical LDS row -> reference column order, coalesced rows ----------------
-    float* out = angular + (size_t)i * NB * nA;
+    float* out = angular + (size_t)i * ld_angular;
     if (dbg & 4) return;
     if (nA <= 32) {                                        // two buckets per pass
         const int m = lane & 31, half = lane >> 5;
@@ -961,7 +961,7 @@ template <bool TORCHANI, int NFRP, int NFZP>
 __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunked(
     const AniParams* __restrict__ P, int cap, int capA, const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
     const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro, float* __restrict__ angular,
-    int dbg, int lds_per_wave) {
+    int ld_angular, int dbg, int lds_per_wave) {
     using L = FwdLayout<NFRP, NFZP>;
     constexpr int CH = L::CH, NSTREAM = L::NSTREAM, SR = L::SR, BLK = L::BLK;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunk
     }
 
     // ---------------- epilogue: canonical LDS row -> reference column order, coalesced rows ----------------
-    float* out = angular + (size_t)i * NB * nA;
+    float* out = angular + (size_t)i * ld_angular;
     if (dbg & 4) return;
     if (nA <= 32) {                                        // two buckets per pass
         const int m = lane & 31, half = lane >> 5;
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                                                            const int* __restrict__ tri_g,
                                                            const int* __restrict__ cnt_a,
                                                            const int* __restrict__ cnt_ro,
-                                                           const float* __restrict__ angular_grad,
+                                                           const float* __restrict__ angular_grad, int ld_angular,
                                                            float4* __restrict__ leg_force,      // [N][capA]
                                                            float4* __restrict__ centre_force,   // [N]
                                                            int dbg, int lds_per_wave, int compact) {
@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     // upstream gradient row -> canonical [bucket][a][z] order, pre-multiplied by 2^(1-zeta).
     // All global loads of a group are issued before LDS is touched (a load-store-load loop waits every trip).
     {
-        const float* g = angular_grad + (size_t)i * NB * nA;
+        const float* g = angular_grad + (size_t)i * ld_angular;
         if (nA <= 32) {
             const int m = lane & 31, half = lane >> 5;
             const bool live = m < nA;

@@ -89,7 +89,12 @@ public:
         checkInterval = interval;
     }
 
-    tensor_list forward(const Tensor& positions, const c10::optional<Tensor>& cellOpt) {
+    tensor_list forward(const Tensor& positions, const c10::optional<Tensor>& cellOpt) { return forwardImpl(positions, cellOpt, false); }
+
+    // fused = true: ONE output, aev [N, S*nR + S(S+1)/2*nA] = (radial | angular) per row -- what TorchANI's AEVComputer
+    // returns and what the Python wrapper otherwise builds with torch.cat: the kernels write the two parts in place
+    // (nnpops_ani_compute_strided), no concatenation copy forward, no split copy backward.
+    tensor_list forwardImpl(const Tensor& positions, const c10::optional<Tensor>& cellOpt, bool fused) {
         // same checks, same messages as the reference (SymmetryFunctions.cpp:76-99)
         if (positions.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"positions\" has to be float32");
         if (positions.dim() != 2) throw std::runtime_error("The shape of \"positions\" has to have 2 dimensions");
@@ -134,14 +139,24 @@ public:
         const Tensor pos = positions.contiguous();
         const int64_t n = (int64_t)atomSpecies.size();
         const auto opts = torch::TensorOptions().device(device).dtype(torch::kFloat32);
-        Tensor radial = torch::empty({n, numSpecies * numRadial}, opts);
-        Tensor angular = torch::empty({n, numSpecies * (numSpecies + 1) / 2 * numAngular}, opts);
+        const int64_t wr = numSpecies * numRadial, wa = numSpecies * (numSpecies + 1) / 2 * numAngular;
+        Tensor radial, angular, aev;
+        float *pr, *pa;
+        int ld = 0;
+        if (fused) {
+            aev = torch::empty({n, wr + wa}, opts);
+            pr = aev.data_ptr<float>(); pa = pr + wr; ld = (int)(wr + wa);
+        } else {
+            radial = torch::empty({n, wr}, opts);
+            angular = torch::empty({n, wa}, opts);
+            pr = radial.data_ptr<float>(); pa = angular.data_ptr<float>();
+        }
         void* stream = current_stream(device);
         nnpops_ani_set_stream(impl, stream);
         const bool capturing = stream_is_capturing(stream);
         for (int attempt = 0;; attempt++) {
-            if (nnpops_ani_compute(impl, pos.data_ptr<float>(), periodic ? cell.data_ptr<float>() : nullptr,
-                                   radial.data_ptr<float>(), angular.data_ptr<float>()) != NNPOPS_OK)
+            if (nnpops_ani_compute_strided(impl, pos.data_ptr<float>(), periodic ? cell.data_ptr<float>() : nullptr, pr, ld, pa, ld) !=
+                NNPOPS_OK)
                 raise_last("NNPOpsANISymmetryFunctions::forward");
             if (capturing) break;                     // no host synchronisation inside a graph capture
             // (additive knob, like getNeighborPairs' checkErrors: the capacity check costs a host round trip;
@@ -153,7 +168,21 @@ public:
             if (rc == NNPOPS_OK) break;
             if (rc != NNPOPS_ERR_CAPACITY || attempt > 8) raise_last("NNPOpsANISymmetryFunctions::forward");
         }
+        if (fused) return {aev};
         return {radial, angular};
+    }
+
+    tensor_list backwardFused(const Tensor& aevGrad) {
+        if (!impl) throw std::runtime_error("backward() called before forward()");
+        const Tensor g = aevGrad.contiguous();
+        const int64_t wr = numSpecies * numRadial, w = g.size(1);
+        Tensor positionsGrad = torch::empty({(int64_t)atomSpecies.size(), 3},
+                                            torch::TensorOptions().device(device).dtype(torch::kFloat32));
+        nnpops_ani_set_stream(impl, current_stream(device));
+        if (nnpops_ani_backprop_strided(impl, g.data_ptr<float>(), (int)w, g.data_ptr<float>() + wr, (int)w,
+                                        positionsGrad.data_ptr<float>()) != NNPOPS_OK)
+            raise_last("NNPOpsANISymmetryFunctions::backward");
+        return {Tensor(), positionsGrad, Tensor()};
     }
 
     tensor_list backward(const tensor_list& grads) {
@@ -238,6 +267,25 @@ tensor_list operation(const c10::optional<HolderPtr>& holder, const Tensor& posi
     return AutogradFunctions::apply(*holder, positions, periodicBoxVectors);
 }
 
+class FusedAutogradFunction : public torch::autograd::Function<FusedAutogradFunction> {
+public:
+    static Tensor forward(AutogradContext* ctx, const HolderPtr& holder, const Tensor& positions,
+                          const c10::optional<Tensor>& periodicBoxVectors) {
+        ctx->saved_data["holder"] = holder;
+        return holder->forwardImpl(positions, periodicBoxVectors, true)[0];
+    }
+    static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
+        const auto holder = ctx->saved_data["holder"].toCustomClass<Holder>();
+        ctx->saved_data.erase("holder");
+        return holder->backwardFused(grads[0]);
+    }
+};
+
+// Additive: the whole AEV as one tensor (see Holder::forwardImpl).  operation() keeps the reference's two-tensor form.
+Tensor aev(const c10::optional<HolderPtr>& holder, const Tensor& positions, const c10::optional<Tensor>& periodicBoxVectors) {
+    return FusedAutogradFunction::apply(*holder, positions, periodicBoxVectors);
+}
+
 TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
     m.class_<Holder>("Holder")
         .def(torch::init<int64_t, double, double, const std::vector<double>&, const std::vector<double>&,
@@ -249,6 +297,7 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
         .def_pickle([](const HolderPtr& self) -> std::string { return Holder::serialize(self); },
                     [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
     m.def("operation", operation);
+    m.def("aev", aev);
 }
 
 }  // namespace ANISymmetryFunctions

@@ -302,3 +302,34 @@ def test_handles_release_their_device_memory():
     gc.collect(); torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)          # allow allocator granularity, not 200 leaked handles
+
+
+def test_strided_rows_write_one_aev_array():
+    """nnpops_ani_compute_strided / _backprop_strided: radial and angular parts written into (and their gradients read
+    from) ONE [N, W_r + W_a + padding] array, bit-identical to the dense calls; strides below the row width refused."""
+    from nnpops_amd.capi import AniSymmetryFunctions, lib, _ptr, _check, NNPOpsHipError
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1300, seed=61)
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+    radial, angular = sym.compute(tpos, tbox)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    g_r = torch.randn(radial.shape, device=dev, generator=gen)
+    g_a = torch.randn(angular.shape, device=dev, generator=gen)
+    grad = sym.backprop(g_r, g_a).clone()
+    wr, wa, pad = radial.shape[1], angular.shape[1], 5
+    ld = wr + wa + pad
+    aev = torch.full((len(pos), ld), float("nan"), device=dev)
+    L = lib()
+    _check(L.nnpops_ani_compute_strided(sym._h, _ptr(tpos), _ptr(tbox), aev.data_ptr(), ld, aev.data_ptr() + 4 * wr, ld))
+    torch.cuda.synchronize()
+    assert torch.equal(aev[:, :wr], radial) and torch.equal(aev[:, wr:wr + wa], angular) and bool(torch.isnan(aev[:, wr + wa:]).all())
+    g = torch.zeros((len(pos), ld), device=dev)
+    g[:, :wr], g[:, wr:wr + wa] = g_r, g_a
+    grad2 = torch.empty_like(grad)
+    _check(L.nnpops_ani_backprop_strided(sym._h, g.data_ptr(), ld, g.data_ptr() + 4 * wr, ld, _ptr(grad2)))
+    torch.cuda.synchronize()
+    assert torch.equal(grad2, grad)
+    with pytest.raises(NNPOpsHipError, match="row strides"):
+        _check(L.nnpops_ani_compute_strided(sym._h, _ptr(tpos), _ptr(tbox), aev.data_ptr(), wr - 1, aev.data_ptr(), ld))
