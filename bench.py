@@ -70,8 +70,8 @@ def cpu_baseline(pos, species, box, rf, af, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)     # 0.07 s of GPU time: long enough for clocks and caches to settle
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="torchani workload: replay the step as one captured HIP graph")
