@@ -33,6 +33,8 @@ from nnpops_amd import workloads  # noqa: E402
 from nnpops_amd.capi import AniSymmetryFunctions  # noqa: E402
 
 ROOFLINE_KERNELS = ("neighbors", "angular_forward", "angular_backward", "radial_backward")   # candidates for "dominant"
+ROCPROF_NAME = {"neighbors": "ani_neighbors_cells (neighbour rows + radial AEV)", "angular_forward": "ani_angular_forward",
+                "angular_backward": "ani_angular_backward", "radial_backward": "ani_radial_backward (+ force gather)"}
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
@@ -205,7 +207,7 @@ def main():
                        "atoms": n, "frames_per_gpu": 1, "max_neighbors_rcr": max_row, "max_neighbors_rca": max_ang},
             "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
             "event_pair_overhead_us": round(1e6 * event_overhead, 2),
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": ROCPROF_NAME.get(dominant, dominant), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes[dominant]},
         }
