@@ -584,14 +584,14 @@ __device__ __forceinline__ void activate_d_fast(float s, float& y, float& dy) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// MFMA backward: same tiling as the forward kernel, with the d/dr path riding along.
+// MFMA backward: same packed tiling as the forward kernel, with the d/dr path riding along.
 //   layer 1   S1 = Gam W1^T + b1 and dS1 = dGam W1^T share every B operand (two MFMAs per LDS read)
 //   Y1 = act(S1) goes to the LDS tile; dY1 = dS1 * act'(S1) waits in registers
 //   layer 2   S2 = Y1 W2^T + b2, then the SAME LDS tile is refilled with dY1 for dS2 = dY1 W2^T
 //             (one tile per wave instead of two keeps 7 waves per CU resident at W = 128)
 //   epilogue  y2 = fc S2 -> input gradient ; dy2 = dfc S2 + fc dS2 -> force on the owner atom   ref :275-291
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t mfma_wave_floats_bwd(int W) { return (size_t)16 * (W + 1) + 128; }
+__host__ __device__ inline size_t mfma_wave_floats_bwd(int W) { return (size_t)16 * (W + 1) + 144; }
 
 template <int ACT, int NCB>
 __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
     float* s_w2t = lds;
     float* s_w1t = s_w2t + (size_t)W * W;
     float* y1 = s_w1t + (size_t)Gp * W + (size_t)wave * mfma_wave_floats_bwd(W);   // [16][YS]
-    float* ps = y1 + 16 * YS;                              // r | fc | dfc | j | 1/r | dx | dy | dz, 16 each
+    float* ps = y1 + 16 * YS;                              // r | fc | dfc | j | 1/r | dx | dy | dz | owner, 16 each
     for (int q = tid; q < W * W; q += blockDim.x) s_w2t[q] = w2t[q];
     for (int q = tid; q < Gp * W; q += blockDim.x) s_w1t[q] = q < G * W ? w1t[q] : 0.f;
     __syncthreads();
@@ -618,117 +618,165 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
     const float sig2 = P.sigma_inv * P.sigma_inv;
     const float gscale = -0.5f * kLog2e * sig2;
 
-    for (int i = blockIdx.x * waves_per_block + wave; i < P.N; i += gridDim.x * waves_per_block) {
-        const int n = min(cnt[i], cap);
-        const float4* row = rows + (size_t)i * cap;
-        float xi[NCB], gi[NCB], gacc[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            xi[cb] = x[(size_t)i * W + cb * 16 + col];
-            gi[cb] = gout[(size_t)i * W + cb * 16 + col];
-            gacc[cb] = 0.f;
-        }
-        float fx = 0.f, fy = 0.f, fz = 0.f;
-        for (int t0 = 0; t0 < n; t0 += 16) {
-            const int np = min(16, n - t0);
-            if (lane < 16) {
-                float r = 1.0f, fc = 0.f, dfc = 0.f;
-                float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(i));
-                if (lane < np) {
-                    rec = row[t0 + lane];
-                    r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
-                    float sn, cs;
-                    sincospif(r / P.cutoff, &sn, &cs);
-                    fc = 0.5f * cs + 0.5f;                                              // ref :301-303
-                    dfc = -(0.5f * kPi / P.cutoff) * sn;                                // ref :305-307
-                }
-                ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = dfc;
-                ps[48 + lane] = __int_as_float(__float_as_int(rec.w) & kIdMask);
-                ps[64 + lane] = 1.0f / r; ps[80 + lane] = rec.x; ps[96 + lane] = rec.y; ps[112 + lane] = rec.z;
-            }
-            wave_fence();
-            // ---- layer 1: value and d/dr together ----
-            f32x4 acc[NCB], dacc[NCB];
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) {
-                acc[cb] = f32x4{b1v[cb], b1v[cb], b1v[cb], b1v[cb]};
-                dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            const float rp = ps[col];
-            for (int s = 0; s < Gp / 4; s++) {
-                const int g = 4 * s + grp;
-                const float d = rp - (float)g * mu_step;
-                const float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                   // ref :151-154
-                const float da = -d * sig2 * a;                                            // ref :242
-                const float* wrow = s_w1t + g * W + col;
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) {
-                    const float b = wrow[cb * 16];
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[cb], 0, 0, 0);
-                    dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, b, dacc[cb], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float yv, dact;
-                    activate_d_fast<ACT>(acc[cb][q], yv, dact);
-                    y1[(grp * 4 + q) * YS + cb * 16 + col] = yv;
-                    dacc[cb][q] *= dact;                                                   // dY1, kept in registers
-                }
-            wave_fence();
-            // ---- layer 2 on Y1 ----
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
-            mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, acc);
-            wave_fence();
-            // ---- refill the tile with dY1, layer 2 again ----
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    y1[(grp * 4 + q) * YS + cb * 16 + col] = dacc[cb][q];
-                    dacc[cb][q] = 0.f;
-                }
-            wave_fence();
-            mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, dacc);
-            // ---- epilogue: my four rows of the tile ----
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int rr = grp * 4 + q;
-                const int j = __float_as_int(ps[48 + rr]);
-                const float fc = ps[16 + rr], dfc = ps[32 + rr];
-                float sc = 0.f;
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) {
-                    const float xj = x[(size_t)j * W + cb * 16 + col], gj = gout[(size_t)j * W + cb * 16 + col];
-                    const float s2 = acc[cb][q];
-                    gacc[cb] += fc * s2 * gj;                                              // ref :275, :284
-                    const float dy2 = dfc * s2 + fc * dacc[cb][q];                         // ref :276
-                    sc += dy2 * (xj * gi[cb] + xi[cb] * gj);                               // ref :286
-                }
-                sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
-                sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
-                sc *= ps[64 + rr];
-                // position_deriv[i] -= sc * delta  (owner side of ref :287-291; delta = pos_j - pos_i)
-                fx -= sc * ps[80 + rr]; fy -= sc * ps[96 + rr]; fz -= sc * ps[112 + rr];
-                __builtin_amdgcn_sched_barrier(0);      // one row's 2*NCB gathers in flight at a time: no spills at W = 128
-            }
-            wave_fence();
-        }
+    // Tiles are packed across the atoms of a wave's contiguous run exactly as in the forward kernel (rows carry
+    // their owner): per-atom tile sequences left 19 % of the rows of every matrix-core pass empty.
+    const int total_waves = gridDim.x * waves_per_block;
+    const int chunk = (P.N + total_waves - 1) / total_waves;
+    const int a0 = min((blockIdx.x * waves_per_block + wave) * chunk, P.N), a1 = min(a0 + chunk, P.N);
+    float xi[NCB], gi[NCB], gacc[NCB];                      // state of the atom whose rows are being consumed (`cur`)
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    int cur = -1;
+    auto flush = [&]() {                                    // fold the four row groups, write cur's two results
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) {
             float v = gacc[cb];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (grp == 0) xgrad[(size_t)i * W + cb * 16 + col] = v;
+            if (grp == 0) xgrad[(size_t)cur * W + cb * 16 + col] = v;
         }
         fx += __shfl_xor(fx, 16, 64); fx += __shfl_xor(fx, 32, 64);
         fy += __shfl_xor(fy, 16, 64); fy += __shfl_xor(fy, 32, 64);
         fz += __shfl_xor(fz, 16, 64); fz += __shfl_xor(fz, 32, 64);
-        if (lane == 0) { pos_grad[3 * i] = fx; pos_grad[3 * i + 1] = fy; pos_grad[3 * i + 2] = fz; }
+        if (lane == 0) { pos_grad[3 * cur] = fx; pos_grad[3 * cur + 1] = fy; pos_grad[3 * cur + 2] = fz; }
+    };
+    auto open = [&](int o) {
+        cur = o;
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            xi[cb] = x[(size_t)o * W + cb * 16 + col];
+            gi[cb] = gout[(size_t)o * W + cb * 16 + col];
+            gacc[cb] = 0.f;
+        }
+        fx = fy = fz = 0.f;
+    };
+    for (int a = a0; a < a1; a++)                           // atoms without neighbours never own a tile row
+        if (min(cnt[a], cap) == 0) {
+            if (grp == 0)
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) xgrad[(size_t)a * W + cb * 16 + col] = 0.f;
+            if (lane == 0) { pos_grad[3 * a] = 0.f; pos_grad[3 * a + 1] = 0.f; pos_grad[3 * a + 2] = 0.f; }
+        }
+    auto request = [&](int start_atom, int start_row, int& atom, int& e, float4& rec) {
+        atom = start_atom;
+        e = start_row + (lane & 15);                        // lanes 0..15 (the others mirror them)
+        while (atom < a1) {
+            const int n = min(cnt[atom], cap);
+            if (e < n) break;
+            e -= n;
+            atom++;
+        }
+        rec = atom < a1 ? rows[(size_t)atom * cap + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int my_atom, my_e;
+    float4 rec;
+    request(a0, 0, my_atom, my_e, rec);
+    while (__shfl(my_atom, 0, 64) < a1) {                   // row 0 of the tile exists (wave-uniform)
+        if (lane < 16) {
+            float r = 1.0f, fc = 0.f, dfc = 0.f;
+            int j = a0, owner = -1;
+            if (my_atom < a1) {
+                r = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+                float sn, cs;
+                sincospif(r / P.cutoff, &sn, &cs);
+                fc = 0.5f * cs + 0.5f;                                              // ref :301-303
+                dfc = -(0.5f * kPi / P.cutoff) * sn;                                // ref :305-307
+                j = __float_as_int(rec.w) & kIdMask;
+                owner = my_atom;
+            }
+            ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = dfc;
+            ps[48 + lane] = __int_as_float(j);
+            ps[64 + lane] = 1.0f / r; ps[80 + lane] = rec.x; ps[96 + lane] = rec.y; ps[112 + lane] = rec.z;
+            ps[128 + lane] = __int_as_float(owner);
+        }
+        // the next tile starts one past row 15 (lane 15 knows): its rows are requested now, used after the GEMMs
+        int next_atom, next_e;
+        float4 next_rec;
+        request(__shfl(my_atom, 15, 64), __shfl(my_e, 15, 64) + 1, next_atom, next_e, next_rec);
+        wave_fence();
+        const int o_lo = __float_as_int(ps[128]);           // row 0 always exists
+        int o_hi = o_lo;
+#pragma unroll
+        for (int r15 = 1; r15 < 16; r15++) o_hi = max(o_hi, __float_as_int(ps[128 + r15]));     // owners ascend; -1 = padding
+        // ---- layer 1: value and d/dr together ----
+        f32x4 acc[NCB], dacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            acc[cb] = f32x4{b1v[cb], b1v[cb], b1v[cb], b1v[cb]};
+            dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float rp = ps[col];
+        for (int s = 0; s < Gp / 4; s++) {
+            const int g = 4 * s + grp;
+            const float d = rp - (float)g * mu_step;
+            const float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                   // ref :151-154
+            const float da = -d * sig2 * a;                                            // ref :242
+            const float* wrow = s_w1t + g * W + col;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                const float b = wrow[cb * 16];
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[cb], 0, 0, 0);
+                dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, b, dacc[cb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float yv, dact;
+                activate_d_fast<ACT>(acc[cb][q], yv, dact);
+                y1[(grp * 4 + q) * YS + cb * 16 + col] = yv;
+                dacc[cb][q] *= dact;                                                   // dY1, kept in registers
+            }
+        wave_fence();
+        // ---- layer 2 on Y1 ----
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+        mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, acc);
+        wave_fence();
+        // ---- refill the tile with dY1, layer 2 again ----
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                y1[(grp * 4 + q) * YS + cb * 16 + col] = dacc[cb][q];
+                dacc[cb][q] = 0.f;
+            }
+        wave_fence();
+        mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, dacc);
+        // ---- epilogue: my four rows of the tile, owner by owner (one owner for two tiles out of three) ----
+        for (int o = o_lo; o <= o_hi; o++) {                // wave-uniform; atoms in between without rows get zeros (again)
+            if (o != cur) {
+                if (cur >= 0) flush();
+                open(o);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int rr = grp * 4 + q;
+                if (__float_as_int(ps[128 + rr]) == o) {    // uniform over the 16 lanes that share the row
+                    const int j = __float_as_int(ps[48 + rr]);
+                    const float fc = ps[16 + rr], dfc = ps[32 + rr];
+                    float sc = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) {
+                        const float xj = x[(size_t)j * W + cb * 16 + col], gj = gout[(size_t)j * W + cb * 16 + col];
+                        const float s2 = acc[cb][q];
+                        gacc[cb] += fc * s2 * gj;                                              // ref :275, :284
+                        const float dy2 = dfc * s2 + fc * dacc[cb][q];                         // ref :276
+                        sc += dy2 * (xj * gi[cb] + xi[cb] * gj);                               // ref :286
+                    }
+                    sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
+                    sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+                    sc *= ps[64 + rr];
+                    // position_deriv[owner] -= sc * delta  (owner side of ref :287-291; delta = pos_j - pos_owner)
+                    fx -= sc * ps[80 + rr]; fy -= sc * ps[96 + rr]; fz -= sc * ps[112 + rr];
+                }
+                __builtin_amdgcn_sched_barrier(0);          // one row's 2*NCB gathers in flight at a time: no spills at W = 128
+            }
+        }
+        my_atom = next_atom; my_e = next_e; rec = next_rec;
+        wave_fence();
     }
+    if (cur >= 0) flush();
 }
 
 }  // namespace
