@@ -39,7 +39,7 @@ constexpr int kPairTile = 8;
 constexpr int kMaxWavesPerBlock = 8;
 constexpr int kMaxWidth = 512;      // <= 128: weights resident in LDS (matrix-core or vector kernels); above: streamed
 constexpr int kMaxGauss = 256;
-enum { kStOverflow = 0, kStMaxRow = 1, kStPairs = 2, kStWordsN = 4 };
+enum { kStOverflow = 0, kStMaxRow = 1, kStPairs = 2, kStUnmatched = 3, kStWordsN = 4 };
 
 // ---------------------------------------------------------------------------------------------
 // neighbour rows (full list): one wave per atom
@@ -54,16 +54,23 @@ __device__ __forceinline__ void append(float4* __restrict__ row, int cap, bool k
     n += __popcll(m);
 }
 
+// One lane per row: the row's length and how many of its pairs are with a higher index -- scan_half turns those into
+// the row's range of pair slots (see "Half list" below).
+__device__ __forceinline__ void publish_row(int i, int n, int n_lo, int* __restrict__ cnt, int* __restrict__ lo_cnt) {
+    cnt[i] = n;
+    lo_cnt[i] = n_lo;
+}
+
 template <bool PERIODIC>
 __global__ __launch_bounds__(64) void rows_allpairs(int N, const float* __restrict__ pos, const float* __restrict__ box,
                                                     float cutoff2, float4* __restrict__ rows, int cap,
-                                                    int* __restrict__ cnt) {
+                                                    int* __restrict__ cnt, int* __restrict__ lo_cnt) {
     const int i = blockIdx.x, lane = lane_id();
     Box b{};
     if (PERIODIC) b = load_box(box);
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
     float4* row = rows + (size_t)i * cap;
-    int n = 0;
+    int n = 0, n_lo = 0;
     for (int base = 0; base < N; base += 64) {
         const int j = base + lane;
         bool keep = false;
@@ -74,8 +81,9 @@ __global__ __launch_bounds__(64) void rows_allpairs(int N, const float* __restri
             keep = dx * dx + dy * dy + dz * dz < cutoff2;          // strict, on r^2 (ref :110)
         }
         append(row, cap, keep, dx, dy, dz, j, n);
+        n_lo += __popcll(__ballot(keep && j > i));
     }
-    if (lane == 0) cnt[i] = n;
+    if (lane == 0) publish_row(i, n, n_lo, cnt, lo_cnt);
 }
 
 template <bool PERIODIC>
@@ -83,14 +91,15 @@ __global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, 
                                                  const CellGrid* __restrict__ grid, const int* __restrict__ cell_start,
                                                  const int* __restrict__ atom_cell, const float4* __restrict__ sorted_pos,
                                                  float4* __restrict__ rows, int cap, int* __restrict__ cnt,
-                                                 int* __restrict__ status, int* __restrict__ cell_hist) {
+                                                 int* __restrict__ lo_cnt, int* __restrict__ status,
+                                                 int* __restrict__ cell_hist) {
     const int lane = lane_id();
     clear_cell_histogram(cell_hist);
     const CellGrid g = *grid;
     if (!g.ok) {
         if (lane == 0) {
             if (blockIdx.x == 0) atomicOr(&status[kStOverflow], g.bin_overflow ? 6 : 2);   // 4: grow the cell bins
-            cnt[blockIdx.x] = 0;
+            publish_row((int)blockIdx.x, 0, 0, cnt, lo_cnt);
         }
         return;
     }
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, 
     const int c = atom_cell[i];
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
     float4* row = rows + (size_t)i * cap;
-    int n = 0;
+    int n = 0, n_lo = 0;
     // the 27-cell stencil as one flat candidate space (celllist.h): full iterations, next batch's load in flight
     const Stencil st = gather_stencil(g, cell_start, cx, cy, cz);
     const int last = max(st.total - 1, 0);
@@ -123,8 +132,165 @@ __global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, 
             }
         }
         append(row, cap, keep, dx, dy, dz, j, n);
+        n_lo += __popcll(__ballot(keep && j > i));
     }
-    if (lane == 0) cnt[i] = n;
+    if (lane == 0) publish_row(i, n, n_lo, cnt, lo_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Half list behind the full rows.  The matrix-core kernels evaluate the filter network ONCE per pair {i, j}: every
+// pair gets a slot (`pid`) -- the pairs a row holds with a higher index, in row order -- and every entry
+// of the full rows learns the slot of its pair, so that the owner-computes gather (cfconv_gather) can fetch the
+// filter row from either end.  half_off[i] = first slot of row i (scan_half); the entry (i -> j), j < i finds its slot by looking i up in row j.  An entry whose mirror image is missing (a pair within rounding of the cutoff, where the
+// cosine cutoff makes its contribution vanish) points at the all-zero row `pair_cap`.
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan of lo_cnt -> half_off, total in half_off[N].  One workgroup: every thread takes kScanPerThread
+// consecutive rows (independent 16-byte loads), one block-wide scan of the thread totals per 16 K rows.
+constexpr int kScanPerThread = 16;
+__global__ __launch_bounds__(1024) void scan_half(int N, const int* __restrict__ lo_cnt, int* __restrict__ half_off) {
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < N; base += 1024 * kScanPerThread) {
+        const int k0 = base + threadIdx.x * kScanPerThread;
+        int v[kScanPerThread], mine = 0;
+        if (k0 + kScanPerThread <= N) {
+#pragma unroll
+            for (int q = 0; q < kScanPerThread; q += 4) {
+                const int4 t = *reinterpret_cast<const int4*>(lo_cnt + k0 + q);
+                v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kScanPerThread; q++) v[q] = k0 + q < N ? lo_cnt[k0 + q] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < kScanPerThread; q++) mine += v[q];
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int t = wsum[w];
+            before += w < wave ? t : 0;
+            total += t;
+        }
+        int run = carry + before + incl - mine;
+#pragma unroll
+        for (int q = 0; q < kScanPerThread; q++) {
+            const int mine_q = run;
+            run += v[q];
+            v[q] = mine_q;
+        }
+        if (k0 + kScanPerThread <= N) {
+#pragma unroll
+            for (int q = 0; q < kScanPerThread; q += 4)
+                *reinterpret_cast<int4*>(half_off + k0 + q) = make_int4(v[q], v[q + 1], v[q + 2], v[q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < kScanPerThread; q++)
+                if (k0 + q < N) half_off[k0 + q] = v[q];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) half_off[N] = carry;
+}
+
+// Looking i up in the rows of its lower-index neighbours: the wave stages the ids of up to kMirrorRows of those rows
+// in LDS (coalesced loads, all in flight together), then every lane scans "its" row there -- lane-parallel vector
+// work.  (Doing it row by row with ballots is scalar-unit work, ~80 SALU instructions per entry, and the one scalar
+// unit of a CU then sets the time of the whole kernel.)
+constexpr int kMirrorRows = 32;
+constexpr int kMirrorStride = 65;                           // ids of one row, +1: the lanes scan different rows in step
+
+__global__ __launch_bounds__(64) void half_slots(const float4* __restrict__ rows, const int* __restrict__ cnt,
+                                                 const int* __restrict__ half_off, int cap, int pair_cap,
+                                                 int* __restrict__ pid, float* __restrict__ half_r, int2* __restrict__ half_ij,
+                                                 int* __restrict__ status, int N, const float4* __restrict__ sorted_pos) {
+    __shared__ int ids[kMirrorRows * kMirrorStride];
+    const int lane = lane_id();
+    const int k0 = xcd_contiguous_wave_id();               // atoms in cell order when there is one: the rows looked up are L2-hot
+    if (k0 >= N) return;
+    const int i = sorted_pos ? __float_as_int(sorted_pos[k0].w) & kIdMask : k0;
+    if (i >= N) return;
+    const int n = min(cnt[i], cap);
+    const int first = half_off[i];
+    int lo_before = 0;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int s = s0 + lane;
+        int j = i;
+        bool lower = false, upper = false;
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < n) {
+            rec = rows[(size_t)i * cap + s];
+            j = __float_as_int(rec.w) & kIdMask;
+            lower = j > i;
+            upper = !lower;
+        }
+        const unsigned long long lm = __ballot(lower);
+        int my_pid = pair_cap;
+        if (lower) {
+            int p = first + lo_before + prefix_popc(lm);
+            if (p >= pair_cap) p = pair_cap;                 // (only after a row overflow: check() grows and rebuilds)
+            my_pid = p;
+            if (p < pair_cap) {
+                half_r[p] = sqrtf(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+                half_ij[p] = make_int2(i, j);
+            }
+        }
+        lo_before += __popcll(lm);
+        // entries towards a lower index j: slot = first slot of row j + rank of i among j's higher-index neighbours
+        const int nj = upper ? min(cnt[j], cap) : 0;
+        const int first_j = upper ? half_off[j] : 0;
+        unsigned long long um = __ballot(upper);
+        while (um) {
+            const int my_row = upper && ((um >> lane) & 1ull) ? prefix_popc(um) : kMirrorRows;   // < kMirrorRows: searched in this round
+            const bool searching = my_row < kMirrorRows;
+            int found = -1, lows = 0;
+            const int longest = cap;                        // (rows are at most cap long; 64 ids per pass)
+            for (int t0 = 0; t0 < longest; t0 += 64) {
+                if (!__ballot(searching && found < 0 && t0 < nj)) break;
+                // stage ids [t0, t0 + 64) of the rows of this round
+                unsigned long long todo = um;
+#pragma unroll 8
+                for (int q = 0; q < kMirrorRows; q++) {
+                    if (!todo) break;
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int jq = __builtin_amdgcn_readlane(j, src);
+                    const int t = t0 + lane;
+                    ids[q * kMirrorStride + lane] = t < cap ? __float_as_int(rows[(size_t)jq * cap + t].w) & kIdMask : -1;
+                }
+                wave_fence();
+                if (searching && found < 0) {
+                    const int* mine = ids + my_row * kMirrorStride;
+                    const int m = min(64, nj - t0);
+                    for (int t = 0; t < m; t++) {
+                        const int id = mine[t];
+                        if (id == i) { found = lows; break; }
+                        lows += id > j ? 1 : 0;
+                    }
+                }
+                wave_fence();
+            }
+            if (searching) {
+                if (found >= 0) my_pid = min(first_j + found, pair_cap);
+                else atomicAdd(&status[kStUnmatched], 1);
+            }
+            // drop the rows of this round from the pending set
+            unsigned long long done = um;
+            for (int q = 0; q < kMirrorRows && done; q++) done &= done - 1;
+            um = done;
+        }
+        if (s < n) pid[(size_t)i * cap + s] = my_pid;
+    }
 }
 
 // max row length and number of half pairs (j > i) of the last build
@@ -779,6 +945,229 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_backward_mfma(
     if (cur >= 0) flush();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Half-list path (the default for the matrix-core widths): the filter network is evaluated once per PAIR.
+//   cfconv_filters_mfma   tile = 16 consecutive pair slots (no owners, no raggedness); writes the filter row
+//                         F[pid] = fc * (W2 y1 + b2) -- 512 B at W = 128 -- and, backward, the pair's radial
+//                         force  s[pid] = sum_c (dfc S2 + fc dS2)_c (x_j g_i + x_i g_j)_c / r            ref :275-291
+//   cfconv_gather         owner computes: out[i] = sum_e F[pid_e] * x[j_e]   (backward: the same sum over gout gives
+//                         dE/dx[i], and dE/dpos[i] = -sum_e s[pid_e] delta_e) -- deterministic, no atomics.
+// Compared with evaluating every pair from both ends this halves the matrix-core AND the activation work (which
+// add up on a SIMD) for one round trip of F through HBM / the Infinity Cache.
+// ---------------------------------------------------------------------------------------------
+template <int ACT, int NCB, bool BWD>
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_mfma(
+    ConvParams P, const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
+    const float* __restrict__ b2, const int* __restrict__ half_off, const float* __restrict__ half_r,
+    const int2* __restrict__ half_ij, int pair_cap, const float* __restrict__ x, const float* __restrict__ gout,
+    float* __restrict__ filt, float* __restrict__ pair_s) {
+    constexpr int W = NCB * 16, YS = W + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = P.G, Gp = (G + 3) & ~3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    float* s_w2t = lds;
+    float* s_w1t = s_w2t + (size_t)W * W;
+    float* y1 = s_w1t + (size_t)Gp * W + (size_t)wave * mfma_wave_floats_bwd(W);   // [16][YS]
+    float* ps = y1 + 16 * YS;                              // r | fc | dfc | 1/r | i | j, 16 each
+    for (int q = tid; q < W * W; q += blockDim.x) s_w2t[q] = w2t[q];
+    for (int q = tid; q < Gp * W; q += blockDim.x) s_w1t[q] = q < G * W ? w1t[q] : 0.f;
+    __syncthreads();
+    if (blockIdx.x == 0) {                                  // the all-zero row behind the last slot (entries without a mirror image)
+        for (int q = tid; q < W; q += blockDim.x) filt[(size_t)pair_cap * W + q] = 0.f;
+        if (BWD && tid == 0) pair_s[pair_cap] = 0.f;
+    }
+
+    const int col = lane & 15, grp = lane >> 4;
+    float b1v[NCB], b2v[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { b1v[cb] = b1[cb * 16 + col]; b2v[cb] = b2[cb * 16 + col]; }
+    const float mu_step = P.cutoff / (float)(G - 1);
+    const float sig2 = P.sigma_inv * P.sigma_inv;
+    const float gscale = -0.5f * kLog2e * sig2;
+
+    const int pairs = min(half_off[P.N], pair_cap);
+    const int tiles = (pairs + 15) >> 4;
+    const int total_waves = gridDim.x * waves_per_block;
+    int t = blockIdx.x * waves_per_block + wave;
+    auto request = [&](int tile, float& r, int2& ij) {      // lanes 0..15 (the others mirror them)
+        const int p = 16 * tile + (lane & 15);
+        r = -1.f;
+        ij = make_int2(0, 0);
+        if (tile < tiles && p < pairs) {
+            r = half_r[p];
+            if constexpr (BWD) ij = half_ij[p];
+        }
+    };
+    float my_r;
+    int2 my_ij;
+    request(t, my_r, my_ij);
+    for (; t < tiles; t += total_waves) {
+        if (lane < 16) {
+            float r = 1.0f, fc = 0.f, dfc = 0.f;
+            if (my_r >= 0.f) {
+                r = my_r;
+                if constexpr (BWD) {
+                    float sn, cs;
+                    sincospif(r / P.cutoff, &sn, &cs);
+                    fc = 0.5f * cs + 0.5f;                                              // ref :301-303
+                    dfc = -(0.5f * kPi / P.cutoff) * sn;                                // ref :305-307
+                } else {
+                    fc = 0.5f * cospif(r / P.cutoff) + 0.5f;
+                }
+            }
+            ps[lane] = r; ps[16 + lane] = fc;
+            if constexpr (BWD) {
+                ps[32 + lane] = dfc; ps[48 + lane] = 1.0f / r;
+                ps[64 + lane] = __int_as_float(my_ij.x); ps[80 + lane] = __int_as_float(my_ij.y);
+            }
+        }
+        float next_r;
+        int2 next_ij;
+        request(t + total_waves, next_r, next_ij);          // used after the GEMMs
+        wave_fence();
+        // ---- layer 1 (backward: value and d/dr together) ----
+        f32x4 acc[NCB], dacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            acc[cb] = f32x4{b1v[cb], b1v[cb], b1v[cb], b1v[cb]};
+            if constexpr (BWD) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float rp = ps[col];
+        for (int s = 0; s < Gp / 4; s++) {
+            const int g = 4 * s + grp;
+            const float d = rp - (float)g * mu_step;
+            const float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                   // ref :151-154
+            const float da = -d * sig2 * a;                                            // ref :242
+            const float* wrow = s_w1t + g * W + col;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                const float b = wrow[cb * 16];
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[cb], 0, 0, 0);
+                if constexpr (BWD) dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(da, b, dacc[cb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if constexpr (BWD) {
+                    float yv, dact;
+                    activate_d_fast<ACT>(acc[cb][q], yv, dact);
+                    y1[(grp * 4 + q) * YS + cb * 16 + col] = yv;
+                    dacc[cb][q] *= dact;                                               // dY1, kept in registers
+                } else {
+                    y1[(grp * 4 + q) * YS + cb * 16 + col] = activate_fast<ACT>(acc[cb][q]);
+                }
+            }
+        wave_fence();
+        // ---- layer 2 on Y1 ----
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+        mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, acc);
+        if constexpr (BWD) {
+            wave_fence();
+            // ---- refill the tile with dY1, layer 2 again ----
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    y1[(grp * 4 + q) * YS + cb * 16 + col] = dacc[cb][q];
+                    dacc[cb][q] = 0.f;
+                }
+            wave_fence();
+            mfma_layer<NCB, W>(y1 + col * YS + grp, s_w2t + grp * W + col, W / 4, dacc);
+        }
+        // ---- my four pairs of the tile ----
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int rr = grp * 4 + q;
+            const int p = 16 * t + rr;
+            const float fc = ps[16 + rr];
+            if (p < pairs) {                                // uniform over the 16 lanes of a row
+                float* frow = filt + (size_t)p * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) frow[cb * 16] = fc * acc[cb][q];      // ref :175
+                if constexpr (BWD) {
+                    const float dfc = ps[32 + rr];
+                    const int i = __float_as_int(ps[64 + rr]), j = __float_as_int(ps[80 + rr]);
+                    float sc = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) {
+                        const size_t c = (size_t)cb * 16 + col;
+                        const float xi = x[(size_t)i * W + c], gi = gout[(size_t)i * W + c];
+                        const float xj = x[(size_t)j * W + c], gj = gout[(size_t)j * W + c];
+                        const float dy2 = dfc * acc[cb][q] + fc * dacc[cb][q];         // ref :276
+                        sc += dy2 * (xj * gi + xi * gj);                               // ref :286
+                    }
+                    sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
+                    sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+                    if (col == 0) pair_s[p] = sc * ps[48 + rr];
+                }
+            }
+            if constexpr (BWD) __builtin_amdgcn_sched_barrier(0);     // one pair's 4*NCB gathers in flight at a time
+        }
+        my_r = next_r; my_ij = next_ij;
+        wave_fence();
+    }
+}
+
+// Owner-computes gather behind cfconv_filters_mfma: one wave per atom, lanes = filter channels.
+//   forward   out[i]   = sum_e F[pid_e] * x[j_e]                                                     ref :180-183
+//   backward  dE/dx[i] = sum_e F[pid_e] * gout[j_e] ,  dE/dpos[i] = -sum_e s[pid_e] * delta_e        ref :284-291
+template <bool BWD, bool VEC2>
+__global__ __launch_bounds__(256) void cfconv_gather(int N, int W, const float4* __restrict__ rows, const int* __restrict__ cnt,
+                                                     int cap, const int* __restrict__ pid, int pair_cap,
+                                                     const float* __restrict__ filt, const float* __restrict__ pair_s,
+                                                     const float* __restrict__ v, float* __restrict__ out,
+                                                     float* __restrict__ pos_grad, const float4* __restrict__ sorted_pos) {
+    const int lane = lane_id();
+    // atoms in cell order, an XCD taking a contiguous part of it: both ends of a pair then read its filter row through
+    // the same L2, close in time
+    const int k = xcd_contiguous_wave_id();
+    if (k >= N) return;
+    const int i = sorted_pos ? __float_as_int(sorted_pos[k].w) & kIdMask : k;
+    if (i >= N) return;                                     // (a grid that could not be built: check() reports it)
+    const int n = min(cnt[i], cap);
+    float acc0 = 0.f, acc1 = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
+    const int c0 = VEC2 ? 2 * lane : lane, c1 = lane + 64;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        int my_p = pair_cap, my_j = i;                       // (the all-zero filter row)
+        if (e < n) {
+            const float4 rec = rows[(size_t)i * cap + e];
+            my_j = __float_as_int(rec.w) & kIdMask;
+            my_p = pid[(size_t)i * cap + e];
+            if (BWD) {
+                const float sc = pair_s[my_p];
+                fx -= sc * rec.x; fy -= sc * rec.y; fz -= sc * rec.z;
+            }
+        }
+        const int m = min(64, n - e0);
+#pragma unroll 4
+        for (int q = 0; q < m; q++) {
+            const size_t fo = (size_t)__builtin_amdgcn_readlane(my_p, q) * W, vo = (size_t)__builtin_amdgcn_readlane(my_j, q) * W;
+            if (VEC2) {
+                const float2 f = *reinterpret_cast<const float2*>(filt + fo + c0);
+                const float2 u = *reinterpret_cast<const float2*>(v + vo + c0);
+                acc0 += f.x * u.x; acc1 += f.y * u.y;
+            } else {
+                if (c0 < W) acc0 += filt[fo + c0] * v[vo + c0];
+                if (c1 < W) acc1 += filt[fo + c1] * v[vo + c1];
+            }
+        }
+    }
+    if (VEC2) {
+        *reinterpret_cast<float2*>(out + (size_t)i * W + c0) = make_float2(acc0, acc1);
+    } else {
+        if (c0 < W) out[(size_t)i * W + c0] = acc0;
+        if (c1 < W) out[(size_t)i * W + c1] = acc1;
+    }
+    if (BWD) {
+        fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+        if (lane == 0) { pos_grad[3 * i] = fx; pos_grad[3 * i + 1] = fy; pos_grad[3 * i + 2] = fz; }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -805,7 +1194,40 @@ struct nnpops_cfconv_neighbors {
     int* d_hist = nullptr;          // two-kernel cell build (celllist.h)
     int* d_bins = nullptr;
     int bin_cap = 64;
+    // half list behind the rows (scan_half / half_slots): built with the rows once a matrix-core convolution has
+    // asked for it, on demand before that
+    int *d_lo_cnt = nullptr, *d_half_off = nullptr, *d_pid = nullptr;
+    float* d_half_r = nullptr;
+    int2* d_half_ij = nullptr;
+    bool want_half = false, half_built = false;
+    bool cell_ordered = false;      // the last build went through the cell grid: d_sorted_pos lists the atoms in cell order
+    int pair_cap() const { return (int)std::min<size_t>((size_t)N * cap / 2, (size_t)INT32_MAX - 1); }
 };
+
+static int alloc_half(nnpops_cfconv_neighbors* h) {
+    dev_free(h->d_pid); dev_free(h->d_half_r); dev_free(h->d_half_ij);
+    h->d_pid = nullptr; h->d_half_r = nullptr; h->d_half_ij = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&h->d_pid, (size_t)h->N * h->cap))) return rc;
+    if ((rc = dev_alloc(&h->d_half_r, (size_t)h->pair_cap() + 1))) return rc;
+    if ((rc = dev_alloc(&h->d_half_ij, (size_t)h->pair_cap() + 1))) return rc;
+    if (hipMemset(h->d_half_r, 0, sizeof(float) * ((size_t)h->pair_cap() + 1)) != hipSuccess ||
+        hipMemset(h->d_half_ij, 0, sizeof(int2) * ((size_t)h->pair_cap() + 1)) != hipSuccess ||
+        hipMemset(h->d_pid, 0, sizeof(int) * (size_t)h->N * h->cap) != hipSuccess)
+        return fail(NNPOPS_ERR_HIP, "memset failed");
+    return NNPOPS_OK;
+}
+
+// the two launches behind the rows that give every pair its slot
+static int launch_half_build(nnpops_cfconv_neighbors* h, hipStream_t stream) {
+    const float4* order = h->cell_ordered ? h->d_sorted_pos : nullptr;
+    hipLaunchKernelGGL(scan_half, dim3(1), dim3(1024), 0, stream, h->N, h->d_lo_cnt, h->d_half_off);
+    hipLaunchKernelGGL(half_slots, dim3(h->N), dim3(64), 0, stream, h->d_rows, h->d_cnt, h->d_half_off, h->cap, h->pair_cap(),
+                       h->d_pid, h->d_half_r, h->d_half_ij, h->d_status, h->N, order);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    h->half_built = true;
+    return NNPOPS_OK;
+}
 
 struct nnpops_cfconv {
     ConvParams p{};
@@ -818,6 +1240,10 @@ struct nnpops_cfconv {
     float *d_w1t_s = nullptr, *d_b1_s = nullptr, *d_w2t_s = nullptr;
     int blocks = 256;
     bool force_valu = false;        // $NNPOPS_CFCONV_VALU=1: keep the matrix cores out (A/B timing, debugging)
+    bool half_list = true;          // $NNPOPS_CFCONV_HALF=0: matrix-core kernels over the full rows (every pair from both ends)
+    // filter rows F[pid][W] and pair forces s[pid] of the half-list path (+1: the all-zero row); sized on first use
+    float *d_filt = nullptr, *d_pair_s = nullptr;
+    size_t spill_rows = 0;
 };
 
 extern "C" {
@@ -848,6 +1274,11 @@ int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t* out, int num_atoms
         if ((rc = dev_alloc(&h->d_bins, (size_t)kBinnedCells * h->bin_cap))) return cleanup(rc);
         if (hipMemset(h->d_hist, 0, sizeof(int) * (kBinnedCells + 1)) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
     }
+    if ((rc = dev_alloc(&h->d_lo_cnt, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_half_off, (size_t)num_atoms + 1))) return cleanup(rc);
+    if (hipMemset(h->d_lo_cnt, 0, sizeof(int) * num_atoms) != hipSuccess || hipMemset(h->d_half_off, 0, sizeof(int) * ((size_t)num_atoms + 1)) != hipSuccess)
+        return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
+    if ((rc = alloc_half(h))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_atom_cell, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_atom_rank, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_unsorted, (size_t)num_atoms))) return cleanup(rc);
@@ -864,6 +1295,7 @@ int nnpops_cfconv_neighbors_destroy(nnpops_cfconv_neighbors_t h) {
     DeviceGuard guard(h->device);
     dev_free(h->d_rows); dev_free(h->d_cnt); dev_free(h->d_status);
     dev_free(h->d_hist); dev_free(h->d_bins);
+    dev_free(h->d_lo_cnt); dev_free(h->d_half_off); dev_free(h->d_pid); dev_free(h->d_half_r); dev_free(h->d_half_ij);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
     dev_free(h->d_atom_rank); dev_free(h->d_unsorted); dev_free(h->d_sorted); dev_free(h->d_sorted_pos);
     delete h;
@@ -892,17 +1324,20 @@ int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t h, const float* posi
         launch_cell_build(h->stream, N, positions, box, per, h->cutoff, nullptr, cb);
         if (per)
             hipLaunchKernelGGL(rows_cells<true>, dim3(N), dim3(64), 0, h->stream, box, c2, h->d_grid, h->d_cell_start,
-                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status, h->d_hist);
+                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_lo_cnt, h->d_status, h->d_hist);
         else
             hipLaunchKernelGGL(rows_cells<false>, dim3(N), dim3(64), 0, h->stream, box, c2, h->d_grid, h->d_cell_start,
-                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_status, h->d_hist);
+                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->cap, h->d_cnt, h->d_lo_cnt, h->d_status, h->d_hist);
     } else if (per) {
-        hipLaunchKernelGGL(rows_allpairs<true>, dim3(N), dim3(64), 0, h->stream, N, positions, box, c2, h->d_rows, h->cap, h->d_cnt);
+        hipLaunchKernelGGL(rows_allpairs<true>, dim3(N), dim3(64), 0, h->stream, N, positions, box, c2, h->d_rows, h->cap, h->d_cnt, h->d_lo_cnt);
     } else {
-        hipLaunchKernelGGL(rows_allpairs<false>, dim3(N), dim3(64), 0, h->stream, N, positions, box, c2, h->d_rows, h->cap, h->d_cnt);
+        hipLaunchKernelGGL(rows_allpairs<false>, dim3(N), dim3(64), 0, h->stream, N, positions, box, c2, h->d_rows, h->cap, h->d_cnt, h->d_lo_cnt);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     h->built = true;
+    h->half_built = false;
+    h->cell_ordered = use_cells;
+    if (h->want_half) return launch_half_build(h, h->stream);
     return NNPOPS_OK;
 }
 
@@ -939,8 +1374,10 @@ int nnpops_cfconv_neighbors_check(nnpops_cfconv_neighbors_t h, int* num_pairs) {
         const int old = h->cap;
         while (h->cap < st[kStMaxRow]) h->cap *= 2;
         dev_free(h->d_rows);
+        h->d_rows = nullptr;
         int rc = dev_alloc(&h->d_rows, (size_t)h->N * h->cap);
         if (rc != NNPOPS_OK) return rc;
+        if ((rc = alloc_half(h)) != NNPOPS_OK) return rc;
         h->built = false;
         return fail(NNPOPS_ERR_CAPACITY, "neighbour rows overflowed (max %d > %d); capacity grown to %d, call build() again",
                     st[kStMaxRow], old, h->cap);
@@ -1033,6 +1470,7 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->blocks = prop.multiProcessorCount;
     if (const char* e = std::getenv("NNPOPS_CFCONV_VALU")) h->force_valu = std::atoi(e) != 0;
+    if (const char* e = std::getenv("NNPOPS_CFCONV_HALF")) h->half_list = std::atoi(e) != 0;
     *out = h;
     return NNPOPS_OK;
 }
@@ -1042,6 +1480,7 @@ int nnpops_cfconv_destroy(nnpops_cfconv_t h) {
     DeviceGuard guard(h->device);
     dev_free(h->d_w1t); dev_free(h->d_w2t); dev_free(h->d_b1); dev_free(h->d_b2);
     dev_free(h->d_w1t_s); dev_free(h->d_w2t_s); dev_free(h->d_b1_s);
+    dev_free(h->d_filt); dev_free(h->d_pair_s);
     delete h;
     return NNPOPS_OK;
 }
@@ -1108,6 +1547,71 @@ int launch_backward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const fl
     return NNPOPS_OK;
 }
 
+// Half-list path: filters once per pair, then the owner-computes gather.
+int ensure_half_path(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb) {
+    nb->want_half = true;                                   // later builds carry the pair slots along
+    if (!nb->half_built) {
+        const int rc = launch_half_build(nb, h->stream);
+        if (rc != NNPOPS_OK) return rc;
+    }
+    const size_t need = (size_t)nb->pair_cap() + 1;
+    if (h->spill_rows < need) {                             // (first use, or the neighbour rows have grown: not capturable)
+        dev_free(h->d_filt); dev_free(h->d_pair_s);
+        h->d_filt = nullptr; h->d_pair_s = nullptr; h->spill_rows = 0;
+        int rc;
+        if ((rc = dev_alloc(&h->d_filt, need * h->p.W))) return rc;
+        if ((rc = dev_alloc(&h->d_pair_s, need))) return rc;
+        h->spill_rows = need;
+    }
+
+    return NNPOPS_OK;
+}
+
+template <int ACT, int NCB, bool BWD>
+int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out, float* pos_grad) {
+    int rc = ensure_half_path(h, nb);
+    if (rc != NNPOPS_OK) return rc;
+    const int pair_cap = nb->pair_cap();
+    const size_t budget = 160 * 1024 / sizeof(float);
+    const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats_bwd(h->p.W);
+    const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
+    const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
+    auto k = cfconv_filters_mfma<ACT, NCB, BWD>;
+    if (lds > 64 * 1024)
+        NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, h->p, ACT == 0 ? h->d_w1t_s : h->d_w1t,
+                       ACT == 0 ? h->d_b1_s : h->d_b1, ACT == 0 ? h->d_w2t_s : h->d_w2t, h->d_b2, nb->d_half_off, nb->d_half_r,
+                       nb->d_half_ij, pair_cap, x, gout, h->d_filt, h->d_pair_s);
+    const int N = h->p.N;
+    const float* v = BWD ? gout : x;
+    const float4* order = nb->cell_ordered ? nb->d_sorted_pos : nullptr;
+    if (h->p.W == 128)
+        hipLaunchKernelGGL((cfconv_gather<BWD, true>), dim3(div_up(N, 4)), dim3(256), 0, h->stream, N, h->p.W, nb->d_rows, nb->d_cnt,
+                           nb->cap, nb->d_pid, pair_cap, h->d_filt, h->d_pair_s, v, out, pos_grad, order);
+    else
+        hipLaunchKernelGGL((cfconv_gather<BWD, false>), dim3(div_up(N, 4)), dim3(256), 0, h->stream, N, h->p.W, nb->d_rows, nb->d_cnt,
+                           nb->cap, nb->d_pid, pair_cap, h->d_filt, h->d_pair_s, v, out, pos_grad, order);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+template <int ACT, bool BWD>
+int dispatch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out,
+                       float* pos_grad, bool& handled) {
+    handled = true;
+    switch (h->p.W) {
+        case 16:  return launch_half_mfma<ACT, 1, BWD>(h, nb, x, gout, out, pos_grad);
+        case 32:  return launch_half_mfma<ACT, 2, BWD>(h, nb, x, gout, out, pos_grad);
+        case 48:  return launch_half_mfma<ACT, 3, BWD>(h, nb, x, gout, out, pos_grad);
+        case 64:  return launch_half_mfma<ACT, 4, BWD>(h, nb, x, gout, out, pos_grad);
+        case 80:  return launch_half_mfma<ACT, 5, BWD>(h, nb, x, gout, out, pos_grad);
+        case 96:  return launch_half_mfma<ACT, 6, BWD>(h, nb, x, gout, out, pos_grad);
+        case 112: return launch_half_mfma<ACT, 7, BWD>(h, nb, x, gout, out, pos_grad);
+        case 128: return launch_half_mfma<ACT, 8, BWD>(h, nb, x, gout, out, pos_grad);
+        default: handled = false; return NNPOPS_OK;
+    }
+}
+
 template <int ACT>
 int dispatch_backward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* xgrad,
                            float* pos_grad, bool& handled) {
@@ -1144,6 +1648,12 @@ int dispatch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const f
 
 template <bool BWD>
 int dispatch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out, float* pos_grad) {
+    if (!h->force_valu && h->half_list) {
+        bool handled = false;
+        const int rc = h->p.activation == 0 ? dispatch_half_mfma<0, BWD>(h, nb, x, gout, out, pos_grad, handled)
+                                            : dispatch_half_mfma<1, BWD>(h, nb, x, gout, out, pos_grad, handled);
+        if (handled) return rc;
+    }
     if (!BWD && !h->force_valu) {
         bool handled = false;
         const int rc = h->p.activation == 0 ? dispatch_forward_mfma<0>(h, nb, x, out, handled)

@@ -114,3 +114,57 @@ def test_nonperiodic_box_cells():
 def test_triclinic_box():
     pos, _, box = workloads.triclinic_box(700, seed=33)
     _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=3)
+
+
+def test_half_and_full_list_paths_agree(monkeypatch):
+    """The matrix-core widths evaluate the filter network once per pair (filters + owner-computes gather);
+    $NNPOPS_CFCONV_HALF=0 (read at handle creation) keeps the kernels that evaluate every pair from both ends.
+    Both meet the oracle, and each other far inside the parity bar."""
+    pos, _, box = workloads.random_box(1500, seed=51)
+    y_half = _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=11)
+    monkeypatch.setenv("NNPOPS_CFCONV_HALF", "0")
+    y_full = _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=11)
+    assert np.abs(y_half - y_full).max() <= 2e-6 * np.abs(y_full).max()
+    pos, _ = workloads.conformer(120, seed=52)              # all-pairs neighbour search, odd number of column blocks
+    _case(pos, None, 48, 20, 5.0, 0.1, "tanh", seed=12)
+
+
+def test_half_list_follows_rebuilds():
+    """The pair slots are rebuilt with the rows: a second build on moved atoms (different pairs) with the same handles
+    gives what fresh handles give."""
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    n, W, G = 1400, 64, 25
+    pos, _, box = workloads.random_box(n, seed=61)
+    rng = np.random.default_rng(62)
+    moved = (pos + rng.normal(0, 0.8, pos.shape)).astype(np.float32)
+    w1 = (0.3 * rng.standard_normal((W, G))).astype(np.float32); w2 = (0.2 * rng.standard_normal((W, W))).astype(np.float32)
+    b1 = (0.3 * rng.standard_normal(W)).astype(np.float32); b2 = (0.3 * rng.standard_normal(W)).astype(np.float32)
+    x = torch.tensor(rng.standard_normal((n, W)).astype(np.float32), device=DEV)
+    gy = torch.tensor(rng.standard_normal((n, W)).astype(np.float32), device=DEV)
+    tbox = torch.tensor(box, device=DEV)
+
+    def run(nb, cf, p):
+        tp = torch.tensor(p, device=DEV)
+        nb.build(tp, tbox)
+        y = cf.compute(nb, tp, x, tbox)
+        xg, pg = cf.backprop(nb, tp, x, gy, tbox)
+        return y.cpu().numpy(), xg.cpu().numpy(), pg.cpu().numpy()
+
+    nb = CFConvNeighbors(n, 5.0, True)
+    cf = CFConv(n, W, G, 5.0, 0.1, "ssp", w1, b1, w2, b2, periodic=True)
+    first = run(nb, cf, pos)
+    second = run(nb, cf, moved)
+    again = run(nb, cf, pos)
+    fresh = run(CFConvNeighbors(n, 5.0, True), CFConv(n, W, G, 5.0, 0.1, "ssp", w1, b1, w2, b2, periodic=True), moved)
+    for a, b in zip(second, fresh):
+        assert np.array_equal(a, b)                          # same list, same arithmetic: bitwise
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(first[0], second[0])
+
+
+def test_half_list_with_rows_longer_than_a_wave():
+    """Twice the usual density: ~105 neighbours per atom overflow the 64-entry rows, check() grows them to 128 and the
+    pair slots with them; the slot lookup and the gather then walk rows in two passes of 64."""
+    pos, _, box = workloads.random_box(1100, density=0.2, seed=71)
+    _case(pos, box, 32, 16, 5.0, 0.4, "ssp", seed=13)
