@@ -502,9 +502,9 @@ def main_cfconv(args):
         "config": {"workload": f"SchNet CFConv + neighbour list, {n} atoms periodic, W={W}, G={G}, cutoff {cutoff} A, ssp",
                    "half_pairs": pairs},
         "phases_ms": {"build": round(tb, 4), "forward": round(tf, 4), "backward": round(tbw, 4)},
-        "roofline": {"bound": "mfma", "kernel": "cfconv_forward", "achieved": round(flops_fwd / (tf * 1e-3) / 1e12, 3),
+        "roofline": {"bound": "mfma", "kernel": "cfconv_filters_mfma + cfconv_gather (forward)", "achieved": round(flops_fwd / (tf * 1e-3) / 1e12, 3),
                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops_fwd / (tf * 1e-3) / 1e12 / 157.3, 5), "traffic": None,
-                     "note": "algorithmic flops (half-pair count) / measured forward time; fp32 matrix peak"},
+                     "note": "algorithmic flops (half-pair count) / measured forward time (filters kernel + gather kernel); fp32 matrix peak"},
     }
     if not args.no_cpu_baseline:
         import oracle
