@@ -10,18 +10,19 @@
 //
 // How it is laid out for CDNA4 (new design; the reference CUDA code runs one warp per half pair and
 // scatters 2W float atomics per pair):
-//   * OWNER COMPUTES over a FULL neighbour list: atom i walks all its neighbours j and accumulates
-//     out[i] (and, backward, dE/dx[i] and dE/dpos[i]) in registers -- no atomics, no scatter,
-//     deterministic.  Every pair is therefore evaluated from both ends; the filter network is the
-//     same function of r on either side, so this doubles its flops in exchange for removing
-//     2W atomics per pair and all cross-wave traffic.
-//   * widths that are a multiple of 16 (16, 32, ... 128: every SchNet in use) run the two dense layers on the
-//     MATRIX CORES: 16 pairs of one atom x W filters per tile, v_mfma_f32_16x16x4_f32 (exact fp32),
-//     weights resident in LDS, 8 waves per CU (cfconv_forward_mfma / cfconv_backward_mfma below).
-//   * other widths use the vector kernel: one wave per atom, lane = filter channel(s) (up to two per
-//     lane), pairs processed 8 at a time so every weight read from LDS feeds 8 (x2 channels) FMAs.
-//   * the neighbour list (rows of {dx, dy, dz, j}) comes from the shared cell grid (celllist.h), or
-//     from an all-pairs scan for small systems.
+//   * the neighbour build keeps a FULL list (rows of {dx, dy, dz, j} per atom, from the shared cell grid of
+//     celllist.h or an all-pairs scan for small systems) and, behind it, a slot per PAIR that both ends know
+//     (scan_half / half_slots).
+//   * widths that are a multiple of 16 (16, 32, ... 128: every SchNet in use) evaluate the filter network ONCE
+//     per pair on the MATRIX CORES -- 16 pair slots x W filters per tile, v_mfma_f32_16x16x4_f32 (exact fp32),
+//     weights resident in LDS, 8 waves per CU (cfconv_filters_mfma) -- and spill the filter row; an
+//     OWNER-COMPUTES gather (cfconv_gather: one wave per atom, lanes = channels) then accumulates out[i]
+//     (backward: dE/dx[i], dE/dpos[i]) over the atom's full row.  No atomics, no scatter, deterministic.
+//   * the same matrix-core code over the full rows -- every pair evaluated from both ends, nothing spilled --
+//     is kept behind $NNPOPS_CFCONV_HALF=0 (cfconv_forward_mfma / cfconv_backward_mfma).
+//   * other widths use the vector kernel: one wave per atom, lane = filter channel(s), pairs processed 8 at a
+//     time so every weight read from LDS feeds 8 (x2 channels) FMAs; weights streamed through the caches
+//     when they do not fit in LDS (W > 128).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
