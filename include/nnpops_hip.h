@@ -151,7 +151,11 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
                          const float* b2, int device);
 int nnpops_cfconv_destroy(nnpops_cfconv_t h);
 int nnpops_cfconv_set_stream(nnpops_cfconv_t h, void* stream);
-/* input / output: device [num_atoms][width]; output fully overwritten (CFConv.h:169-171). */
+/* input / output: device [num_atoms][width]; output fully overwritten (CFConv.h:169-171).
+ * Widths 16, 32, ... 128 evaluate the filter network once per pair and keep one filter row per pair in a
+ * scratch buffer owned by the convolution (num_atoms * row capacity / 2 rows of `width` floats; 164 MB for 10 000
+ * atoms at width 128): it is allocated by the first compute()/backprop() with a given neighbour list, so run one
+ * step before capturing a HIP graph. */
 int nnpops_cfconv_compute(nnpops_cfconv_t h, nnpops_cfconv_neighbors_t neighbors, const float* positions,
                           const float* box, const float* input, float* output);
 /* output_deriv: device [num_atoms][width]; input_deriv: device [num_atoms][width];
