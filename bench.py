@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="torchani workload: replay the step as one captured HIP graph")
+    ap.add_argument("--graph", action="store_true", help="torchani / cfconv workloads: replay the step as one captured HIP graph")
     ap.add_argument("--nn-layout", default="grouped", choices=["grouped", "reference"],
                     help="torchani workload: species-grouped GEMMs (default) or the reference's per-atom replicated weights")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
@@ -482,25 +482,45 @@ def main_cfconv(args):
         step()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    t0 = time.perf_counter()
-    tb = tf = tbw = 0.0
-    for _ in range(args.steps):
-        ev[0].record(); nb.build(tpos, tbox, check=False)
-        ev[1].record(); cf.compute(nb, tpos, tx, tbox, out)
-        ev[2].record(); cf.backprop(nb, tpos, tx, tg, tbox)
-        ev[3].record()
+    # per-phase times of one eager step
+    ev[0].record(); nb.build(tpos, tbox, check=False)
+    ev[1].record(); cf.compute(nb, tpos, tx, tbox, out)
+    ev[2].record(); eager_xg, eager_pg = cf.backprop(nb, tpos, tx, tg, tbox)
+    ev[3].record()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # per-phase times of the last step (events are re-recorded each iteration)
     tb, tf, tbw = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    if args.graph:
+        # the nine launches of a step as one HIP graph (buffers were sized by the warm-up steps above)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_xg, g_pg = step()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_xg, eager_xg) and torch.equal(g_pg, eager_pg)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    else:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     flops_fwd = 2.0 * (G * W + W * W) * pairs            # per half pair
     out_json = {
         "metric": "CFConv build+forward+backward evaluations/sec, W=128 G=50 cutoff 5 A, 10k-atom periodic box",
         "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SchNet CFConv + neighbour list, {n} atoms periodic, W={W}, G={G}, cutoff {cutoff} A, ssp",
-                   "half_pairs": pairs},
+        "config": {"workload": f"SchNet CFConv + neighbour list, {n} atoms periodic, W={W}, G={G}, cutoff {cutoff} A, ssp"
+                               + (", replayed as one HIP graph" if args.graph else ""), "half_pairs": pairs},
         "phases_ms": {"build": round(tb, 4), "forward": round(tf, 4), "backward": round(tbw, 4)},
         "roofline": {"bound": "mfma", "kernel": "cfconv_filters_mfma + cfconv_gather (forward)", "achieved": round(flops_fwd / (tf * 1e-3) / 1e12, 3),
                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops_fwd / (tf * 1e-3) / 1e12 / 157.3, 5), "traffic": None,
