@@ -20,7 +20,8 @@ def main():
                          "from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
                          "where k.name like ? group by k.name, p.counter_name", (f"%{flt}%",)).fetchall()
         for name, counter, total, ndisp, d in rows:
-            key = name.split("(")[0].replace("void nnpops::", "")[:44]
+            key = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("nnpops::", "")
+            key = key.split("(")[0][:48]
             table[key][counter] = total / ndisp          # chip total per dispatch
             dur[key] = d / 1e3
     for key, counters in table.items():
