@@ -129,6 +129,56 @@ def test_cfconv_random_configuration(seed):
     assert np.abs(gpos.cpu().numpy() - pg_ref).max() <= 1e-4 * max(float(np.abs(pg_ref).max()), 1e-6)
 
 
+@pytest.mark.parametrize("seed", range(6 * SCALE))
+def test_cfconv_random_cell_grid_configuration(seed):
+    """Systems large enough for the cell-grid neighbour search (>= 1024 atoms), matrix-core widths: the pair slots behind
+    the rows, rows that outgrow their capacity at the higher densities, empty space around a non-periodic cloud."""
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    rng = np.random.default_rng(7000 + seed)
+    W = int(rng.choice([16, 32, 48, 64]))
+    G = int(rng.integers(4, 21))
+    act = ["ssp", "tanh"][seed % 2]
+    cutoff = float(rng.uniform(3.5, 5.5))
+    sigma = float(rng.uniform(0.2, 0.6))
+    kind = ["cubic", "triclinic", "open"][seed % 3]
+    n = int(rng.integers(1024, 2200))
+    density = float(rng.choice([0.06, 0.1, 0.2]))
+    pos, box = _random_geometry(rng, n, "triclinic" if kind == "triclinic" else "cubic", density)
+    if kind == "open":
+        box = None
+    periodic = box is not None
+    if periodic and min(box[0, 0], box[1, 1], box[2, 2]) < 3.05 * cutoff:
+        pytest.skip("box below 3 cells")
+    w1 = (0.3 * rng.standard_normal((W, G))).astype(np.float32)
+    w2 = (0.3 * rng.standard_normal((W, W)) / np.sqrt(W)).astype(np.float32)
+    b1 = (0.3 * rng.standard_normal(W)).astype(np.float32)
+    b2 = (0.3 * rng.standard_normal(W)).astype(np.float32)
+    x = rng.standard_normal((n, W)).astype(np.float32)
+    gy = rng.standard_normal((n, W)).astype(np.float32)
+    onb = CFConvNeighborsOracle(n, cutoff, periodic)
+    onb.build(pos, box)
+    ocf = CFConvOracle(n, W, G, cutoff, sigma, act, w1, b1, w2, b2, periodic=periodic)
+    y_ref = ocf.forward(onb, pos, x, box)
+    xg_ref, pg_ref = ocf.backward(onb, pos, x, gy, box)
+    dev = torch.device("cuda:0")
+    tpos = torch.tensor(pos, device=dev)
+    tbox = torch.tensor(box, device=dev) if periodic else None
+    nb = CFConvNeighbors(n, cutoff, periodic=periodic)
+    nb.build(tpos, tbox, check=True)
+    cf = CFConv(n, W, G, cutoff, sigma, act, w1, b1, w2, b2, periodic=periodic)
+    tx, tg = torch.tensor(x, device=dev), torch.tensor(gy, device=dev)
+    y = torch.empty_like(tx)
+    cf.compute(nb, tpos, tx, tbox, y)
+    gx, gpos = cf.backprop(nb, tpos, tx, tg, tbox)
+    atoms, _ = nb.export()
+    start, other, _ = onb.export()
+    assert atoms.shape[1] == len(other)
+    scale_y = max(float(np.abs(y_ref).max()), 1e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, rtol=5e-5, atol=5e-6 * scale_y)
+    np.testing.assert_allclose(gx.cpu().numpy(), xg_ref, rtol=5e-5, atol=5e-6 * max(float(np.abs(xg_ref).max()), 1e-6))
+    assert np.abs(gpos.cpu().numpy() - pg_ref).max() <= 1e-4 * max(float(np.abs(pg_ref).max()), 1e-6)
+
+
 @pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_neighbor_pairs_random_configuration(seed):
     from nnpops_amd.capi import neighbor_pairs_forward
