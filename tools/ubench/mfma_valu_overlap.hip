@@ -74,6 +74,8 @@ __global__ __launch_bounds__(512) void k(float* out, int mode, int iters) {
                 for (int r = 0; r < 8; r++) v[r] = __builtin_fmaf(v[r], a, b);   // 8 v_fma (32 cycles) in each MFMA's shadow
             }
         }
+    } else if (mode & 64) {
+        fma_block(v, a, b, iters);                                  // every wave: two V waves per SIMD
     } else if (first) {
         if (mode & 1) mfma_block(acc, a, b, iters);
         if (mode & 16) hmfma_block(acc, ha, hb, iters);
@@ -107,6 +109,7 @@ int main() {
     run(3, "M on one wave, V on the other wave of the SIMD");
     run(5, "M on one wave, T on the other wave of the SIMD");
     run(8, "one wave: 8 x (MFMA + 8 v_fma)  [2 such waves per SIMD]");
+    run(64, "V on both waves of the SIMD (2 x 64 v_fma / iteration)");
     run(16, "H alone: 16 f16 MFMA 16x16x32 / iteration");
     run(18, "H on one wave, V on the other wave of the SIMD");
     run(20, "H on one wave, T on the other wave of the SIMD");
