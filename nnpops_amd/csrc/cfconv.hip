@@ -1112,6 +1112,244 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_mfma(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// cfconv_filters_h2: the filters kernel with the SECOND layer (W x W: 70 % of the matrix work) on the half-precision
+// matrix instruction, operands split into two fp16 planes so that the result keeps fp32 accuracy:
+//     x = hi + 2^-11 lo'   (hi = fp16(x), lo' = fp16((x - hi) 2^11): 22 significant bits, every plane in normal range)
+//     A B = Ahi Bhi + 2^-11 (Ahi Blo' + Alo' Bhi) + O(2^-22)          -- three v_mfma_f32_16x16x32_f16 per 16x16x32
+//     block (fp32 accumulation, two accumulators) instead of eight v_mfma_f32_16x16x4_f32: 48 instead of 256 issue cycles.
+// Measured on a 16 x 128 x 128 tile (tools/ubench/split_f16_gemm.hip): 2.6x faster than the fp32 form including the
+// split, and a SMALLER error against a double-precision product (1.6e-6 against 3.8e-6 at |y| ~ 9: exact fp16
+// products summed in fp32 versus a chain of 128 rounded fp32 FMAs).  The host only takes this kernel when the weights
+// bound every operand below the fp16 range (nnpops_cfconv_create); $NNPOPS_CFCONV_SPLIT=0 keeps the all-fp32 one.
+//   layer 1   stays v_mfma_f32_16x16x4_f32 but TRANSPOSED (operands swapped: rows = filters, columns = pairs), so a lane
+//             ends up with four consecutive filters of one pair -- after the activation exactly the 8-byte groups the
+//             A planes of layer 2 are written in.  b1 rides along as one more row of W1^T against a constant 1.
+//   LDS       W2 planes [f2][k] and the per-wave A planes [pair][k] with the 16-byte slots of a row rotated by the row
+//             index (conflict-free ds_read_b128 across rows); W1^T fp32 as before.  Same footprint as the fp32 kernel.
+// ---------------------------------------------------------------------------------------------
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+__host__ __device__ inline int h2_l1_rows(int G) { return ((G + 1) + 3) & ~3; }            // Gaussians + the bias row, padded to 4
+__host__ __device__ inline size_t h2_weight_bytes(int W, int G) { return (size_t)2 * W * W * 2 + (size_t)h2_l1_rows(G) * W * 4; }
+__host__ __device__ inline size_t h2_wave_bytes(int W) { return (size_t)2 * 16 * W * 2 + 144 * 4; }
+
+// byte offset of the 16-byte slot `slot` of row `row` in a plane whose rows hold W halves
+template <int W>
+__device__ __forceinline__ int h2_slot(int row, int slot) { return row * (2 * W) + ((slot + row) % (W / 8)) * 16; }
+
+__device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) { return (_Float16)((v - (float)hi) * kLoScale); }
+
+// D = A B for one 16-row tile against all NCB column blocks: acc1 += Ahi Bhi, acc2 += Ahi Blo' + Alo' Bhi
+template <int NCB, int W>
+__device__ __forceinline__ void h2_layer(const char* a_h, const char* a_l, const char* b_h, const char* b_l, int row, int grp, int col,
+                                         f32x4 (&acc1)[NCB], f32x4 (&acc2)[NCB]) {
+#pragma unroll
+    for (int s = 0; s < W / 32; s++) {
+        const int slot = 4 * s + grp;                       // this lane's 8 consecutive k of the step
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(a_h + h2_slot<W>(row, slot));
+        const f16x8 al = *reinterpret_cast<const f16x8*>(a_l + h2_slot<W>(row, slot));
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            const int f2 = cb * 16 + col;
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(b_h + h2_slot<W>(f2, slot));
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(b_l + h2_slot<W>(f2, slot));
+            acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc1[cb], 0, 0, 0);
+            acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc2[cb], 0, 0, 0);
+            acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc2[cb], 0, 0, 0);
+        }
+    }
+}
+
+template <int ACT, int NCB, bool BWD>
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
+    ConvParams P, const float* __restrict__ w1b, const _Float16* __restrict__ w2h, const _Float16* __restrict__ w2l,
+    const float* __restrict__ b2, const int* __restrict__ half_off, const float* __restrict__ half_r,
+    const int2* __restrict__ half_ij, int pair_cap, const float* __restrict__ x, const float* __restrict__ gout,
+    float* __restrict__ filt, float* __restrict__ pair_s) {
+    constexpr int W = NCB * 16;
+    static_assert(W % 32 == 0, "the K steps of layer 2 are 32 wide");
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int G = P.G, Gq = h2_l1_rows(G);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    char* s_w2h = ldsb;                                      // [W][W] halves, slots rotated
+    char* s_w2l = s_w2h + (size_t)W * W * 2;
+    float* s_w1t = reinterpret_cast<float*>(s_w2l + (size_t)W * W * 2);     // [Gq][W]: rows < G = W1^T, row G = b1, rest 0
+    char* a_h = reinterpret_cast<char*>(s_w1t + (size_t)Gq * W) + (size_t)wave * h2_wave_bytes(W);
+    char* a_l = a_h + 16 * W * 2;
+    float* ps = reinterpret_cast<float*>(a_l + 16 * W * 2);  // r | fc | dfc | 1/r | i | j, 16 each
+    for (int q = tid; q < W * (W / 8); q += blockDim.x) {    // 16-byte slots of the W2 planes
+        const int f2 = q / (W / 8), slot = q % (W / 8);
+        *reinterpret_cast<f16x8*>(s_w2h + h2_slot<W>(f2, slot)) = *reinterpret_cast<const f16x8*>(w2h + (size_t)f2 * W + slot * 8);
+        *reinterpret_cast<f16x8*>(s_w2l + h2_slot<W>(f2, slot)) = *reinterpret_cast<const f16x8*>(w2l + (size_t)f2 * W + slot * 8);
+    }
+    for (int q = tid; q < Gq * W; q += blockDim.x) s_w1t[q] = w1b[q];
+    __syncthreads();
+    if (blockIdx.x == 0) {                                  // the all-zero row behind the last slot (entries without a mirror image)
+        for (int q = tid; q < W; q += blockDim.x) filt[(size_t)pair_cap * W + q] = 0.f;
+        if (BWD && tid == 0) pair_s[pair_cap] = 0.f;
+    }
+
+    const int col = lane & 15, grp = lane >> 4;
+    float b2v[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) b2v[cb] = b2[cb * 16 + col];
+    const float mu_step = P.cutoff / (float)(G - 1);
+    const float sig2 = P.sigma_inv * P.sigma_inv;
+    const float gscale = -0.5f * kLog2e * sig2;
+
+    const int pairs = min(half_off[P.N], pair_cap);
+    const int tiles = (pairs + 15) >> 4;
+    const int total_waves = gridDim.x * waves_per_block;
+    int t = blockIdx.x * waves_per_block + wave;
+    auto request = [&](int tile, float& r, int2& ij) {      // lanes 0..15 (the others mirror them)
+        const int p = 16 * tile + (lane & 15);
+        r = -1.f;
+        ij = make_int2(0, 0);
+        if (tile < tiles && p < pairs) {
+            r = half_r[p];
+            if constexpr (BWD) ij = half_ij[p];
+        }
+    };
+    float my_r;
+    int2 my_ij;
+    request(t, my_r, my_ij);
+    for (; t < tiles; t += total_waves) {
+        if (lane < 16) {
+            float r = 1.0f, fc = 0.f, dfc = 0.f;
+            if (my_r >= 0.f) {
+                r = my_r;
+                if constexpr (BWD) {
+                    float sn, cs;
+                    sincospif(r / P.cutoff, &sn, &cs);
+                    fc = 0.5f * cs + 0.5f;                                              // ref :301-303
+                    dfc = -(0.5f * kPi / P.cutoff) * sn;                                // ref :305-307
+                } else {
+                    fc = 0.5f * cospif(r / P.cutoff) + 0.5f;
+                }
+            }
+            ps[lane] = r; ps[16 + lane] = fc;
+            if constexpr (BWD) {
+                ps[32 + lane] = dfc; ps[48 + lane] = 1.0f / r;
+                ps[64 + lane] = __int_as_float(my_ij.x); ps[80 + lane] = __int_as_float(my_ij.y);
+            }
+        }
+        float next_r;
+        int2 next_ij;
+        request(t + total_waves, next_r, next_ij);          // used after the GEMMs
+        wave_fence();
+        // ---- layer 1, transposed: acc[cb][q] = S1 of filter 16 cb + 4 grp + q for the pair `col` ----
+        f32x4 acc[NCB], dacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BWD) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float rp = ps[col];
+        for (int s = 0; s < Gq / 4; s++) {
+            const int g = 4 * s + grp;
+            const float d = rp - (float)g * mu_step;
+            float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                         // ref :151-154
+            float da = -d * sig2 * a;                                                  // ref :242
+            if (g == G) { a = 1.0f; da = 0.f; }                                        // the bias row
+            const float* wrow = s_w1t + g * W + col;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                const float w = wrow[cb * 16];
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, a, acc[cb], 0, 0, 0);
+                if constexpr (BWD) dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, da, dacc[cb], 0, 0, 0);
+            }
+        }
+        // ---- activation, split, A planes: pair `col`, filters 16 cb + 4 grp .. + 3 = half a 16-byte slot ----
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            f16x4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float yv;
+                if constexpr (BWD) {
+                    float dact;
+                    activate_d_fast<ACT>(acc[cb][q], yv, dact);
+                    dacc[cb][q] *= dact;                                               // dY1, kept in registers
+                } else {
+                    yv = activate_fast<ACT>(acc[cb][q]);
+                }
+                h[q] = (_Float16)yv;
+                l[q] = split_lo(yv, h[q]);
+            }
+            const int off = h2_slot<W>(col, 2 * cb + (grp >> 1)) + (grp & 1) * 8;
+            *reinterpret_cast<f16x4*>(a_h + off) = h;
+            *reinterpret_cast<f16x4*>(a_l + off) = l;
+        }
+        wave_fence();
+        // ---- layer 2 on Y1: S2[pair 4 grp + q][filter 16 cb + col] ----
+        f32x4 acc2[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+            acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        h2_layer<NCB, W>(a_h, a_l, s_w2h, s_w2l, col, grp, col, acc, acc2);
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] += kLoInv * acc2[cb];
+        if constexpr (BWD) {
+            wave_fence();
+            // ---- refill the planes with dY1, layer 2 again ----
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                f16x4 h, l;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    h[q] = (_Float16)dacc[cb][q];
+                    l[q] = split_lo(dacc[cb][q], h[q]);
+                }
+                const int off = h2_slot<W>(col, 2 * cb + (grp >> 1)) + (grp & 1) * 8;
+                *reinterpret_cast<f16x4*>(a_h + off) = h;
+                *reinterpret_cast<f16x4*>(a_l + off) = l;
+                dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            wave_fence();
+            h2_layer<NCB, W>(a_h, a_l, s_w2h, s_w2l, col, grp, col, dacc, acc2);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) dacc[cb] += kLoInv * acc2[cb];
+        }
+        // ---- my four pairs of the tile ----
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int rr = grp * 4 + q;
+            const int p = 16 * t + rr;
+            const float fc = ps[16 + rr];
+            if (p < pairs) {                                // uniform over the 16 lanes of a row
+                float* frow = filt + (size_t)p * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) frow[cb * 16] = fc * acc[cb][q];      // ref :175
+                if constexpr (BWD) {
+                    const float dfc = ps[32 + rr];
+                    const int i = __float_as_int(ps[64 + rr]), j = __float_as_int(ps[80 + rr]);
+                    float sc = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) {
+                        const size_t c = (size_t)cb * 16 + col;
+                        const float xi = x[(size_t)i * W + c], gi = gout[(size_t)i * W + c];
+                        const float xj = x[(size_t)j * W + c], gj = gout[(size_t)j * W + c];
+                        const float dy2 = dfc * acc[cb][q] + fc * dacc[cb][q];         // ref :276
+                        sc += dy2 * (xj * gi + xi * gj);                               // ref :286
+                    }
+                    sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
+                    sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+                    if (col == 0) pair_s[p] = sc * ps[48 + rr];
+                }
+            }
+            if constexpr (BWD) __builtin_amdgcn_sched_barrier(0);     // one pair's 4*NCB gathers in flight at a time
+        }
+        my_r = next_r; my_ij = next_ij;
+        wave_fence();
+    }
+}
+
 // Owner-computes gather behind cfconv_filters_mfma: one wave per atom, lanes = filter channels.
 //   forward   out[i]   = sum_e F[pid_e] * x[j_e]                                                     ref :180-183
 //   backward  dE/dx[i] = sum_e F[pid_e] * gout[j_e] ,  dE/dpos[i] = -sum_e s[pid_e] * delta_e        ref :284-291
@@ -1244,6 +1482,11 @@ struct nnpops_cfconv {
     int blocks = 256;
     bool force_valu = false;        // $NNPOPS_CFCONV_VALU=1: keep the matrix cores out (A/B timing, debugging)
     bool half_list = true;          // $NNPOPS_CFCONV_HALF=0: matrix-core kernels over the full rows (every pair from both ends)
+    // split-fp16 second layer (cfconv_filters_h2): W1^T with the bias row, the two fp16 planes of W2 [out][in];
+    // split_ok = width a multiple of 32 and every operand provably inside the fp16 range ($NNPOPS_CFCONV_SPLIT=0: never)
+    float* d_w1b = nullptr;
+    _Float16 *d_w2h = nullptr, *d_w2l = nullptr;
+    bool split_ok = false;
     // filter rows F[pid][W] and pair forces s[pid] of the half-list path (+1: the all-zero row); sized on first use
     float *d_filt = nullptr, *d_pair_s = nullptr;
     size_t spill_rows = 0;
@@ -1470,6 +1713,44 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
             hipMemcpy(h->d_b1_s, b1s.data(), (size_t)W * 4, hipMemcpyHostToDevice) != hipSuccess)
             return cleanup(fail(NNPOPS_ERR_HIP, "weight upload failed"));
     }
+    if (W % 32 == 0 && W <= 128) {
+        // operands of the split-fp16 second layer, in the scaled domain the kernels work in (see activate_fast)
+        const float s1 = activation == 0 ? kLog2e : 1.0f, s2 = activation == 0 ? 1.0f / kLog2e : 1.0f;
+        const int Gq = h2_l1_rows(G);
+        std::vector<float> w1b((size_t)Gq * W, 0.f);
+        std::vector<_Float16> w2h((size_t)W * W), w2l((size_t)W * W);
+        double max_w2 = 0, max_y = 0, max_dy = 0;
+        for (int f = 0; f < W; f++) {
+            double row = 0;
+            for (int g = 0; g < G; g++) {
+                w1b[(size_t)g * W + f] = s1 * w1[(size_t)f * G + g];
+                row += std::fabs((double)s1 * w1[(size_t)f * G + g]);
+            }
+            w1b[(size_t)G * W + f] = s1 * b1[f];
+            max_y = std::max(max_y, row + std::fabs((double)s1 * b1[f]) + 1.0);     // |act(s)| <= |s| + 1 in either domain
+            max_dy = std::max(max_dy, row * 0.61 / gaussian_width);                  // |d gamma / dr| <= 0.607 / sigma, act' <= 1
+        }
+        for (int f2 = 0; f2 < W; f2++)
+            for (int k = 0; k < W; k++) {
+                const float v = s2 * w2[(size_t)f2 * W + k];
+                const _Float16 hi = (_Float16)v;
+                w2h[(size_t)f2 * W + k] = hi;
+                w2l[(size_t)f2 * W + k] = (_Float16)((v - (float)hi) * kLoScale);
+                max_w2 = std::max(max_w2, (double)std::fabs(v));
+            }
+        const double limit = 3.0e4;                         // fp16 holds 65504; the low planes stay below 32 in any case
+        h->split_ok = max_w2 < limit && max_y < limit && max_dy < limit;
+        if (const char* e = std::getenv("NNPOPS_CFCONV_SPLIT")) h->split_ok = h->split_ok && std::atoi(e) != 0;
+        if (h->split_ok) {
+            if ((rc = dev_alloc(&h->d_w1b, w1b.size()))) return cleanup(rc);
+            if ((rc = dev_alloc(&h->d_w2h, w2h.size()))) return cleanup(rc);
+            if ((rc = dev_alloc(&h->d_w2l, w2l.size()))) return cleanup(rc);
+            if (hipMemcpy(h->d_w1b, w1b.data(), w1b.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(h->d_w2h, w2h.data(), w2h.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(h->d_w2l, w2l.data(), w2l.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                return cleanup(fail(NNPOPS_ERR_HIP, "weight upload failed"));
+        }
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->blocks = prop.multiProcessorCount;
     if (const char* e = std::getenv("NNPOPS_CFCONV_VALU")) h->force_valu = std::atoi(e) != 0;
@@ -1484,6 +1765,7 @@ int nnpops_cfconv_destroy(nnpops_cfconv_t h) {
     dev_free(h->d_w1t); dev_free(h->d_w2t); dev_free(h->d_b1); dev_free(h->d_b2);
     dev_free(h->d_w1t_s); dev_free(h->d_w2t_s); dev_free(h->d_b1_s);
     dev_free(h->d_filt); dev_free(h->d_pair_s);
+    dev_free(h->d_w1b); dev_free(h->d_w2h); dev_free(h->d_w2l);
     delete h;
     return NNPOPS_OK;
 }
@@ -1575,16 +1857,35 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
     int rc = ensure_half_path(h, nb);
     if (rc != NNPOPS_OK) return rc;
     const int pair_cap = nb->pair_cap();
-    const size_t budget = 160 * 1024 / sizeof(float);
-    const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats_bwd(h->p.W);
-    const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
-    const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
-    auto k = cfconv_filters_mfma<ACT, NCB, BWD>;
-    if (lds > 64 * 1024)
-        NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, h->p, ACT == 0 ? h->d_w1t_s : h->d_w1t,
-                       ACT == 0 ? h->d_b1_s : h->d_b1, ACT == 0 ? h->d_w2t_s : h->d_w2t, h->d_b2, nb->d_half_off, nb->d_half_r,
-                       nb->d_half_ij, pair_cap, x, gout, h->d_filt, h->d_pair_s);
+    bool launched = false;
+    if constexpr (NCB % 2 == 0) {
+        if (h->split_ok) {                                  // second layer as split-fp16 matrix products
+            const size_t budget = 160 * 1024;
+            const size_t wb = h2_weight_bytes(h->p.W, h->p.G), per_wave = h2_wave_bytes(h->p.W);
+            if (wb + per_wave <= budget) {
+                const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wb) / per_wave);
+                const size_t lds = wb + (size_t)wpb * per_wave;
+                auto k = cfconv_filters_h2<ACT, NCB, BWD>;
+                if (lds > 64 * 1024)
+                    NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1b, h->d_w2h, h->d_w2l, h->d_b2,
+                                   nb->d_half_off, nb->d_half_r, nb->d_half_ij, pair_cap, x, gout, h->d_filt, h->d_pair_s);
+                launched = true;
+            }
+        }
+    }
+    if (!launched) {
+        const size_t budget = 160 * 1024 / sizeof(float);
+        const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats_bwd(h->p.W);
+        const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wfl) / per_wave);
+        const size_t lds = (wfl + (size_t)wpb * per_wave) * sizeof(float);
+        auto k = cfconv_filters_mfma<ACT, NCB, BWD>;
+        if (lds > 64 * 1024)
+            NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, h->p, ACT == 0 ? h->d_w1t_s : h->d_w1t,
+                           ACT == 0 ? h->d_b1_s : h->d_b1, ACT == 0 ? h->d_w2t_s : h->d_w2t, h->d_b2, nb->d_half_off, nb->d_half_r,
+                           nb->d_half_ij, pair_cap, x, gout, h->d_filt, h->d_pair_s);
+    }
     const int N = h->p.N;
     const float* v = BWD ? gout : x;
     const float4* order = nb->cell_ordered ? nb->d_sorted_pos : nullptr;

@@ -12,7 +12,7 @@ OUT_RTOL, OUT_ATOL_FRAC = 2e-5, 2e-6       # |diff| <= rtol*|ref| + atol_frac*ma
 FORCE_RTOL = 1e-4                          # relative to the largest force component
 
 
-def _case(pos, box, W, G, cutoff, sigma, act, seed=0, w=None):
+def _case(pos, box, W, G, cutoff, sigma, act, seed=0, w=None, keep=None):
     from nnpops_amd.capi import CFConv, CFConvNeighbors
     n = pos.shape[0]
     rng = np.random.default_rng(seed)
@@ -56,6 +56,8 @@ def _case(pos, box, W, G, cutoff, sigma, act, seed=0, w=None):
     e_ref = float((y_ref.astype(np.float64) * gy).sum())
     e = float((y.astype(np.float64) * gy).sum())
     assert abs(e - e_ref) <= 1e-5 * float(np.abs(y_ref.astype(np.float64) * gy).sum())
+    if keep is not None:
+        keep.update(y=y, xg=xg, pg=pg, y_ref=y_ref, xg_ref=xg_ref, pg_ref=pg_ref)
     return y
 
 
@@ -168,3 +170,37 @@ def test_half_list_with_rows_longer_than_a_wave():
     pair slots with them; the slot lookup and the gather then walk rows in two passes of 64."""
     pos, _, box = workloads.random_box(1100, density=0.2, seed=71)
     _case(pos, box, 32, 16, 5.0, 0.4, "ssp", seed=13)
+
+
+def test_split_fp16_second_layer_is_as_accurate_as_fp32(monkeypatch):
+    """Widths 32/64/96/128 run the W x W layer as split-fp16 matrix products (x = hi + 2^-11 lo', three
+    v_mfma_f32_16x16x32_f16 per block, fp32 accumulation); $NNPOPS_CFCONV_SPLIT=0 keeps the fp32 matrix instruction.
+    Both meet the oracle under the same bar, and the split form is not the less accurate of the two."""
+    pos, _, box = workloads.random_box(1500, seed=81)
+    split, plain = {}, {}
+    _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=21, keep=split)
+    monkeypatch.setenv("NNPOPS_CFCONV_SPLIT", "0")
+    _case(pos, box, 128, 50, 5.0, 0.1, "ssp", seed=21, keep=plain)
+    for key in ("y", "xg", "pg"):
+        ref = split[key + "_ref"].astype(np.float64)
+        err_split = np.abs(split[key] - ref).max() / np.abs(ref).max()
+        err_plain = np.abs(plain[key] - ref).max() / np.abs(ref).max()
+        assert err_split <= 2.0 * err_plain + 2e-7, (key, err_split, err_plain)
+    monkeypatch.delenv("NNPOPS_CFCONV_SPLIT")
+    pos, _ = workloads.conformer(150, seed=82)
+    _case(pos, None, 96, 33, 5.0, 0.2, "tanh", seed=22)
+    _case(pos, None, 32, 9, 4.0, 0.3, "ssp", seed=23)
+
+
+def test_weights_outside_the_fp16_range_keep_the_fp32_layer():
+    """The split form is only taken when the weights bound every operand below the fp16 range (checked when the handle is
+    created); layers with very large weights go through the fp32 matrix instruction and still match."""
+    pos, _ = workloads.conformer(130, seed=83)
+    n, W, G = len(pos), 64, 20
+    rng = np.random.default_rng(84)
+    w1 = (0.3 * rng.standard_normal((W, G))).astype(np.float32)
+    w2 = (2.0e4 * rng.standard_normal((W, W))).astype(np.float32)          # max |W2| ~ 7e4: beyond fp16
+    b1 = (0.3 * rng.standard_normal(W)).astype(np.float32)
+    b2 = (0.3 * rng.standard_normal(W)).astype(np.float32)
+    x = rng.standard_normal((n, W)).astype(np.float32)
+    _case(pos, None, W, G, 5.0, 0.3, "tanh", seed=24, w=(w1, b1, w2, b2, x))
