@@ -514,15 +514,17 @@ def main_cfconv(args):
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     flops_fwd = 2.0 * (G * W + W * W) * pairs            # per half pair
+    split = os.environ.get("NNPOPS_CFCONV_SPLIT", "1") != "0" and os.environ.get("NNPOPS_CFCONV_HALF", "1") != "0"
     out_json = {
         "metric": "CFConv build+forward+backward evaluations/sec, W=128 G=50 cutoff 5 A, 10k-atom periodic box",
         "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" + (" (W x W layer: operands split into two fp16 planes, products exact, fp32 accumulation)" if split else ""),
+        "data": "synthetic",
         "config": {"workload": f"SchNet CFConv + neighbour list, {n} atoms periodic, W={W}, G={G}, cutoff {cutoff} A, ssp"
                                + (", replayed as one HIP graph" if args.graph else ""), "half_pairs": pairs},
         "phases_ms": {"build": round(tb, 4), "forward": round(tf, 4), "backward": round(tbw, 4)},
-        "roofline": {"bound": "mfma", "kernel": "cfconv_filters_mfma + cfconv_gather (forward)", "achieved": round(flops_fwd / (tf * 1e-3) / 1e12, 3),
+        "roofline": {"bound": "mfma", "kernel": ("cfconv_filters_h2" if split else "cfconv_filters_mfma") + " + cfconv_gather (forward)", "achieved": round(flops_fwd / (tf * 1e-3) / 1e12, 3),
                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops_fwd / (tf * 1e-3) / 1e12 / 157.3, 5), "traffic": None,
                      "note": "algorithmic flops (half-pair count) / measured forward time (filters kernel + gather kernel); fp32 matrix peak"},
     }
