@@ -15,7 +15,8 @@
 //     (scan_half / half_slots).
 //   * widths that are a multiple of 16 (16, 32, ... 128: every SchNet in use) evaluate the filter network ONCE
 //     per pair on the MATRIX CORES -- 16 pair slots x W filters per tile, v_mfma_f32_16x16x4_f32 (exact fp32),
-//     weights resident in LDS, 8 waves per CU (cfconv_filters_mfma) -- and spill the filter row; an
+//     weights resident in LDS, 8 waves per CU (cfconv_filters_mfma; cfconv_filters_h2 runs the W x W layer as
+//     split-fp16 products, three v_mfma_f32_16x16x32_f16 in place of eight fp32 ones) -- and spill the filter row; an
 //     OWNER-COMPUTES gather (cfconv_gather: one wave per atom, lanes = channels) then accumulates out[i]
 //     (backward: dE/dx[i], dE/dpos[i]) over the atom's full row.  No atomics, no scatter, deterministic.
 //   * the same matrix-core code over the full rows -- every pair evaluated from both ends, nothing spilled --
