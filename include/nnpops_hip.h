@@ -155,7 +155,7 @@ int nnpops_cfconv_set_stream(nnpops_cfconv_t h, void* stream);
  * Widths 16, 32, ... 128 evaluate the filter network once per pair and keep one filter row per pair in a
  * scratch buffer owned by the convolution (num_atoms * row capacity / 2 rows of `width` floats; 164 MB for 10 000
  * atoms at width 128): it is allocated by the first compute()/backprop() with a given neighbour list, so run one
- * step before capturing a HIP graph.  For widths 32, 64, 96, 128 the width x width layer is evaluated as split-fp16
+ * step before capturing a HIP graph.  For widths 32, 64, 96, 128 the dense layers are evaluated as split-fp16
  * matrix products with fp32 accumulation (every fp32 operand = two fp16 planes, 22 significant bits; at least as
  * accurate as a chain of fp32 FMAs) whenever the weights keep all operands inside the fp16 range; otherwise, or with
  * NNPOPS_CFCONV_SPLIT=0 in the environment at creation, on the fp32 matrix instruction. */

@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "celllist.h"
@@ -1135,7 +1136,12 @@ constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
 __host__ __device__ inline int h2_l1_rows(int G) { return ((G + 1) + 3) & ~3; }            // Gaussians + the bias row, padded to 4
 __host__ __device__ inline size_t h2_weight_bytes(int W, int G) { return (size_t)2 * W * W * 2 + (size_t)h2_l1_rows(G) * W * 4; }
-__host__ __device__ inline size_t h2_wave_bytes(int W) { return (size_t)2 * 16 * W * 2 + 144 * 4; }
+__host__ __device__ inline size_t h2_wave_bytes(int W) { return (size_t)2 * 16 * W * 2 + 96 * 4; }
+// layer 1 as split products too (L1H): W1 planes [filter][k], k = Gaussians then the bias, rows an ODD number of 16-byte
+// slots long (neighbouring rows then start 4 * odd banks apart: ds_read_b128 across rows is conflict-free without a swizzle)
+__host__ __device__ inline int h2_l1_slots(int G) { return (G + 1 + 7) >> 3; }
+__host__ __device__ inline int h2_l1_row_bytes(int G) { return (h2_l1_slots(G) | 1) * 16; }
+__host__ __device__ inline size_t h2_weight_bytes_l1h(int W, int G) { return (size_t)2 * W * W * 2 + (size_t)2 * W * h2_l1_row_bytes(G); }
 
 // byte offset of the 16-byte slot `slot` of row `row` in a plane whose rows hold W halves
 template <int W>
@@ -1144,11 +1150,10 @@ __device__ __forceinline__ int h2_slot(int row, int slot) { return row * (2 * W)
 __device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) { return (_Float16)((v - (float)hi) * kLoScale); }
 
 // D = A B for one 16-row tile against all NCB column blocks: acc1 += Ahi Bhi, acc2 += Ahi Blo' + Alo' Bhi
-template <int NCB, int W>
+template <int NCB, int W, bool TIGHT = false>             // TIGHT (backward): one K step's 2 + 2 NCB plane reads in flight, not two steps'
 __device__ __forceinline__ void h2_layer(const char* a_h, const char* a_l, const char* b_h, const char* b_l, int row, int grp, int col,
                                          f32x4 (&acc1)[NCB], f32x4 (&acc2)[NCB]) {
-#pragma unroll
-    for (int s = 0; s < W / 32; s++) {
+    auto step = [&](int s) {
         const int slot = 4 * s + grp;                       // this lane's 8 consecutive k of the step
         const f16x8 ah = *reinterpret_cast<const f16x8*>(a_h + h2_slot<W>(row, slot));
         const f16x8 al = *reinterpret_cast<const f16x8*>(a_l + h2_slot<W>(row, slot));
@@ -1161,13 +1166,20 @@ __device__ __forceinline__ void h2_layer(const char* a_h, const char* a_l, const
             acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc2[cb], 0, 0, 0);
             acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc2[cb], 0, 0, 0);
         }
+    };
+    if constexpr (TIGHT) {
+#pragma unroll 1
+        for (int s = 0; s < W / 32; s++) step(s);
+    } else {
+#pragma unroll
+        for (int s = 0; s < W / 32; s++) step(s);
     }
 }
 
-template <int ACT, int NCB, bool BWD>
+template <int ACT, int NCB, bool BWD, bool L1H>
 __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
-    ConvParams P, const float* __restrict__ w1b, const _Float16* __restrict__ w2h, const _Float16* __restrict__ w2l,
-    const float* __restrict__ b2, const int* __restrict__ half_off, const float* __restrict__ half_r,
+    ConvParams P, const float* __restrict__ w1b, const _Float16* __restrict__ w1h, const _Float16* __restrict__ w1l,
+    const _Float16* __restrict__ w2h, const _Float16* __restrict__ w2l, const float* __restrict__ b2, const int* __restrict__ half_off, const float* __restrict__ half_r,
     const int2* __restrict__ half_ij, int pair_cap, const float* __restrict__ x, const float* __restrict__ gout,
     float* __restrict__ filt, float* __restrict__ pair_s) {
     constexpr int W = NCB * 16;
@@ -1178,7 +1190,10 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
     char* s_w2h = ldsb;                                      // [W][W] halves, slots rotated
     char* s_w2l = s_w2h + (size_t)W * W * 2;
     float* s_w1t = reinterpret_cast<float*>(s_w2l + (size_t)W * W * 2);     // [Gq][W]: rows < G = W1^T, row G = b1, rest 0
-    char* a_h = reinterpret_cast<char*>(s_w1t + (size_t)Gq * W) + (size_t)wave * h2_wave_bytes(W);
+    const int row1 = h2_l1_row_bytes(G), slots1 = h2_l1_slots(G);           // L1H: W1 planes instead, [W][row1 bytes]
+    char* s_w1h = reinterpret_cast<char*>(s_w1t);
+    char* s_w1l = s_w1h + (size_t)W * row1;
+    char* a_h = (L1H ? s_w1l + (size_t)W * row1 : reinterpret_cast<char*>(s_w1t + (size_t)Gq * W)) + (size_t)wave * h2_wave_bytes(W);
     char* a_l = a_h + 16 * W * 2;
     float* ps = reinterpret_cast<float*>(a_l + 16 * W * 2);  // r | fc | dfc | 1/r | i | j, 16 each
     for (int q = tid; q < W * (W / 8); q += blockDim.x) {    // 16-byte slots of the W2 planes
@@ -1186,7 +1201,14 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
         *reinterpret_cast<f16x8*>(s_w2h + h2_slot<W>(f2, slot)) = *reinterpret_cast<const f16x8*>(w2h + (size_t)f2 * W + slot * 8);
         *reinterpret_cast<f16x8*>(s_w2l + h2_slot<W>(f2, slot)) = *reinterpret_cast<const f16x8*>(w2l + (size_t)f2 * W + slot * 8);
     }
-    for (int q = tid; q < Gq * W; q += blockDim.x) s_w1t[q] = w1b[q];
+    if constexpr (L1H) {
+        for (int q = tid; q < W * (row1 / 16); q += blockDim.x) {
+            reinterpret_cast<f16x8*>(s_w1h)[q] = reinterpret_cast<const f16x8*>(w1h)[q];
+            reinterpret_cast<f16x8*>(s_w1l)[q] = reinterpret_cast<const f16x8*>(w1l)[q];
+        }
+    } else {
+        for (int q = tid; q < Gq * W; q += blockDim.x) s_w1t[q] = w1b[q];
+    }
     __syncthreads();
     if (blockIdx.x == 0) {                                  // the all-zero row behind the last slot (entries without a mirror image)
         for (int q = tid; q < W; q += blockDim.x) filt[(size_t)pair_cap * W + q] = 0.f;
@@ -1194,7 +1216,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
     }
 
     const int col = lane & 15, grp = lane >> 4;
-    float b2v[NCB];
+    float b2v[NCB];                                         // (backward: re-read per tile, the registers are needed)
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) b2v[cb] = b2[cb * 16 + col];
     const float mu_step = P.cutoff / (float)(G - 1);
@@ -1246,21 +1268,68 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) {
             acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BWD) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BWD && !L1H) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const float rp = ps[col];
-        for (int s = 0; s < Gq / 4; s++) {
-            const int g = 4 * s + grp;
-            const float d = rp - (float)g * mu_step;
-            float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                         // ref :151-154
-            float da = -d * sig2 * a;                                                  // ref :242
-            if (g == G) { a = 1.0f; da = 0.f; }                                        // the bias row
-            const float* wrow = s_w1t + g * W + col;
+        if constexpr (L1H) {
+            // split products here too: B = the Gaussians of pair `col` (and their d/dr), eight consecutive g per lane and
+            // step, split in registers; A = the W1 planes.  G + 1 <= 64: at most two K steps.
+            // (backward: one pass for the values, one for d/dr -- four accumulator sets at once do not fit the registers;
+            //  the second pass recomputes the Gaussians rather than keep their planes)
+            auto l1_pass = [&](auto deriv, f32x4 (&hi)[NCB]) {
+                f32x4 lo[NCB];
 #pragma unroll
-            for (int cb = 0; cb < NCB; cb++) {
-                const float w = wrow[cb * 16];
-                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, a, acc[cb], 0, 0, 0);
-                if constexpr (BWD) dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, da, dacc[cb], 0, 0, 0);
+                for (int cb = 0; cb < NCB; cb++) lo[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int s = 0; s < 2; s++) {               // (not unrolled: the second step's plane reads would be hoisted)
+                    if (32 * s >= G + 1) break;             // (wave-uniform: fewer than 32 Gaussians)
+                    f16x8 gh, gl;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int g = 32 * s + 8 * grp + i;
+                        const float d = rp - (float)g * mu_step;
+                        float v = g < G ? fast_exp2(gscale * d * d) : 0.f;             // ref :151-154
+                        if (decltype(deriv)::value) v *= -d * sig2;                    // ref :242
+                        if (g == G) v = decltype(deriv)::value ? 0.f : 1.0f;           // the bias column of the planes
+                        gh[i] = (_Float16)v;
+                        gl[i] = split_lo(v, gh[i]);
+                    }
+                    const int slot = min(4 * s + grp, slots1 - 1);  // a slot past the row meets all-zero Gaussians
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) {
+                        const int off = (cb * 16 + col) * row1 + slot * 16;
+                        const f16x8 wh = *reinterpret_cast<const f16x8*>(s_w1h + off);
+                        const f16x8 wl = *reinterpret_cast<const f16x8*>(s_w1l + off);
+                        hi[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gh, hi[cb], 0, 0, 0);
+                        lo[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gl, lo[cb], 0, 0, 0);
+                        lo[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, gh, lo[cb], 0, 0, 0);
+                        if (BWD && (cb & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // (four blocks' plane reads in flight, not eight)
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) hi[cb] += kLoInv * lo[cb];
+            };
+            l1_pass(std::false_type{}, acc);
+            if constexpr (BWD) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                l1_pass(std::true_type{}, dacc);
+            }
+        } else {
+            for (int s = 0; s < Gq / 4; s++) {
+                const int g = 4 * s + grp;
+                const float d = rp - (float)g * mu_step;
+                float a = g < G ? fast_exp2(gscale * d * d) : 0.f;                     // ref :151-154
+                float da = -d * sig2 * a;                                              // ref :242
+                if (g == G) { a = 1.0f; da = 0.f; }                                    // the bias row
+                const float* wrow = s_w1t + g * W + col;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    const float w = wrow[cb * 16];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, a, acc[cb], 0, 0, 0);
+                    if constexpr (BWD) dacc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, da, dacc[cb], 0, 0, 0);
+                }
             }
         }
         // ---- activation, split, A planes: pair `col`, filters 16 cb + 4 grp .. + 3 = half a 16-byte slot ----
@@ -1289,10 +1358,11 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
         f32x4 acc2[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) {
-            acc[cb] = f32x4{b2v[cb], b2v[cb], b2v[cb], b2v[cb]};
+            const float bias = BWD ? b2[cb * 16 + col] : b2v[cb];
+            acc[cb] = f32x4{bias, bias, bias, bias};
             acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        h2_layer<NCB, W>(a_h, a_l, s_w2h, s_w2l, col, grp, col, acc, acc2);
+        h2_layer<NCB, W, BWD>(a_h, a_l, s_w2h, s_w2l, col, grp, col, acc, acc2);
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) acc[cb] += kLoInv * acc2[cb];
         if constexpr (BWD) {
@@ -1313,7 +1383,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
                 acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             wave_fence();
-            h2_layer<NCB, W>(a_h, a_l, s_w2h, s_w2l, col, grp, col, dacc, acc2);
+            h2_layer<NCB, W, true>(a_h, a_l, s_w2h, s_w2l, col, grp, col, dacc, acc2);
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) dacc[cb] += kLoInv * acc2[cb];
         }
@@ -1486,8 +1556,8 @@ struct nnpops_cfconv {
     // split-fp16 second layer (cfconv_filters_h2): W1^T with the bias row, the two fp16 planes of W2 [out][in];
     // split_ok = width a multiple of 32 and every operand provably inside the fp16 range ($NNPOPS_CFCONV_SPLIT=0: never)
     float* d_w1b = nullptr;
-    _Float16 *d_w2h = nullptr, *d_w2l = nullptr;
-    bool split_ok = false;
+    _Float16 *d_w2h = nullptr, *d_w2l = nullptr, *d_w1h = nullptr, *d_w1l = nullptr;
+    bool split_ok = false, split_l1 = false;      // split_l1: layer 1 as split products too (G + 1 <= 64 and the planes fit in LDS)
     // filter rows F[pid][W] and pair forces s[pid] of the half-list path (+1: the all-zero row); sized on first use
     float *d_filt = nullptr, *d_pair_s = nullptr;
     size_t spill_rows = 0;
@@ -1741,7 +1811,27 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
             }
         const double limit = 3.0e4;                         // fp16 holds 65504; the low planes stay below 32 in any case
         h->split_ok = max_w2 < limit && max_y < limit && max_dy < limit;
-        if (const char* e = std::getenv("NNPOPS_CFCONV_SPLIT")) h->split_ok = h->split_ok && std::atoi(e) != 0;
+        int level = 2;                                      // 0: fp32 only, 1: second layer split, 2: both layers where possible
+        if (const char* e = std::getenv("NNPOPS_CFCONV_SPLIT")) level = std::atoi(e);
+        h->split_ok = h->split_ok && level != 0;
+        h->split_l1 = h->split_ok && level >= 2 && G + 1 <= 64 &&
+                      h2_weight_bytes_l1h(W, G) + kMaxWavesPerBlock * h2_wave_bytes(W) <= (size_t)160 * 1024;
+        if (h->split_l1) {
+            const int rowh = h2_l1_row_bytes(G) / 2;        // halves per plane row
+            std::vector<_Float16> w1h((size_t)W * rowh, (_Float16)0.f), w1l((size_t)W * rowh, (_Float16)0.f);
+            for (int f = 0; f < W; f++)
+                for (int k = 0; k <= G; k++) {
+                    const float v = w1b[(size_t)k * W + f];  // (row G = the bias)
+                    const _Float16 hi = (_Float16)v;
+                    w1h[(size_t)f * rowh + k] = hi;
+                    w1l[(size_t)f * rowh + k] = (_Float16)((v - (float)hi) * kLoScale);
+                }
+            if ((rc = dev_alloc(&h->d_w1h, w1h.size()))) return cleanup(rc);
+            if ((rc = dev_alloc(&h->d_w1l, w1l.size()))) return cleanup(rc);
+            if (hipMemcpy(h->d_w1h, w1h.data(), w1h.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(h->d_w1l, w1l.data(), w1l.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                return cleanup(fail(NNPOPS_ERR_HIP, "weight upload failed"));
+        }
         if (h->split_ok) {
             if ((rc = dev_alloc(&h->d_w1b, w1b.size()))) return cleanup(rc);
             if ((rc = dev_alloc(&h->d_w2h, w2h.size()))) return cleanup(rc);
@@ -1766,7 +1856,7 @@ int nnpops_cfconv_destroy(nnpops_cfconv_t h) {
     dev_free(h->d_w1t); dev_free(h->d_w2t); dev_free(h->d_b1); dev_free(h->d_b2);
     dev_free(h->d_w1t_s); dev_free(h->d_w2t_s); dev_free(h->d_b1_s);
     dev_free(h->d_filt); dev_free(h->d_pair_s);
-    dev_free(h->d_w1b); dev_free(h->d_w2h); dev_free(h->d_w2l);
+    dev_free(h->d_w1b); dev_free(h->d_w2h); dev_free(h->d_w2l); dev_free(h->d_w1h); dev_free(h->d_w1l);
     delete h;
     return NNPOPS_OK;
 }
@@ -1862,15 +1952,17 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
     if constexpr (NCB % 2 == 0) {
         if (h->split_ok) {                                  // second layer as split-fp16 matrix products
             const size_t budget = 160 * 1024;
-            const size_t wb = h2_weight_bytes(h->p.W, h->p.G), per_wave = h2_wave_bytes(h->p.W);
+            const size_t wb = h->split_l1 ? h2_weight_bytes_l1h(h->p.W, h->p.G) : h2_weight_bytes(h->p.W, h->p.G);
+            const size_t per_wave = h2_wave_bytes(h->p.W);
             if (wb + per_wave <= budget) {
                 const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wb) / per_wave);
                 const size_t lds = wb + (size_t)wpb * per_wave;
-                auto k = cfconv_filters_h2<ACT, NCB, BWD>;
+                auto k = h->split_l1 ? cfconv_filters_h2<ACT, NCB, BWD, true> : cfconv_filters_h2<ACT, NCB, BWD, false>;
                 if (lds > 64 * 1024)
                     NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1b, h->d_w2h, h->d_w2l, h->d_b2,
-                                   nb->d_half_off, nb->d_half_r, nb->d_half_ij, pair_cap, x, gout, h->d_filt, h->d_pair_s);
+                hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1b, h->d_w1h, h->d_w1l, h->d_w2h,
+                                   h->d_w2l, h->d_b2, nb->d_half_off, nb->d_half_r, nb->d_half_ij, pair_cap, x, gout, h->d_filt,
+                                   h->d_pair_s);
                 launched = true;
             }
         }
