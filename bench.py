@@ -519,7 +519,7 @@ def main_cfconv(args):
         "metric": "CFConv build+forward+backward evaluations/sec, W=128 G=50 cutoff 5 A, 10k-atom periodic box",
         "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" + (" (W x W layer: operands split into two fp16 planes, products exact, fp32 accumulation)" if split else ""),
+        "dtype": "f32" + (" (dense layers: operands split into two fp16 planes, products exact, fp32 accumulation)" if split else ""),
         "data": "synthetic",
         "config": {"workload": f"SchNet CFConv + neighbour list, {n} atoms periodic, W={W}, G={G}, cutoff {cutoff} A, ssp"
                                + (", replayed as one HIP graph" if args.graph else ""), "half_pairs": pairs},

@@ -1115,8 +1115,8 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_mfma(
 }
 
 // ---------------------------------------------------------------------------------------------
-// cfconv_filters_h2: the filters kernel with the SECOND layer (W x W: 70 % of the matrix work) on the half-precision
-// matrix instruction, operands split into two fp16 planes so that the result keeps fp32 accuracy:
+// cfconv_filters_h2: the filters kernel with its dense layers on the half-precision matrix instruction, every fp32
+// operand split into two fp16 planes so that the result keeps fp32 accuracy:
 //     x = hi + 2^-11 lo'   (hi = fp16(x), lo' = fp16((x - hi) 2^11): 22 significant bits, every plane in normal range)
 //     A B = Ahi Bhi + 2^-11 (Ahi Blo' + Alo' Bhi) + O(2^-22)          -- three v_mfma_f32_16x16x32_f16 per 16x16x32
 //     block (fp32 accumulation, two accumulators) instead of eight v_mfma_f32_16x16x4_f32: 48 instead of 256 issue cycles.
@@ -1124,11 +1124,14 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_mfma(
 // split, and a SMALLER error against a double-precision product (1.6e-6 against 3.8e-6 at |y| ~ 9: exact fp16
 // products summed in fp32 versus a chain of 128 rounded fp32 FMAs).  The host only takes this kernel when the weights
 // bound every operand below the fp16 range (nnpops_cfconv_create); $NNPOPS_CFCONV_SPLIT=0 keeps the all-fp32 one.
-//   layer 1   stays v_mfma_f32_16x16x4_f32 but TRANSPOSED (operands swapped: rows = filters, columns = pairs), so a lane
-//             ends up with four consecutive filters of one pair -- after the activation exactly the 8-byte groups the
-//             A planes of layer 2 are written in.  b1 rides along as one more row of W1^T against a constant 1.
+//   layer 1   is computed TRANSPOSED (rows = filters, columns = pairs), so a lane ends up with four consecutive filters
+//             of one pair -- after the activation exactly the 8-byte groups the A planes of layer 2 are written in.  b1
+//             rides along as one more K index against a constant 1.  L1H (G + 1 <= 64): split products here too, B = the
+//             pair's Gaussians computed and split in registers, A = the W1 planes [filter][k]; otherwise
+//             v_mfma_f32_16x16x4_f32 with the operands swapped.
 //   LDS       W2 planes [f2][k] and the per-wave A planes [pair][k] with the 16-byte slots of a row rotated by the row
-//             index (conflict-free ds_read_b128 across rows); W1^T fp32 as before.  Same footprint as the fp32 kernel.
+//             index (conflict-free ds_read_b128 across rows); W1 planes with rows an odd number of slots long (or W1^T
+//             fp32).  Same footprint as the fp32 kernel.
 // ---------------------------------------------------------------------------------------------
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
