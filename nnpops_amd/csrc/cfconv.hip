@@ -1153,10 +1153,14 @@ __device__ __forceinline__ int h2_slot(int row, int slot) { return row * (2 * W)
 __device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) { return (_Float16)((v - (float)hi) * kLoScale); }
 
 // D = A B for one 16-row tile against all NCB column blocks: acc1 += Ahi Bhi, acc2 += Ahi Blo' + Alo' Bhi
-template <int NCB, int W, bool TIGHT = false>             // TIGHT (backward): one K step's 2 + 2 NCB plane reads in flight, not two steps'
+// FRESH1 / FRESH2: the accumulator starts from zero -- passed as the (inline constant) C operand of its first MFMA instead
+// of being cleared register by register beforehand.
+template <int NCB, int W, bool TIGHT, bool FRESH1, bool FRESH2>   // TIGHT (backward): one K step's plane reads in flight, not two steps'
 __device__ __forceinline__ void h2_layer(const char* a_h, const char* a_l, const char* b_h, const char* b_l, int row, int grp, int col,
                                          f32x4 (&acc1)[NCB], f32x4 (&acc2)[NCB]) {
-    auto step = [&](int s) {
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int s, auto first) {
+        constexpr bool kFirst = decltype(first)::value;
         const int slot = 4 * s + grp;                       // this lane's 8 consecutive k of the step
         const f16x8 ah = *reinterpret_cast<const f16x8*>(a_h + h2_slot<W>(row, slot));
         const f16x8 al = *reinterpret_cast<const f16x8*>(a_l + h2_slot<W>(row, slot));
@@ -1165,17 +1169,19 @@ __device__ __forceinline__ void h2_layer(const char* a_h, const char* a_l, const
             const int f2 = cb * 16 + col;
             const f16x8 bh = *reinterpret_cast<const f16x8*>(b_h + h2_slot<W>(f2, slot));
             const f16x8 bl = *reinterpret_cast<const f16x8*>(b_l + h2_slot<W>(f2, slot));
-            acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc1[cb], 0, 0, 0);
-            acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc2[cb], 0, 0, 0);
+            acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, kFirst && FRESH1 ? zero : acc1[cb], 0, 0, 0);
+            acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, kFirst && FRESH2 ? zero : acc2[cb], 0, 0, 0);
             acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc2[cb], 0, 0, 0);
         }
     };
-    if constexpr (TIGHT) {
+    if constexpr (TIGHT) {                                  // (the caller has cleared / preset the accumulators)
+        static_assert(!FRESH1 && !FRESH2, "the loop form does not peel its first step");
 #pragma unroll 1
-        for (int s = 0; s < W / 32; s++) step(s);
+        for (int s = 0; s < W / 32; s++) step(s, std::false_type{});
     } else {
+        step(0, std::true_type{});
 #pragma unroll
-        for (int s = 0; s < W / 32; s++) step(s);
+        for (int s = 1; s < W / 32; s++) step(s, std::false_type{});
     }
 }
 
@@ -1267,11 +1273,14 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
         request(t + total_waves, next_r, next_ij);          // used after the GEMMs
         wave_fence();
         // ---- layer 1, transposed: acc[cb][q] = S1 of filter 16 cb + 4 grp + q for the pair `col` ----
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 acc[NCB], dacc[NCB];
+        if constexpr (!L1H) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BWD && !L1H) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < NCB; cb++) {
+                acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (BWD) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         const float rp = ps[col];
         if constexpr (L1H) {
@@ -1279,13 +1288,10 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
             // step, split in registers; A = the W1 planes.  G + 1 <= 64: at most two K steps.
             // (backward: one pass for the values, one for d/dr -- four accumulator sets at once do not fit the registers;
             //  the second pass recomputes the Gaussians rather than keep their planes)
-            auto l1_pass = [&](auto deriv, f32x4 (&hi)[NCB]) {
-                f32x4 lo[NCB];
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) lo[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-                for (int s = 0; s < 2; s++) {               // (not unrolled: the second step's plane reads would be hoisted)
-                    if (32 * s >= G + 1) break;             // (wave-uniform: fewer than 32 Gaussians)
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto l1_step = [&](auto deriv, auto first, int s, f32x4 (&hi)[NCB], f32x4 (&lo)[NCB]) {
+                constexpr bool kFirst = decltype(first)::value;
+                {
                     f16x8 gh, gl;
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
@@ -1303,11 +1309,27 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
                         const int off = (cb * 16 + col) * row1 + slot * 16;
                         const f16x8 wh = *reinterpret_cast<const f16x8*>(s_w1h + off);
                         const f16x8 wl = *reinterpret_cast<const f16x8*>(s_w1l + off);
-                        hi[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gh, hi[cb], 0, 0, 0);
-                        lo[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gl, lo[cb], 0, 0, 0);
+                        hi[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gh, kFirst ? zero : hi[cb], 0, 0, 0);
+                        lo[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gl, kFirst ? zero : lo[cb], 0, 0, 0);
                         lo[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, gh, lo[cb], 0, 0, 0);
                         if (BWD && (cb & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // (four blocks' plane reads in flight, not eight)
                     }
+                }
+            };
+            // (the accumulators start as the zero C operand of the first step; backward: one pass for the values, one for d/dr)
+            auto l1_pass = [&](auto deriv, f32x4 (&hi)[NCB]) {
+                f32x4 lo[NCB];
+                if constexpr (BWD) {                        // (a loop, cleared accumulators: the registers do not allow both steps inline)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) { hi[cb] = zero; lo[cb] = zero; }
+#pragma unroll 1
+                    for (int s = 0; s < 2; s++) {
+                        if (32 * s >= G + 1) break;         // (wave-uniform: fewer than 32 Gaussians)
+                        l1_step(deriv, std::false_type{}, s, hi, lo);
+                    }
+                } else {
+                    l1_step(deriv, std::true_type{}, 0, hi, lo);
+                    if (32 < G + 1) l1_step(deriv, std::false_type{}, 1, hi, lo);      // (wave-uniform: more than 31 Gaussians)
                 }
 #pragma unroll
                 for (int cb = 0; cb < NCB; cb++) hi[cb] += kLoInv * lo[cb];
@@ -1315,8 +1337,6 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
             l1_pass(std::false_type{}, acc);
             if constexpr (BWD) {
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
                 l1_pass(std::true_type{}, dacc);
             }
         } else {
@@ -1359,13 +1379,17 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
         wave_fence();
         // ---- layer 2 on Y1: S2[pair 4 grp + q][filter 16 cb + col] ----
         f32x4 acc2[NCB];
+        if constexpr (BWD) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            const float bias = BWD ? b2[cb * 16 + col] : b2v[cb];
-            acc[cb] = f32x4{bias, bias, bias, bias};
-            acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < NCB; cb++) {
+                const float bias = b2[cb * 16 + col];
+                acc[cb] = f32x4{bias, bias, bias, bias};
+                acc2[cb] = zero4;
+            }
+            h2_layer<NCB, W, true, false, false>(a_h, a_l, s_w2h, s_w2l, col, grp, col, acc, acc2);
+        } else {                                            // (zero C operands; the bias joins in the epilogue)
+            h2_layer<NCB, W, false, true, true>(a_h, a_l, s_w2h, s_w2l, col, grp, col, acc, acc2);
         }
-        h2_layer<NCB, W, BWD>(a_h, a_l, s_w2h, s_w2l, col, grp, col, acc, acc2);
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) acc[cb] += kLoInv * acc2[cb];
         if constexpr (BWD) {
@@ -1382,15 +1406,16 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
                 const int off = h2_slot<W>(col, 2 * cb + (grp >> 1)) + (grp & 1) * 8;
                 *reinterpret_cast<f16x4*>(a_h + off) = h;
                 *reinterpret_cast<f16x4*>(a_l + off) = l;
-                dacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dacc[cb] = zero4;
+                acc2[cb] = zero4;
             }
             wave_fence();
-            h2_layer<NCB, W, true>(a_h, a_l, s_w2h, s_w2l, col, grp, col, dacc, acc2);
+            h2_layer<NCB, W, true, false, false>(a_h, a_l, s_w2h, s_w2l, col, grp, col, dacc, acc2);
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) dacc[cb] += kLoInv * acc2[cb];
         }
-        // ---- my four pairs of the tile ----
+        // ---- my four pairs of the tile: the filter rows first (backward: and dy2 = dfc S2 + fc dS2 in place of dS2, after
+        //      which S2 is dead and its registers serve the gathers), then the pair forces ----
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int rr = grp * 4 + q;
@@ -1399,9 +1424,22 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
             if (p < pairs) {                                // uniform over the 16 lanes of a row
                 float* frow = filt + (size_t)p * W + col;
 #pragma unroll
-                for (int cb = 0; cb < NCB; cb++) frow[cb * 16] = fc * acc[cb][q];      // ref :175
-                if constexpr (BWD) {
-                    const float dfc = ps[32 + rr];
+                for (int cb = 0; cb < NCB; cb++)
+                    frow[cb * 16] = BWD ? fc * acc[cb][q] : fc * (acc[cb][q] + b2v[cb]);      // ref :175
+            }
+            if constexpr (BWD) {
+                const float dfc = ps[32 + rr];
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) dacc[cb][q] = dfc * acc[cb][q] + fc * dacc[cb][q];     // ref :276
+            }
+        }
+        if constexpr (BWD) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int rr = grp * 4 + q;
+                const int p = 16 * t + rr;
+                if (p < pairs) {
                     const int i = __float_as_int(ps[64 + rr]), j = __float_as_int(ps[80 + rr]);
                     float sc = 0.f;
 #pragma unroll
@@ -1409,15 +1447,14 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
                         const size_t c = (size_t)cb * 16 + col;
                         const float xi = x[(size_t)i * W + c], gi = gout[(size_t)i * W + c];
                         const float xj = x[(size_t)j * W + c], gj = gout[(size_t)j * W + c];
-                        const float dy2 = dfc * acc[cb][q] + fc * dacc[cb][q];         // ref :276
-                        sc += dy2 * (xj * gi + xi * gj);                               // ref :286
+                        sc += dacc[cb][q] * (xj * gi + xi * gj);                       // ref :286
                     }
                     sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
                     sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
                     if (col == 0) pair_s[p] = sc * ps[48 + rr];
                 }
+                if (q & 1) __builtin_amdgcn_sched_barrier(0);       // two pairs' gathers in flight at a time
             }
-            if constexpr (BWD) __builtin_amdgcn_sched_barrier(0);     // one pair's 4*NCB gathers in flight at a time
         }
         my_r = next_r; my_ij = next_ij;
         wave_fence();
