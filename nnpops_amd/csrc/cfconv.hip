@@ -2085,19 +2085,23 @@ int dispatch_forward_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const f
 
 template <bool BWD>
 int dispatch_conv(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float* x, const float* gout, float* out, float* pos_grad) {
-    if (!h->force_valu && h->half_list) {
+    // the matrix-core kernels keep both weight matrices in LDS beside at least one wave's tile; layers with very many
+    // Gaussians (W = 128: G > ~180) do not fit and take the vector kernel, which streams its weights
+    const bool mfma_fits = mfma_weight_floats(h->p.W, h->p.G) + mfma_wave_floats_bwd(h->p.W) <= (size_t)160 * 1024 / sizeof(float);
+    const bool use_mfma = !h->force_valu && mfma_fits;
+    if (use_mfma && h->half_list) {
         bool handled = false;
         const int rc = h->p.activation == 0 ? dispatch_half_mfma<0, BWD>(h, nb, x, gout, out, pos_grad, handled)
                                             : dispatch_half_mfma<1, BWD>(h, nb, x, gout, out, pos_grad, handled);
         if (handled) return rc;
     }
-    if (!BWD && !h->force_valu) {
+    if (!BWD && use_mfma) {
         bool handled = false;
         const int rc = h->p.activation == 0 ? dispatch_forward_mfma<0>(h, nb, x, out, handled)
                                             : dispatch_forward_mfma<1>(h, nb, x, out, handled);
         if (handled) return rc;
     }
-    if (BWD && !h->force_valu) {
+    if (BWD && use_mfma) {
         bool handled = false;
         const int rc = h->p.activation == 0 ? dispatch_backward_mfma<0>(h, nb, x, gout, out, pos_grad, handled)
                                             : dispatch_backward_mfma<1>(h, nb, x, gout, out, pos_grad, handled);

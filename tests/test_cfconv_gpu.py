@@ -204,3 +204,10 @@ def test_weights_outside_the_fp16_range_keep_the_fp32_layer():
     b2 = (0.3 * rng.standard_normal(W)).astype(np.float32)
     x = rng.standard_normal((n, W)).astype(np.float32)
     _case(pos, None, W, G, 5.0, 0.3, "tanh", seed=24, w=(w1, b1, w2, b2, x))
+
+
+def test_many_gaussians_at_a_matrix_width():
+    """W = 128 with 200 Gaussians: the two weight matrices no longer fit in LDS beside a tile, the matrix-core kernels
+    step aside for the vector kernel with streamed weights (any G up to 256 is accepted)."""
+    pos, _ = workloads.conformer(60, seed=91)
+    _case(pos, None, 128, 200, 5.0, 0.05, "ssp", seed=31)
