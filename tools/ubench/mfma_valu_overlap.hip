@@ -76,6 +76,8 @@ __global__ __launch_bounds__(512) void k(float* out, int mode, int iters) {
         }
     } else if (mode & 64) {
         fma_block(v, a, b, iters);                                  // every wave: two V waves per SIMD
+    } else if (mode & 128) {
+        if (first) exp_block(v, iters); else fma_block(v, a, b, iters);   // T on one wave, V on the other wave of the SIMD
     } else if (first) {
         if (mode & 1) mfma_block(acc, a, b, iters);
         if (mode & 16) hmfma_block(acc, ha, hb, iters);
@@ -110,6 +112,7 @@ int main() {
     run(5, "M on one wave, T on the other wave of the SIMD");
     run(8, "one wave: 8 x (MFMA + 8 v_fma)  [2 such waves per SIMD]");
     run(64, "V on both waves of the SIMD (2 x 64 v_fma / iteration)");
+    run(128, "T on one wave, V on the other wave of the SIMD");
     run(16, "H alone: 16 f16 MFMA 16x16x32 / iteration");
     run(18, "H on one wave, V on the other wave of the SIMD");
     run(20, "H on one wave, T on the other wave of the SIMD");
