@@ -1146,9 +1146,17 @@ __host__ __device__ inline int h2_l1_slots(int G) { return (G + 1 + 7) >> 3; }
 __host__ __device__ inline int h2_l1_row_bytes(int G) { return (h2_l1_slots(G) | 1) * 16; }
 __host__ __device__ inline size_t h2_weight_bytes_l1h(int W, int G) { return (size_t)2 * W * W * 2 + (size_t)2 * W * h2_l1_row_bytes(G); }
 
-// byte offset of the 16-byte slot `slot` of row `row` in a plane whose rows hold W halves
+// Byte offset of the 16-byte slot `slot` of row `row` in a plane whose rows hold W halves.  ds_read_b128 serves a wave in
+// four groups of 16 lanes that mix two K groups (lanes {0-3, 12-15} of one with {4-11} of the next): with the slot index
+// XORed by the row, the two halves of such a group land in different quarters of the 256-byte bank row for any K step,
+// so the 16 lanes hit 16 different slots (a rotation by the row, the first attempt, left every group 2-way conflicted:
+// SQ_LDS_BANK_CONFLICT 47 % of the LDS cycles).  Row lengths that are not a power of two keep the rotation.
 template <int W>
-__device__ __forceinline__ int h2_slot(int row, int slot) { return row * (2 * W) + ((slot + row) % (W / 8)) * 16; }
+__device__ __forceinline__ int h2_slot(int row, int slot) {
+    constexpr int kSlots = W / 8;
+    if constexpr ((kSlots & (kSlots - 1)) == 0) return row * (2 * W) + ((slot ^ row) & (kSlots - 1)) * 16;
+    return row * (2 * W) + ((slot + row) % kSlots) * 16;
+}
 
 __device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) { return (_Float16)((v - (float)hi) * kLoScale); }
 
