@@ -1129,9 +1129,9 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_mfma(
 //             rides along as one more K index against a constant 1.  L1H (G + 1 <= 64): split products here too, B = the
 //             pair's Gaussians computed and split in registers, A = the W1 planes [filter][k]; otherwise
 //             v_mfma_f32_16x16x4_f32 with the operands swapped.
-//   LDS       W2 planes [f2][k] and the per-wave A planes [pair][k] with the 16-byte slots of a row rotated by the row
-//             index (conflict-free ds_read_b128 across rows); W1 planes with rows an odd number of slots long (or W1^T
-//             fp32).  Same footprint as the fp32 kernel.
+//   LDS       W2 planes [f2][k] and the per-wave A planes [pair][k] with the 16-byte slot index XORed by the row
+//             (h2_slot: conflict-free ds_read_b128); W1 planes with rows an odd number of slots long (or W1^T fp32).
+//             Same footprint as the fp32 kernel.
 // ---------------------------------------------------------------------------------------------
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
