@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="torchani / cfconv workloads: replay the step as one captured HIP graph")
-    ap.add_argument("--nn-layout", default="grouped", choices=["grouped", "reference"],
+    ap.add_argument("--nn-layout", default="fused", choices=["fused", "grouped", "reference"],
                     help="torchani workload: species-grouped GEMMs (default) or the reference's per-atom replicated weights")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
     ap.add_argument("--workload", default="aev", choices=["aev", "cfconv", "conformers", "neighbors", "torchani"],
@@ -299,8 +299,8 @@ def main_torchani(args):
     pos, species, box = workloads.water_box(667, seed=1)
     numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=dev)
     opt = OptimizedTorchANI(model, numbers.cpu())
-    if args.nn_layout == "reference":
-        opt.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="reference")
+    if args.nn_layout != "fused":
+        opt.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=args.nn_layout)
     opt = opt.to(dev)
     # (pbc stays on the host: the wrapper reads it with .tolist(), reference SymmetryFunctions.py:113, which on a
     # device tensor is a synchronising copy and cannot be captured)

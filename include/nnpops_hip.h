@@ -190,6 +190,22 @@ int nnpops_neighbor_pairs_backward(int dtype, int num_atoms, int64_t num_slots, 
                                    const void* deltas, const void* distances, const void* grad_deltas,
                                    const void* grad_distances, void* grad_positions, void* stream);
 
+/* ---- dense layers of the ANI atomic networks (reference src/pytorch/BatchedNN.cpp:30-50, BatchedNN.py:37-122) ----
+ * C[M x N] = A[M x K] B with fp32 in and out; the products run on the half-precision matrix instruction with every
+ * operand carried as two fp16 planes (22 significant bits) and fp32 accumulation.  B arrives pre-split:
+ * nnpops_split_planes writes the planes [rows][ldp] (ldp a multiple of 32, zero padded) of W [rows][cols] -- or of its
+ * transpose: rows/cols then describe the OUTPUT, W is [cols][rows].  For y = x W^T with a torch Linear weight
+ * W [out][in], B = planes(W) with rows = N = out, cols = K = in.  All pointers are device pointers. */
+int nnpops_split_planes(void* stream, int rows, int cols, const float* w, long ldw, int transpose, void* hi, void* lo, long ldp);
+/* batch: independent problems `stride*` elements apart (0 = shared operand).
+ * epilogue 0: none; 1: C = CELU(C + bias[N], alpha); 2: C *= CELU'(Y) with Y [M][ldy] a saved CELU OUTPUT.
+ * prologue 0: A as given; 1: A[m][k] = pv[k] * CELU'(PY[m][k]) (A itself is not read).
+ * a_scale: A is multiplied by it before the split (and C divided by it): keep |A| * a_scale below 6e4. */
+int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float* A, long lda, long strideA, const void* Bh,
+                      const void* Bl, long ldb, long strideB, float* C, long ldc, long strideC, int epilogue, const float* bias,
+                      long strideBias, const float* Y, long ldy, long strideY, int prologue, const float* PY, long ldpy,
+                      long stridePY, const float* pv, long stridePv, float alpha, float a_scale);
+
 #ifdef __cplusplus
 }
 #endif

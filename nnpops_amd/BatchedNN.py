@@ -119,6 +119,9 @@ class _SpeciesGroupedNN(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
+        return self._grouped_forward(species_aev)
+
+    def _grouped_forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
         species, aev = species_aev
         mols = aev.shape[0]
         x = aev.index_select(1, self.atom_order)                            # [mols, atoms, features], grouped
@@ -140,14 +143,82 @@ class _SpeciesGroupedNN(nn.Module):
         return SpeciesEnergies(species, energies / num_models)
 
 
-class TorchANIBatchedNN(nn.ModuleList):
-    """``layout='grouped'`` (default): species-grouped GEMMs; ``layout='reference'``: the reference's per-atom
-    replicated weights through ``BatchedLinear`` (interchange with reference state dicts / archives)."""
+def _planes(w: Tensor) -> Tuple[Tensor, Tensor]:
+    """fp32 [rows, cols] -> the two fp16 planes [rows, cols rounded up to 32] the split GEMM takes: w = hi + 2^-11 lo."""
+    rows, cols = w.shape
+    padded = torch.zeros((rows, (cols + 31) // 32 * 32), dtype=torch.float32, device=w.device)
+    padded[:, :cols] = w
+    hi = padded.half()
+    lo = ((padded - hi.float()) * 2048.0).half()
+    return hi, lo
 
-    def __init__(self, converter, ensemble, atomicNumbers: Tensor, layout: str = 'grouped'):
-        if layout not in ('grouped', 'reference'):
-            raise ValueError("layout must be 'grouped' or 'reference'")
-        impl = _SpeciesGroupedNN if layout == 'grouped' else _BatchedNN
+
+class _FusedSpeciesNN(_SpeciesGroupedNN):
+    """The species-grouped networks on the library's own GEMM (``torch.ops.NNPOpsBatchedNN.GroupedMLP``,
+    csrc/batched_nn.hip): fp32 in and out, products as split-fp16 matrix instructions with fp32 accumulation, bias + CELU
+    fused into the epilogues and CELU' into the input-gradient pass -- six launches per species and step instead of
+    GEMM + elementwise kernels for every layer.  Same buffers (and state dicts) as :class:`_SpeciesGroupedNN`; the packed
+    operand planes are derived from them (non-persistent buffers, rebuilt when a state dict is loaded).  Frames with
+    several molecules, CPU tensors and double precision take the parent's path."""
+
+    def __init__(self, converter, ensemble, atomicNumbers: Tensor):
+        super().__init__(converter, ensemble, atomicNumbers)
+        self.num_models = int(self.layer0_weights.shape[1])
+        self.h1 = int(self.layer0_weights.shape[2])
+        self.h2 = int(self.layer2_weights.shape[2])
+        self.h3 = int(self.layer4_weights.shape[2])
+        for name in ('fwd_hi', 'fwd_lo', 'bwd_hi', 'bwd_lo', 'packed_biases', 'last_w', 'last_b'):
+            self.register_buffer(name, torch.empty(0), persistent=False)
+        self._refresh_planes()
+
+    @torch.jit.unused
+    def _refresh_planes(self) -> None:
+        w0, w2, w4, w6 = self.layer0_weights, self.layer2_weights, self.layer4_weights, self.layer6_weights
+        kinds, models = w0.shape[0], w0.shape[1]
+        fwd_hi, fwd_lo, bwd_hi, bwd_lo, biases, last_w, last_b = [], [], [], [], [], [], []
+        for k in range(kinds):
+            fwd = [w0[k].reshape(-1, w0.shape[3]), w2[k].reshape(-1, w2.shape[3]), w4[k].reshape(-1, w4.shape[3])]
+            bwd = [w0[k].reshape(-1, w0.shape[3]).t().contiguous(),
+                   torch.cat([w2[k][m].t() for m in range(models)], 0).contiguous(),
+                   torch.cat([w4[k][m].t() for m in range(models)], 0).contiguous()]
+            for mats, his, los in ((fwd, fwd_hi, fwd_lo), (bwd, bwd_hi, bwd_lo)):
+                for w in mats:
+                    hi, lo = _planes(w.float())
+                    his.append(hi.reshape(-1))
+                    los.append(lo.reshape(-1))
+            biases += [self.layer0_biases[k].reshape(-1), self.layer2_biases[k].reshape(-1), self.layer4_biases[k].reshape(-1)]
+            last_w.append(w6[k][:, 0, :].reshape(-1))
+            last_b.append(self.layer6_biases[k].sum().reshape(1))
+        self.fwd_hi, self.fwd_lo = torch.cat(fwd_hi), torch.cat(fwd_lo)
+        self.bwd_hi, self.bwd_lo = torch.cat(bwd_hi), torch.cat(bwd_lo)
+        self.packed_biases = torch.cat(biases).float().contiguous()
+        self.last_w = torch.cat(last_w).float().contiguous()
+        self.last_b = torch.cat(last_b).float().contiguous()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        self._refresh_planes()
+
+    def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
+        species, aev = species_aev
+        if aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32:
+            return self._grouped_forward(species_aev)
+        x = aev[0].index_select(0, self.atom_order)                         # [atoms, features], grouped by species
+        per_atom = torch.ops.NNPOpsBatchedNN.GroupedMLP(x, self.group_sizes, self.num_models, self.h1, self.h2, self.h3,
+                                                        self.fwd_hi, self.fwd_lo, self.bwd_hi, self.bwd_lo,
+                                                        self.packed_biases, self.last_w, self.last_b)
+        return SpeciesEnergies(species, per_atom.sum().reshape(1) / self.num_models)
+
+
+class TorchANIBatchedNN(nn.ModuleList):
+    """``layout='fused'`` (default): species-grouped layers on the library's split-fp16 GEMM with fused activations;
+    ``'grouped'``: the same grouping on torch's library GEMMs; ``'reference'``: the reference's per-atom replicated
+    weights through ``BatchedLinear`` (interchange with reference state dicts / archives)."""
+
+    def __init__(self, converter, ensemble, atomicNumbers: Tensor, layout: str = 'fused'):
+        if layout not in ('fused', 'grouped', 'reference'):
+            raise ValueError("layout must be 'fused', 'grouped' or 'reference'")
+        impl = {'fused': _FusedSpeciesNN, 'grouped': _SpeciesGroupedNN, 'reference': _BatchedNN}[layout]
         super().__init__([impl(converter, ensemble, atomicNumbers)])
 
     def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:

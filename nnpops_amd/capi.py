@@ -54,6 +54,11 @@ SIGNATURES = {
     "nnpops_cfconv_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_cfconv_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "nnpops_split_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long]),
+    "nnpops_gemm_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p,
+                                    C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long,
+                                    C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long,
+                                    C.c_float, C.c_float]),
     "nnpops_neighbor_pairs_workspace_bytes": (C.c_int64, [C.c_int]),
     "nnpops_neighbor_pairs_forward": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -381,3 +386,34 @@ class CFConv:
         _check(self._lib.nnpops_cfconv_backprop(self._h, neighbors._h, _ptr(positions), _ptr(box), _ptr(x), _ptr(out_grad),
                                                 _ptr(x_grad), _ptr(pos_grad)))
         return x_grad, pos_grad
+
+
+# ---- dense layers (batched_nn.hip) ----
+def split_planes(w, transpose=False):
+    """fp32 matrix [rows][cols] on the device -> (hi, lo) fp16 planes [R][ldp] of it (or of its transpose), ldp = the row
+    length rounded up to 32, zero padded; what nnpops_gemm_split takes as its B operand."""
+    w = _dev_f32(w, "w")
+    src_rows, src_cols = w.shape
+    rows, cols = (src_cols, src_rows) if transpose else (src_rows, src_cols)
+    ldp = (cols + 31) // 32 * 32
+    hi = torch.empty((rows, ldp), dtype=torch.float16, device=w.device)
+    lo = torch.empty_like(hi)
+    _check(lib().nnpops_split_planes(_stream_ptr(w.device), rows, cols, _ptr(w), src_cols, int(transpose), _ptr(hi), _ptr(lo), ldp))
+    return hi, lo
+
+
+def gemm_split(a, planes, bias=None, celu_of=None, alpha=0.1, a_scale=1.0, out=None):
+    """out[M][N] = a[M][K] @ B, B = the planes of an [N][K] matrix (see split_planes).  ``bias``: add it and apply CELU;
+    ``celu_of``: multiply by CELU'(.) of that saved activation instead.  Single problem (the batched / strided form is
+    what the torch op uses)."""
+    a = _dev_f32(a, "a")
+    hi, lo = planes
+    m, k = a.shape
+    n = hi.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    epi = 1 if bias is not None else 2 if celu_of is not None else 0
+    _check(lib().nnpops_gemm_split(_stream_ptr(a.device), m, n, k, 1, _ptr(a), k, 0, _ptr(hi), _ptr(lo), hi.shape[1], 0, _ptr(out), n, 0,
+                                   epi, _ptr(bias) if bias is not None else None, 0, _ptr(celu_of) if celu_of is not None else None, n, 0,
+                                   0, None, 0, 0, None, 0, float(alpha), float(a_scale)))
+    return out

@@ -658,6 +658,135 @@ Tensor BatchedLinear(const Tensor& vectors, const Tensor& weights, const Tensor&
     return BatchedLinearFunction::apply(vectors, weights, biases);
 }
 
-TORCH_LIBRARY(NNPOpsBatchedNN, m) { m.def("BatchedLinear", BatchedLinear); }
+// =============================================================================================
+// GroupedMLP: the atomic networks of one frame, atoms grouped by species, on the split-fp16 GEMM of the C ABI
+// (nnpops_gemm_split, batched_nn.hip).  Same function as BatchedNN.py:100-122 of the reference -- Linear, CELU(0.1),
+// Linear, CELU, Linear, CELU, Linear per atom and ensemble member -- with bias + CELU fused into the GEMM epilogues
+// and CELU' into the epilogues / prologue of the input-gradient pass: six GEMM launches per species and step, no
+// elementwise kernels in between.  Returns the per-atom energies summed over the ensemble members.
+//   x          [atoms, F] fp32, atoms sorted by kind        group_sizes  atoms per kind
+//   fwd_*      planes of the weights, per kind: [M*H1][Fp] | [M*H2][H1p] | [M*H3][H2p]   (p: rounded up to 32)
+//   bwd_*      planes of their transposes, per kind: [F][(M*H1)p] | M x [H1][H2p] | M x [H2][H3p]
+//   biases     per kind: [M*H1] | [M*H2] | [M*H3]           last_w per kind [M*H3], last_b [kinds] (summed over members)
+// =============================================================================================
+constexpr float kCeluAlpha = 0.1f;          // BatchedNN.py:103
+constexpr float kOperandScale = 1.0f / 16;   // operands are split after this scale: |activation| up to 1e6 stays in fp16 range
+
+inline int64_t up32(int64_t v) { return (v + 31) / 32 * 32; }
+
+struct MlpLayout {
+    int64_t F, M, H1, H2, H3;
+    int64_t fwd_kind() const { return M * H1 * up32(F) + M * H2 * up32(H1) + M * H3 * up32(H2); }
+    int64_t bwd_kind() const { return F * up32(M * H1) + M * H1 * up32(H2) + M * H2 * up32(H3); }
+    int64_t bias_kind() const { return M * (H1 + H2 + H3); }
+};
+
+void gemm_checked(int rc) { TORCH_CHECK(rc == NNPOPS_OK, nnpops_last_error()); }
+
+class GroupedMLPFunction : public torch::autograd::Function<GroupedMLPFunction> {
+public:
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1,
+                          int64_t h2, int64_t h3, const Tensor& fwd_hi, const Tensor& fwd_lo, const Tensor& bwd_hi,
+                          const Tensor& bwd_lo, const Tensor& biases, const Tensor& last_w, const Tensor& last_b) {
+        require_device_tensor(x, "x");
+        TORCH_CHECK(x.dim() == 2 && x.scalar_type() == torch::kFloat32 && x.is_contiguous(), "x must be a contiguous [atoms, features] float32 tensor");
+        const MlpLayout L{x.size(1), num_models, h1, h2, h3};
+        const int64_t kinds = (int64_t)group_sizes.size(), atoms = x.size(0);
+        TORCH_CHECK(fwd_hi.numel() == kinds * L.fwd_kind() && bwd_hi.numel() == kinds * L.bwd_kind() &&
+                    biases.numel() == kinds * L.bias_kind() && last_w.numel() == kinds * L.M * L.H3 && last_b.numel() == kinds,
+                    "GroupedMLP: packed parameter buffers do not match the layer widths");
+        c10::hip::HIPGuard guard(x.device().index());
+        void* stream = current_stream(x.device());
+        const auto opts = x.options();
+        Tensor y1 = torch::empty({atoms, L.M * L.H1}, opts), y2 = torch::empty({atoms, L.M * L.H2}, opts), y3 = torch::empty({atoms, L.M * L.H3}, opts);
+        Tensor energies = torch::empty({atoms}, opts);
+        const at::Half* fh = fwd_hi.data_ptr<at::Half>(); const at::Half* fl = fwd_lo.data_ptr<at::Half>();
+        const float* bs = biases.data_ptr<float>();
+        int64_t first = 0;
+        for (int64_t k = 0; k < kinds; k++) {
+            const int64_t n = group_sizes[k];
+            if (n > 0) {
+                const at::Half *h0 = fh + k * L.fwd_kind(), *l0 = fl + k * L.fwd_kind();
+                const at::Half *h1p = h0 + L.M * L.H1 * up32(L.F), *l1p = l0 + L.M * L.H1 * up32(L.F);
+                const at::Half *h2p = h1p + L.M * L.H2 * up32(L.H1), *l2p = l1p + L.M * L.H2 * up32(L.H1);
+                const float* b0 = bs + k * L.bias_kind(); const float* b1 = b0 + L.M * L.H1; const float* b2 = b1 + L.M * L.H2;
+                const float* xs = x.data_ptr<float>() + first * L.F;
+                float* p1 = y1.data_ptr<float>() + first * L.M * L.H1;
+                float* p2 = y2.data_ptr<float>() + first * L.M * L.H2;
+                float* p3 = y3.data_ptr<float>() + first * L.M * L.H3;
+                // layer 0: every member reads the same AEVs -> one GEMM, N = members * H1
+                gemm_checked(nnpops_gemm_split(stream, n, L.M * L.H1, L.F, 1, xs, L.F, 0, h0, l0, up32(L.F), 0, p1, L.M * L.H1, 0, 1, b0, 0,
+                                               nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                // layers 2 and 4: one problem per member
+                gemm_checked(nnpops_gemm_split(stream, n, L.H2, L.H1, L.M, p1, L.M * L.H1, L.H1, h1p, l1p, up32(L.H1), L.H2 * up32(L.H1), p2,
+                                               L.M * L.H2, L.H2, 1, b1, L.H2, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                gemm_checked(nnpops_gemm_split(stream, n, L.H3, L.H2, L.M, p2, L.M * L.H2, L.H2, h2p, l2p, up32(L.H2), L.H3 * up32(L.H2), p3,
+                                               L.M * L.H3, L.H3, 1, b2, L.H3, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                // layer 6: one output per member, summed over the members
+                Tensor e = torch::mv(y3.narrow(0, first, n), last_w.narrow(0, k * L.M * L.H3, L.M * L.H3)) + last_b[k];
+                energies.narrow(0, first, n).copy_(e);
+            }
+            first += n;
+        }
+        TORCH_CHECK(first == atoms, "GroupedMLP: group sizes do not add up to the number of atoms");
+        ctx->save_for_backward({y1, y2, y3, bwd_hi, bwd_lo, last_w});
+        ctx->saved_data["group_sizes"] = group_sizes;
+        ctx->saved_data["dims"] = std::vector<int64_t>{L.F, L.M, L.H1, L.H2, L.H3};
+        return energies;
+    }
+
+    static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor &y1 = saved[0], &y2 = saved[1], &y3 = saved[2], &bwd_hi = saved[3], &bwd_lo = saved[4], &last_w = saved[5];
+        const std::vector<int64_t> group_sizes = ctx->saved_data["group_sizes"].toIntVector();
+        const std::vector<int64_t> d = ctx->saved_data["dims"].toIntVector();
+        const MlpLayout L{d[0], d[1], d[2], d[3], d[4]};
+        const int64_t atoms = y1.size(0);
+        c10::hip::HIPGuard guard(y1.device().index());
+        void* stream = current_stream(y1.device());
+        const auto opts = y1.options();
+        Tensor d2 = torch::empty({atoms, L.M * L.H2}, opts), d1 = torch::empty({atoms, L.M * L.H1}, opts), dx = torch::empty({atoms, L.F}, opts);
+        const at::Half* bh = bwd_hi.data_ptr<at::Half>(); const at::Half* bl = bwd_lo.data_ptr<at::Half>();
+        int64_t first = 0;
+        for (size_t k = 0; k < group_sizes.size(); k++) {
+            const int64_t n = group_sizes[k];
+            if (n > 0) {
+                const at::Half *t0h = bh + k * L.bwd_kind(), *t0l = bl + k * L.bwd_kind();               // [F][(M*H1)p]
+                const at::Half *t1h = t0h + L.F * up32(L.M * L.H1), *t1l = t0l + L.F * up32(L.M * L.H1);  // M x [H1][H2p]
+                const at::Half *t2h = t1h + L.M * L.H1 * up32(L.H2), *t2l = t1l + L.M * L.H1 * up32(L.H2);  // M x [H2][H3p]
+                const float* p1 = y1.data_ptr<float>() + first * L.M * L.H1;
+                const float* p2 = y2.data_ptr<float>() + first * L.M * L.H2;
+                const float* p3 = y3.data_ptr<float>() + first * L.M * L.H3;
+                float* q2 = d2.data_ptr<float>() + first * L.M * L.H2;
+                float* q1 = d1.data_ptr<float>() + first * L.M * L.H1;
+                const float* w6 = last_w.data_ptr<float>() + k * L.M * L.H3;
+                // dE/dy3 = w6 * CELU'(y3) is formed while it is staged (prologue); times W4, times CELU'(y2)
+                gemm_checked(nnpops_gemm_split(stream, n, L.H2, L.H3, L.M, nullptr, 0, 0, t2h, t2l, up32(L.H3), L.H2 * up32(L.H3), q2, L.M * L.H2,
+                                               L.H2, 2, nullptr, 0, p2, L.M * L.H2, L.H2, 1, p3, L.M * L.H3, L.H3, w6, L.H3, kCeluAlpha, kOperandScale));
+                gemm_checked(nnpops_gemm_split(stream, n, L.H1, L.H2, L.M, q2, L.M * L.H2, L.H2, t1h, t1l, up32(L.H2), L.H1 * up32(L.H2), q1, L.M * L.H1,
+                                               L.H1, 2, nullptr, 0, p1, L.M * L.H1, L.H1, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                // all members' first layers at once: K = members * H1
+                gemm_checked(nnpops_gemm_split(stream, n, L.F, L.M * L.H1, 1, q1, L.M * L.H1, 0, t0h, t0l, up32(L.M * L.H1), 0,
+                                               dx.data_ptr<float>() + first * L.F, L.F, 0, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0,
+                                               kCeluAlpha, kOperandScale));
+            }
+            first += n;
+        }
+        Tensor gx = dx * grads[0].unsqueeze(1);             // upstream gradient of every atom's energy
+        return {gx, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor GroupedMLP(const Tensor& x, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1, int64_t h2, int64_t h3,
+                  const Tensor& fwd_hi, const Tensor& fwd_lo, const Tensor& bwd_hi, const Tensor& bwd_lo, const Tensor& biases,
+                  const Tensor& last_w, const Tensor& last_b) {
+    return GroupedMLPFunction::apply(x, group_sizes, num_models, h1, h2, h3, fwd_hi, fwd_lo, bwd_hi, bwd_lo, biases, last_w, last_b);
+}
+
+TORCH_LIBRARY(NNPOpsBatchedNN, m) {
+    m.def("BatchedLinear", BatchedLinear);
+    m.def("GroupedMLP(Tensor x, int[] group_sizes, int num_models, int h1, int h2, int h3, Tensor fwd_hi, Tensor fwd_lo, "
+          "Tensor bwd_hi, Tensor bwd_lo, Tensor biases, Tensor last_w, Tensor last_b) -> Tensor", GroupedMLP);
+}
 
 }  // namespace

@@ -1,0 +1,85 @@
+"""The split-fp16 GEMM behind the ANI atomic networks (batched_nn.hip) against float64 torch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(shape, scale, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(shape, generator=g)).to(DEV)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 32, 16), (64, 1008, 2048), (1333, 1008, 256), (667, 256, 192), (100, 160, 96), (70, 96, 1),
+                                   (129, 33, 130), (2000, 2048, 1008)])
+def test_gemm_matches_float64(M, K, N):
+    from nnpops_amd import capi
+    a = _rand((M, K), 1.5, 1)
+    w = _rand((N, K), 1.0 / np.sqrt(K), 2)                   # a torch Linear weight [out][in]
+    ref = (a.double() @ w.double().t())
+    out = capi.gemm_split(a, capi.split_planes(w))
+    torch.cuda.synchronize()
+    err = (out.double() - ref).abs().max().item()
+    ref32 = (a @ w.t()).double()                               # what the library fp32 GEMM gives
+    err32 = (ref32 - ref).abs().max().item()
+    assert err <= 4e-6 * ref.abs().max().item() + 1e-7, (err, err32)
+    assert err <= 3 * err32 + 1e-6
+
+
+def test_epilogues_and_transpose():
+    from nnpops_amd import capi
+    M, K, N = 300, 224, 192
+    a, w, b = _rand((M, K), 1.0, 3), _rand((N, K), 1.0 / np.sqrt(K), 4), _rand((N,), 0.3, 5)
+    y = capi.gemm_split(a, capi.split_planes(w), bias=b)
+    ref = torch.nn.functional.celu((a.double() @ w.double().t()) + b.double(), alpha=0.1)
+    assert (y.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    # backward step: d_in = (d_out @ W) * celu'(saved activation of the layer below)
+    saved = torch.nn.functional.celu(_rand((M, K), 1.0, 6), alpha=0.1)
+    d_out = _rand((M, N), 1.0, 7)
+    d_in = capi.gemm_split(d_out, capi.split_planes(w, transpose=True), celu_of=saved)
+    grad = torch.where(saved > 0, torch.ones_like(saved), saved / 0.1 + 1.0).double()
+    ref = (d_out.double() @ w.double()) * grad
+    assert (d_in.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+
+
+def test_large_inputs_are_scaled_into_range():
+    from nnpops_amd import capi
+    a = _rand((50, 128), 3.0e4, 8)                            # beyond fp16 without the scale
+    w = _rand((64, 128), 0.1, 9)
+    out = capi.gemm_split(a, capi.split_planes(w), a_scale=2.0 ** -6)
+    ref = a.double() @ w.double().t()
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+
+
+def test_fused_networks_match_the_library_gemm_path():
+    """TorchANIBatchedNN's default layout (GroupedMLP: split-fp16 GEMMs with fused activations) against the same
+    grouping on torch's fp32 library GEMMs: energies and AEV gradients, every ANI-2x species present, 8 members."""
+    from nnpops_amd import workloads
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    model = workloads.torchani_like_model(n_models=8, seed=11)
+    pos, species, _ = workloads.water_box(200, seed=3)
+    species = np.concatenate([species, [1, 2, 4, 6, 5, 1, 2, 2]]).astype(np.int32)
+    numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
+    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu()).to(DEV)
+    grouped = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").to(DEV)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    aev = torch.randn(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4)).abs()
+    a1, a2 = aev.clone().requires_grad_(True), aev.clone().requires_grad_(True)
+    e1, e2 = fused((sp, a1)).energies, grouped((sp, a2)).energies
+    (3.0 * e1.sum()).backward()
+    (3.0 * e2.sum()).backward()
+    # float64 reference of the same networks
+    g64 = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").double().to(DEV)
+    a3 = aev.double().clone().requires_grad_(True)
+    e3 = g64((sp, a3)).energies
+    (3.0 * e3.sum()).backward()
+    assert abs(float(e1) - float(e3)) <= 1e-5 * abs(float(e3)) + 1e-4
+    err_fused = float((a1.grad.double() - a3.grad).abs().max()); err_lib = float((a2.grad.double() - a3.grad).abs().max())
+    scale = float(a3.grad.abs().max())
+    assert err_fused <= 1e-5 * scale, (err_fused, err_lib, scale)
+    assert err_fused <= 3 * err_lib + 1e-7 * scale
+    scripted = torch.jit.script(fused)
+    torch.testing.assert_close(scripted((sp, aev)).energies, e1.detach(), rtol=1e-6, atol=1e-6)
