@@ -31,8 +31,8 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
-constexpr int BM = 64, BN = 128, BK = 32;
-constexpr int kStageBytes = 2 * BM * 64 + 2 * BN * 64;      // A planes + B planes, 64-byte rows
+constexpr int BM = 64, BK = 32;                           // BN = 128 or 64 (template): small problems need the workgroups
+constexpr int stage_bytes(int BN) { return 2 * BM * 64 + 2 * BN * 64; }     // A planes + B planes, 64-byte rows
 
 // byte offset of 16-byte slot `slot` (0..3) of row `row` inside a plane of 64-byte rows
 __device__ __forceinline__ int sw(int row, int slot) {
@@ -55,11 +55,20 @@ struct GemmArgs {
 };
 
 // EPI: 0 plain, 1 bias + CELU, 2 times CELU'(Y).   PRO: 0 A as given, 1 A[m][k] = pv[k] * CELU'(PY[m][k])
-template <int EPI, int PRO>
-__global__ __launch_bounds__(256) void gemm_h2(GemmArgs g) {
+// KS = 2: eight waves, K in steps of 64 -- waves 0-3 take the first 32 of a step, waves 4-7 the second, and the two halves
+// are added through LDS at the end.  For problems too small to give every CU several workgroups (the layers of one
+// species of a 2 000-atom frame) this doubles the waves that hide each other's latency and halves the number of steps.
+template <int EPI, int PRO, int BN, int KS>
+__global__ __launch_bounds__(256 * KS) void gemm_h2(GemmArgs g) {
+    constexpr int NB = BN / 32;                             // 16-column blocks per wave (2 x NB MFMA blocks)
+    constexpr int kSubBytes = stage_bytes(BN);              // one 32-wide K sub-step: A planes + B planes
+    constexpr int kStageBytes = KS * kSubBytes;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave8 = threadIdx.x >> 6;
+    const int sub = KS == 2 ? wave8 >> 2 : 0;               // which half of a K step this wave (and its loads) serves
+    const int tid = threadIdx.x & 255, wave = wave8 & 3;
     const int wm = wave & 1, wn = wave >> 1;
+    const int kpad = (g.K + 31) & ~31;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, b = blockIdx.z;
     const float* A = PRO == 0 ? g.A + (size_t)b * g.strideA : g.PY + (size_t)b * g.stridePY;
     const long lda = PRO == 0 ? g.lda : g.ldpy;
@@ -72,13 +81,15 @@ __global__ __launch_bounds__(256) void gemm_h2(GemmArgs g) {
     const int srow = tid >> 2, sslot = tid & 3;
     const bool a_row_ok = m0 + srow < g.M;
     const float* a_src = A + (size_t)(m0 + (a_row_ok ? srow : 0)) * lda + sslot * 8;
-    const bool b_ok0 = n0 + srow < g.N, b_ok1 = n0 + srow + 64 < g.N;
+    const bool b_ok0 = n0 + srow < g.N, b_ok1 = BN == 128 && n0 + srow + 64 < g.N;
     const size_t b_off0 = (size_t)(n0 + (b_ok0 ? srow : 0)) * g.ldb + sslot * 8;
     const size_t b_off1 = (size_t)(n0 + (b_ok1 ? srow + 64 : 0)) * g.ldb + sslot * 8;
 
-    float av[8];
-    f16x8 bh0, bl0, bh1, bl1;
-    auto fetch = [&](int k0) {
+    struct Regs { float av[8]; f16x8 bh0, bl0, bh1, bl1; };
+    auto fetch = [&](int kstep, Regs& R) {
+        const int k0 = kstep + 32 * sub;
+        float (&av)[8] = R.av;
+        f16x8 &bh0 = R.bh0, &bl0 = R.bl0, &bh1 = R.bh1, &bl1 = R.bl1;
         const int k = k0 + sslot * 8;
 #pragma unroll
         for (int i = 0; i < 8; i++) av[i] = 0.f;
@@ -96,12 +107,18 @@ __global__ __launch_bounds__(256) void gemm_h2(GemmArgs g) {
             }
         }
         const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        bh0 = b_ok0 ? *reinterpret_cast<const f16x8*>(Bh + b_off0 + k0) : zero;
-        bl0 = b_ok0 ? *reinterpret_cast<const f16x8*>(Bl + b_off0 + k0) : zero;
-        bh1 = b_ok1 ? *reinterpret_cast<const f16x8*>(Bh + b_off1 + k0) : zero;
-        bl1 = b_ok1 ? *reinterpret_cast<const f16x8*>(Bl + b_off1 + k0) : zero;
+        const bool k_ok = k0 < kpad;                         // (KS = 2: the second half of the last step may lie past the planes)
+        bh0 = b_ok0 && k_ok ? *reinterpret_cast<const f16x8*>(Bh + b_off0 + k0) : zero;
+        bl0 = b_ok0 && k_ok ? *reinterpret_cast<const f16x8*>(Bl + b_off0 + k0) : zero;
+        if (BN == 128) {
+            bh1 = b_ok1 && k_ok ? *reinterpret_cast<const f16x8*>(Bh + b_off1 + k0) : zero;
+            bl1 = b_ok1 && k_ok ? *reinterpret_cast<const f16x8*>(Bl + b_off1 + k0) : zero;
+        }
     };
-    auto stage = [&](char* base) {
+    auto stage = [&](char* stage_base, const Regs& R) {
+        char* base = stage_base + sub * kSubBytes;
+        const float (&av)[8] = R.av;
+        const f16x8 &bh0 = R.bh0, &bl0 = R.bl0, &bh1 = R.bh1, &bl1 = R.bl1;
         char* a_h = base; char* a_l = base + BM * 64;
         char* s_bh = base + 2 * BM * 64; char* s_bl = s_bh + BN * 64;
         f16x8 h, l;
@@ -115,24 +132,22 @@ __global__ __launch_bounds__(256) void gemm_h2(GemmArgs g) {
         *reinterpret_cast<f16x8*>(a_l + sw(srow, sslot)) = l;
         *reinterpret_cast<f16x8*>(s_bh + sw(srow, sslot)) = bh0;
         *reinterpret_cast<f16x8*>(s_bl + sw(srow, sslot)) = bl0;
-        *reinterpret_cast<f16x8*>(s_bh + sw(srow + 64, sslot)) = bh1;
-        *reinterpret_cast<f16x8*>(s_bl + sw(srow + 64, sslot)) = bl1;
+        if (BN == 128) {
+            *reinterpret_cast<f16x8*>(s_bh + sw(srow + 64, sslot)) = bh1;
+            *reinterpret_cast<f16x8*>(s_bl + sw(srow + 64, sslot)) = bl1;
+        }
     };
 
-    f32x4 acc1[2][4], acc2[2][4];
+    f32x4 acc1[2][NB], acc2[2][NB];
 #pragma unroll
     for (int mb = 0; mb < 2; mb++)
 #pragma unroll
-        for (int nb = 0; nb < 4; nb++) { acc1[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int nb = 0; nb < NB; nb++) { acc1[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const int ksteps = (g.K + BK - 1) / BK;
-    fetch(0);
-    stage(lds);
-    __syncthreads();
+    const int ksteps = (g.K + BK * KS - 1) / (BK * KS);
     const int r16 = lane & 15, kg = lane >> 4;
-    for (int s = 0; s < ksteps; s++) {
-        char* cur = lds + (s & 1) * kStageBytes;
-        if (s + 1 < ksteps) fetch((s + 1) * BK);            // in flight during the MFMAs below
+    auto compute = [&](const char* stage_base) {
+        const char* cur = stage_base + sub * kSubBytes;
         const char* a_h = cur; const char* a_l = cur + BM * 64;
         const char* s_bh = cur + 2 * BM * 64; const char* s_bl = s_bh + BN * 64;
         f16x8 ah[2], al[2];
@@ -143,8 +158,8 @@ __global__ __launch_bounds__(256) void gemm_h2(GemmArgs g) {
             al[mb] = *reinterpret_cast<const f16x8*>(a_l + sw(row, kg));
         }
 #pragma unroll
-        for (int nb = 0; nb < 4; nb++) {
-            const int row = wn * 64 + nb * 16 + r16;
+        for (int nb = 0; nb < NB; nb++) {
+            const int row = wn * (BN / 2) + nb * 16 + r16;
             const f16x8 bh = *reinterpret_cast<const f16x8*>(s_bh + sw(row, kg));
             const f16x8 bl = *reinterpret_cast<const f16x8*>(s_bl + sw(row, kg));
 #pragma unroll
@@ -154,18 +169,48 @@ __global__ __launch_bounds__(256) void gemm_h2(GemmArgs g) {
                 acc2[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], bh, acc2[mb][nb], 0, 0, 0);
             }
         }
-        if (s + 1 < ksteps) stage(lds + ((s + 1) & 1) * kStageBytes);
+    };
+    // The loads of K step s + 1 are issued before the MFMAs of step s and written to LDS after them.  (A second register
+    // set, two steps ahead, costs the third workgroup per CU -- 176 registers -- and loses more than it hides.)
+    Regs R;
+    fetch(0, R);
+    stage(lds, R);
+    __syncthreads();
+    for (int s = 0; s < ksteps; s++) {
+        if (s + 1 < ksteps) fetch((s + 1) * BK * KS, R);
+        compute(lds + (s & 1) * kStageBytes);
+        if (s + 1 < ksteps) stage(lds + ((s + 1) & 1) * kStageBytes, R);
         __syncthreads();
     }
 
+    if constexpr (KS == 2) {                                // the second half hands its sums over (16 * NB floats per lane)
+        float* red = reinterpret_cast<float*>(lds);
+        if (sub == 1) {
+#pragma unroll
+            for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        red[((mb * NB + nb) * 4 + q) * 256 + tid] = acc1[mb][nb][q] + kLoInv * acc2[mb][nb][q];
+        }
+        __syncthreads();
+        if (sub == 1) return;
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc1[mb][nb][q] += red[((mb * NB + nb) * 4 + q) * 256 + tid];
+    }
     // ---- epilogue: D[row = 4 * (lane >> 4) + q][col = lane & 15] of every block ----
     const float out_scale = 1.0f / g.a_scale;
     float* C = g.C + (size_t)b * g.strideC;
     const float* bias = EPI == 1 ? g.bias + (size_t)b * g.strideBias : nullptr;
     const float* Y = EPI == 2 ? g.Y + (size_t)b * g.strideY : nullptr;
 #pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
-        const int col = n0 + wn * 64 + nb * 16 + r16;
+    for (int nb = 0; nb < NB; nb++) {
+        const int col = n0 + wn * (BN / 2) + nb * 16 + r16;
         if (col >= g.N) continue;
         const float bv = EPI == 1 ? bias[col] : 0.f;
 #pragma unroll
@@ -230,10 +275,20 @@ int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float*
     NNPOPS_REQUIRE(alpha > 0 && a_scale > 0, "alpha and a_scale must be positive");
     GemmArgs g{M, N, K, A, lda, strideA, (const _Float16*)Bh, (const _Float16*)Bl, ldb, strideB, C, ldc, strideC, bias, strideBias,
                Y, ldy, strideY, PY, ldpy, stridePY, pv, stridePv, alpha, a_scale};
-    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
-    const size_t lds = 2 * kStageBytes;
+    // 64 x 128 tiles, four waves, when they still give every CU a few workgroups; otherwise 64 x 64 tiles with eight waves
+    // splitting every K step (the layers of one species of a 2 000-atom frame are 10-300 tiles: one wave per SIMD hides
+    // nothing)
+    const long tiles128 = (long)((N + 127) / 128) * ((M + BM - 1) / BM) * batch;
+    const long tiles64 = (long)((N + 63) / 64) * ((M + BM - 1) / BM) * batch;
+    const int shape = tiles128 >= 1024 ? 0 : tiles64 >= 600 ? 1 : 2;      // 0: 64x128 | 1: 64x64 | 2: 64x64, eight waves splitting K
+    const int bn = shape == 0 ? 128 : 64;
+    const dim3 grid((N + bn - 1) / bn, (M + BM - 1) / BM, batch);
+    const size_t lds = (shape == 2 ? 2 : 1) * 2 * stage_bytes(bn);
     hipStream_t st = (hipStream_t)stream;
-#define NNPOPS_LAUNCH_GEMM(E, P) hipLaunchKernelGGL((gemm_h2<E, P>), grid, dim3(256), lds, st, g)
+#define NNPOPS_LAUNCH_GEMM(E, P) \
+    do { if (shape == 0) hipLaunchKernelGGL((gemm_h2<E, P, 128, 1>), grid, dim3(256), lds, st, g); \
+         else if (shape == 1) hipLaunchKernelGGL((gemm_h2<E, P, 64, 1>), grid, dim3(256), lds, st, g); \
+         else hipLaunchKernelGGL((gemm_h2<E, P, 64, 2>), grid, dim3(512), lds, st, g); } while (0)
     if (prologue == 0) {
         if (epilogue == 0) NNPOPS_LAUNCH_GEMM(0, 0); else if (epilogue == 1) NNPOPS_LAUNCH_GEMM(1, 0); else NNPOPS_LAUNCH_GEMM(2, 0);
     } else {
