@@ -201,6 +201,8 @@ int nnpops_split_planes(void* stream, int rows, int cols, const float* w, long l
  * epilogue 0: none; 1: C = CELU(C + bias[N], alpha); 2: C *= CELU'(Y) with Y [M][ldy] a saved CELU OUTPUT.
  * prologue 0: A as given; 1: A[m][k] = pv[k] * CELU'(PY[m][k]) (A itself is not read).
  * a_scale: A is multiplied by it before the split (and C divided by it): keep |A| * a_scale below 6e4. */
+/* out[m] = A[m][0..K) . w + bias (the networks' last layer: one output per member, summed over the members). */
+int nnpops_rows_dot(void* stream, int M, int K, const float* A, long lda, const float* w, float bias, float* out);
 int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float* A, long lda, long strideA, const void* Bh,
                       const void* Bl, long ldb, long strideB, float* C, long ldc, long strideC, int epilogue, const float* bias,
                       long strideBias, const float* Y, long ldy, long strideY, int prologue, const float* PY, long ldpy,

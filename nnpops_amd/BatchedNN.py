@@ -167,7 +167,8 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         self.h1 = int(self.layer0_weights.shape[2])
         self.h2 = int(self.layer2_weights.shape[2])
         self.h3 = int(self.layer4_weights.shape[2])
-        for name in ('fwd_hi', 'fwd_lo', 'bwd_hi', 'bwd_lo', 'packed_biases', 'last_w', 'last_b'):
+        self.last_b: List[float] = []
+        for name in ('fwd_hi', 'fwd_lo', 'bwd_hi', 'bwd_lo', 'packed_biases', 'last_w'):
             self.register_buffer(name, torch.empty(0), persistent=False)
         self._refresh_planes()
 
@@ -188,12 +189,12 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
                     los.append(lo.reshape(-1))
             biases += [self.layer0_biases[k].reshape(-1), self.layer2_biases[k].reshape(-1), self.layer4_biases[k].reshape(-1)]
             last_w.append(w6[k][:, 0, :].reshape(-1))
-            last_b.append(self.layer6_biases[k].sum().reshape(1))
+            last_b.append(float(self.layer6_biases[k].sum()))
         self.fwd_hi, self.fwd_lo = torch.cat(fwd_hi), torch.cat(fwd_lo)
         self.bwd_hi, self.bwd_lo = torch.cat(bwd_hi), torch.cat(bwd_lo)
         self.packed_biases = torch.cat(biases).float().contiguous()
         self.last_w = torch.cat(last_w).float().contiguous()
-        self.last_b = torch.cat(last_b).float().contiguous()
+        self.last_b = last_b
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)

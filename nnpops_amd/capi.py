@@ -55,6 +55,7 @@ SIGNATURES = {
     "nnpops_cfconv_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "nnpops_split_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long]),
+    "nnpops_rows_dot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_float, C.c_void_p]),
     "nnpops_gemm_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p,
                                     C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long,
                                     C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long,

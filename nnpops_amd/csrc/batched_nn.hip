@@ -246,9 +246,38 @@ __global__ __launch_bounds__(256) void split_planes(int rows, int cols, const fl
     }
 }
 
+// out[m] = A[m][0..K) . w + bias : the last layer of the networks (one output per member, summed over the members).
+// One wave per row, float4 loads.
+__global__ __launch_bounds__(256) void rows_dot(int M, int K, const float* __restrict__ A, long lda, const float* __restrict__ w,
+                                                float bias, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* a = A + (size_t)row * lda;
+    float acc = 0.f;
+    if ((K & 3) == 0 && (lda & 3) == 0) {
+        for (int k = 4 * lane; k < K; k += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(a + k), y = *reinterpret_cast<const float4*>(w + k);
+            acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) acc += a[k] * w[k];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[row] = acc + bias;
+}
+
 }  // namespace
 
 extern "C" {
+
+int nnpops_rows_dot(void* stream, int M, int K, const float* A, long lda, const float* w, float bias, float* out) {
+    NNPOPS_REQUIRE(M > 0 && K > 0 && A && w && out, "empty problem or NULL device pointer");
+    hipLaunchKernelGGL(rows_dot, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, M, K, A, lda, w, bias, out);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
 
 int nnpops_split_planes(void* stream, int rows, int cols, const float* w, long ldw, int transpose, void* hi, void* lo, long ldp) {
     NNPOPS_REQUIRE(w && hi && lo, "NULL device pointer");

@@ -667,7 +667,7 @@ Tensor BatchedLinear(const Tensor& vectors, const Tensor& weights, const Tensor&
 //   x          [atoms, F] fp32, atoms sorted by kind        group_sizes  atoms per kind
 //   fwd_*      planes of the weights, per kind: [M*H1][Fp] | [M*H2][H1p] | [M*H3][H2p]   (p: rounded up to 32)
 //   bwd_*      planes of their transposes, per kind: [F][(M*H1)p] | M x [H1][H2p] | M x [H2][H3p]
-//   biases     per kind: [M*H1] | [M*H2] | [M*H3]           last_w per kind [M*H3], last_b [kinds] (summed over members)
+//   biases     per kind: [M*H1] | [M*H2] | [M*H3]           last_w per kind [M*H3], last_b per kind (summed over members)
 // =============================================================================================
 constexpr float kCeluAlpha = 0.1f;          // BatchedNN.py:103
 constexpr float kOperandScale = 1.0f / 16;   // operands are split after this scale: |activation| up to 1e6 stays in fp16 range
@@ -687,13 +687,13 @@ class GroupedMLPFunction : public torch::autograd::Function<GroupedMLPFunction> 
 public:
     static Tensor forward(AutogradContext* ctx, const Tensor& x, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1,
                           int64_t h2, int64_t h3, const Tensor& fwd_hi, const Tensor& fwd_lo, const Tensor& bwd_hi,
-                          const Tensor& bwd_lo, const Tensor& biases, const Tensor& last_w, const Tensor& last_b) {
+                          const Tensor& bwd_lo, const Tensor& biases, const Tensor& last_w, std::vector<double> last_b_host) {
         require_device_tensor(x, "x");
         TORCH_CHECK(x.dim() == 2 && x.scalar_type() == torch::kFloat32 && x.is_contiguous(), "x must be a contiguous [atoms, features] float32 tensor");
         const MlpLayout L{x.size(1), num_models, h1, h2, h3};
         const int64_t kinds = (int64_t)group_sizes.size(), atoms = x.size(0);
         TORCH_CHECK(fwd_hi.numel() == kinds * L.fwd_kind() && bwd_hi.numel() == kinds * L.bwd_kind() &&
-                    biases.numel() == kinds * L.bias_kind() && last_w.numel() == kinds * L.M * L.H3 && last_b.numel() == kinds,
+                    biases.numel() == kinds * L.bias_kind() && last_w.numel() == kinds * L.M * L.H3,
                     "GroupedMLP: packed parameter buffers do not match the layer widths");
         c10::hip::HIPGuard guard(x.device().index());
         void* stream = current_stream(x.device());
@@ -702,6 +702,7 @@ public:
         Tensor energies = torch::empty({atoms}, opts);
         const at::Half* fh = fwd_hi.data_ptr<at::Half>(); const at::Half* fl = fwd_lo.data_ptr<at::Half>();
         const float* bs = biases.data_ptr<float>();
+        TORCH_CHECK((int64_t)last_b_host.size() == kinds, "GroupedMLP: one last-layer bias per kind");
         int64_t first = 0;
         for (int64_t k = 0; k < kinds; k++) {
             const int64_t n = group_sizes[k];
@@ -723,8 +724,8 @@ public:
                 gemm_checked(nnpops_gemm_split(stream, n, L.H3, L.H2, L.M, p2, L.M * L.H2, L.H2, h2p, l2p, up32(L.H2), L.H3 * up32(L.H2), p3,
                                                L.M * L.H3, L.H3, 1, b2, L.H3, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
                 // layer 6: one output per member, summed over the members
-                Tensor e = torch::mv(y3.narrow(0, first, n), last_w.narrow(0, k * L.M * L.H3, L.M * L.H3)) + last_b[k];
-                energies.narrow(0, first, n).copy_(e);
+                gemm_checked(nnpops_rows_dot(stream, n, L.M * L.H3, p3, L.M * L.H3, last_w.data_ptr<float>() + k * L.M * L.H3, last_b_host[k],
+                                             energies.data_ptr<float>() + first));
             }
             first += n;
         }
@@ -779,14 +780,14 @@ public:
 
 Tensor GroupedMLP(const Tensor& x, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1, int64_t h2, int64_t h3,
                   const Tensor& fwd_hi, const Tensor& fwd_lo, const Tensor& bwd_hi, const Tensor& bwd_lo, const Tensor& biases,
-                  const Tensor& last_w, const Tensor& last_b) {
+                  const Tensor& last_w, std::vector<double> last_b) {
     return GroupedMLPFunction::apply(x, group_sizes, num_models, h1, h2, h3, fwd_hi, fwd_lo, bwd_hi, bwd_lo, biases, last_w, last_b);
 }
 
 TORCH_LIBRARY(NNPOpsBatchedNN, m) {
     m.def("BatchedLinear", BatchedLinear);
     m.def("GroupedMLP(Tensor x, int[] group_sizes, int num_models, int h1, int h2, int h3, Tensor fwd_hi, Tensor fwd_lo, "
-          "Tensor bwd_hi, Tensor bwd_lo, Tensor biases, Tensor last_w, Tensor last_b) -> Tensor", GroupedMLP);
+          "Tensor bwd_hi, Tensor bwd_lo, Tensor biases, Tensor last_w, float[] last_b) -> Tensor", GroupedMLP);
 }
 
 }  // namespace
