@@ -360,11 +360,13 @@ def main_torchani(args):
         "metric": "OptimizedTorchANI energy+forces evaluations/sec, 2001-atom periodic water box, 8 models, fp32",
         "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" + (" (network GEMMs: operands split into two fp16 planes, products exact, fp32 accumulation)" if args.nn_layout == "fused" else ""),
+        "data": "synthetic",
         "config": {"workload": f"OptimizedTorchANI, {n}-atom periodic water box (667 H2O), ANI-2x AEV + 8 x ANI-2x-shaped networks, "
                                f"random weights, BatchedNN layout = {args.nn_layout}" + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
                    "nn_weight_bytes": nn_weight_bytes},
-        "roofline": {"bound": "mfma", "kernel": "BatchedNN GEMMs (hipBLASLt via torch.matmul), forward + input-gradient backward",
+        "roofline": {"bound": "mfma", "kernel": ("gemm_h2 (batched_nn.hip: split-fp16 GEMMs with fused activations)" if args.nn_layout == "fused"
+                                                else "BatchedNN GEMMs (hipBLASLt via torch.matmul)") + ", forward + input-gradient backward",
                      "achieved": round(2 * flops_fwd / elapsed * args.steps / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
                      "frac": round(2 * flops_fwd / elapsed * args.steps / 1e12 / 157.3, 5), "traffic": None,
                      "note": "whole step time (AEV + NN + autograd overhead) against the NN's algorithmic flops; fp32 matrix peak"},
