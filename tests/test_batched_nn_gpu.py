@@ -83,3 +83,31 @@ def test_fused_networks_match_the_library_gemm_path():
     assert err_fused <= 3 * err_lib + 1e-7 * scale
     scripted = torch.jit.script(fused)
     torch.testing.assert_close(scripted((sp, aev)).energies, e1.detach(), rtol=1e-6, atol=1e-6)
+
+
+def test_fused_networks_edge_cases():
+    """A species with a single atom, species that do not occur at all, inference without gradients, and the paths the
+    fused op hands back to the library GEMMs (two molecules in a frame, float64)."""
+    from nnpops_amd import workloads
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    model = workloads.torchani_like_model(n_models=2, seed=21)
+    species = np.array([0] * 37 + [3] * 5 + [6], dtype=np.int32)            # H, O and one Cl: four kinds never occur
+    numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
+    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu()).to(DEV)
+    grouped = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").to(DEV)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    aev = torch.randn(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).abs()
+    with torch.no_grad():
+        e1, e2 = fused((sp, aev)).energies, grouped((sp, aev)).energies
+    torch.testing.assert_close(e1, e2, rtol=1e-5, atol=1e-4)
+    a1, a2 = aev.clone().requires_grad_(True), aev.clone().requires_grad_(True)
+    fused((sp, a1)).energies.sum().backward()
+    grouped((sp, a2)).energies.sum().backward()
+    torch.testing.assert_close(a1.grad, a2.grad, rtol=1e-4, atol=1e-5 * float(a2.grad.abs().max()))
+    # two molecules per frame and float64 inputs go through the library GEMMs
+    two = torch.cat([aev, 0.5 * aev], 0)
+    e_two = fused((sp.expand(2, -1), two)).energies
+    assert e_two.shape == (2,)
+    torch.testing.assert_close(e_two[0:1], e2, rtol=1e-5, atol=1e-4)
+    e64 = fused.double()((sp, aev.double())).energies
+    assert e64.dtype == torch.float64 and abs(float(e64) - float(e2)) <= 1e-5 * abs(float(e2)) + 1e-4
