@@ -202,7 +202,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
 
     def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
         species, aev = species_aev
-        if aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32:
+        if aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32 or self.fwd_hi.dtype != torch.float16:
             return self._grouped_forward(species_aev)
         x = aev[0].index_select(0, self.atom_order)                         # [atoms, features], grouped by species
         per_atom = torch.ops.NNPOpsBatchedNN.GroupedMLP(x, self.group_sizes, self.num_models, self.h1, self.h2, self.h3,
