@@ -168,6 +168,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         self.h2 = int(self.layer2_weights.shape[2])
         self.h3 = int(self.layer4_weights.shape[2])
         self.last_b: List[float] = []
+        self.fused_ok = True
         for name in ('fwd_hi', 'fwd_lo', 'bwd_hi', 'bwd_lo', 'packed_biases', 'last_w'):
             self.register_buffer(name, torch.empty(0), persistent=False)
         self._refresh_planes()
@@ -192,6 +193,13 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
             last_b.append(float(self.layer6_biases[k].sum()))
         self.fwd_hi, self.fwd_lo = torch.cat(fwd_hi), torch.cat(fwd_lo)
         self.bwd_hi, self.bwd_lo = torch.cat(bwd_hi), torch.cat(bwd_lo)
+        # the split GEMM scales its A operand by 1/16 before the fp16 split: activations must stay below ~1e6.  A crude
+        # bound from the weights (AEV entries are sums of at most a few dozen terms <= 1) decides; networks that could
+        # exceed it keep the library-GEMM path.
+        bound = torch.full((1,), 64.0, device=w0.device)
+        for w, b in ((w0, self.layer0_biases), (w2, self.layer2_biases), (w4, self.layer4_biases)):
+            bound = (w.abs().sum(-1).amax() * bound + b.abs().amax()).reshape(1)
+        self.fused_ok = bool(torch.isfinite(bound).all()) and float(bound) < 1.0e6
         self.packed_biases = torch.cat(biases).float().contiguous()
         self.last_w = torch.cat(last_w).float().contiguous()
         self.last_b = last_b
@@ -202,7 +210,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
 
     def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
         species, aev = species_aev
-        if aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32 or self.fwd_hi.dtype != torch.float16:
+        if aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32 or self.fwd_hi.dtype != torch.float16 or not self.fused_ok:
             return self._grouped_forward(species_aev)
         x = aev[0].index_select(0, self.atom_order)                         # [atoms, features], grouped by species
         per_atom = torch.ops.NNPOpsBatchedNN.GroupedMLP(x, self.group_sizes, self.num_models, self.h1, self.h2, self.h3,

@@ -111,3 +111,21 @@ def test_fused_networks_edge_cases():
     torch.testing.assert_close(e_two[0:1], e2, rtol=1e-5, atol=1e-4)
     e64 = fused.double()((sp, aev.double())).energies
     assert e64.dtype == torch.float64 and abs(float(e64) - float(e2)) <= 1e-5 * abs(float(e2)) + 1e-4
+
+
+def test_networks_with_huge_weights_keep_the_library_gemms():
+    """The fused path carries activations through fp16 planes (after a 1/16 scale): networks whose weights allow
+    activations beyond ~1e6 are detected when the operand planes are built and evaluated by the library GEMMs instead."""
+    from nnpops_amd import workloads
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    model = workloads.torchani_like_model(n_models=1, seed=31)
+    for net in model.neural_networks[0].values():
+        net[2].weight.data *= 300.0
+    species = np.array([0, 0, 3, 1], dtype=np.int32)
+    numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
+    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu()).to(DEV)
+    grouped = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").to(DEV)
+    assert not fused[0].fused_ok
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    aev = torch.rand(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    torch.testing.assert_close(fused((sp, aev)).energies, grouped((sp, aev)).energies, rtol=1e-6, atol=1e-6)
