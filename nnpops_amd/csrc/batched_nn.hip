@@ -58,7 +58,10 @@ struct GemmArgs {
 // KS = 2: eight waves, K in steps of 64 -- waves 0-3 take the first 32 of a step, waves 4-7 the second, and the two halves
 // are added through LDS at the end.  For problems too small to give every CU several workgroups (the layers of one
 // species of a 2 000-atom frame) this doubles the waves that hide each other's latency and halves the number of steps.
-template <int EPI, int PRO, int BN, int KS>
+// FAST (K a multiple of 8, rows of A 16-byte aligned: every layer of the networks): the staging loads are straight-line
+// 16-byte loads from clamped addresses, masked afterwards -- a branch around a load makes the compiler drain the whole
+// load queue (s_waitcnt vmcnt(0)) where the paths meet, inside the very function that is meant to run ahead.
+template <int EPI, int PRO, int BN, int KS, bool FAST>
 __global__ __launch_bounds__(256 * KS) void gemm_h2(GemmArgs g) {
     constexpr int NB = BN / 32;                             // 16-column blocks per wave (2 x NB MFMA blocks)
     constexpr int kSubBytes = stage_bytes(BN);              // one 32-wide K sub-step: A planes + B planes
@@ -85,12 +88,35 @@ __global__ __launch_bounds__(256 * KS) void gemm_h2(GemmArgs g) {
     const size_t b_off0 = (size_t)(n0 + (b_ok0 ? srow : 0)) * g.ldb + sslot * 8;
     const size_t b_off1 = (size_t)(n0 + (b_ok1 ? srow + 64 : 0)) * g.ldb + sslot * 8;
 
-    struct Regs { float av[8]; f16x8 bh0, bl0, bh1, bl1; };
+    struct Regs { float av[8]; float pw[PRO == 1 ? 8 : 1]; f16x8 bh0, bl0, bh1, bl1; bool a_ok, b_ok; };
     auto fetch = [&](int kstep, Regs& R) {
         const int k0 = kstep + 32 * sub;
         float (&av)[8] = R.av;
         f16x8 &bh0 = R.bh0, &bl0 = R.bl0, &bh1 = R.bh1, &bl1 = R.bl1;
         const int k = k0 + sslot * 8;
+        const bool k_ok = k0 < kpad;                         // (KS = 2: the second half of the last step may lie past the planes)
+        if constexpr (FAST) {
+            const bool k_in = k < g.K;                      // (all eight or none)
+            const float* src = a_src + (k_in ? k0 : -sslot * 8);
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            av[0] = lo.x; av[1] = lo.y; av[2] = lo.z; av[3] = lo.w; av[4] = hi.x; av[5] = hi.y; av[6] = hi.z; av[7] = hi.w;
+            if constexpr (PRO == 1) {
+                const float* ps = pv + (k_in ? k : 0);
+                const float4 plo = *reinterpret_cast<const float4*>(ps), phi = *reinterpret_cast<const float4*>(ps + 4);
+                R.pw[0] = plo.x; R.pw[1] = plo.y; R.pw[2] = plo.z; R.pw[3] = plo.w; R.pw[4] = phi.x; R.pw[5] = phi.y; R.pw[6] = phi.z; R.pw[7] = phi.w;
+            }
+            const int kb = k_ok ? k0 : 0;
+            bh0 = *reinterpret_cast<const f16x8*>(Bh + b_off0 + kb);
+            bl0 = *reinterpret_cast<const f16x8*>(Bl + b_off0 + kb);
+            if (BN == 128) {
+                bh1 = *reinterpret_cast<const f16x8*>(Bh + b_off1 + kb);
+                bl1 = *reinterpret_cast<const f16x8*>(Bl + b_off1 + kb);
+            }
+            R.a_ok = a_row_ok && k_in;
+            R.b_ok = k_ok;
+            return;
+        }
+        R.a_ok = true; R.b_ok = true;
 #pragma unroll
         for (int i = 0; i < 8; i++) av[i] = 0.f;
         if (a_row_ok) {
@@ -107,7 +133,6 @@ __global__ __launch_bounds__(256 * KS) void gemm_h2(GemmArgs g) {
             }
         }
         const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bool k_ok = k0 < kpad;                         // (KS = 2: the second half of the last step may lie past the planes)
         bh0 = b_ok0 && k_ok ? *reinterpret_cast<const f16x8*>(Bh + b_off0 + k0) : zero;
         bl0 = b_ok0 && k_ok ? *reinterpret_cast<const f16x8*>(Bl + b_off0 + k0) : zero;
         if (BN == 128) {
@@ -121,20 +146,25 @@ __global__ __launch_bounds__(256 * KS) void gemm_h2(GemmArgs g) {
         const f16x8 &bh0 = R.bh0, &bl0 = R.bl0, &bh1 = R.bh1, &bl1 = R.bl1;
         char* a_h = base; char* a_l = base + BM * 64;
         char* s_bh = base + 2 * BM * 64; char* s_bl = s_bh + BN * 64;
+        const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float scale = R.a_ok ? g.a_scale : 0.f;       // (FAST: out-of-range rows / k were read from a valid address)
         f16x8 h, l;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float v = av[i] * g.a_scale;
+            float v = av[i];
+            if constexpr (FAST && PRO == 1) v = R.pw[i] * celu_grad_from_output(v, inv_alpha);
+            v *= scale;
             h[i] = (_Float16)v;
             l[i] = (_Float16)((v - (float)h[i]) * kLoScale);
         }
+        const bool k0_ok = !FAST || (b_ok0 && R.b_ok), k1_ok = !FAST || (b_ok1 && R.b_ok);
         *reinterpret_cast<f16x8*>(a_h + sw(srow, sslot)) = h;
         *reinterpret_cast<f16x8*>(a_l + sw(srow, sslot)) = l;
-        *reinterpret_cast<f16x8*>(s_bh + sw(srow, sslot)) = bh0;
-        *reinterpret_cast<f16x8*>(s_bl + sw(srow, sslot)) = bl0;
+        *reinterpret_cast<f16x8*>(s_bh + sw(srow, sslot)) = k0_ok ? bh0 : zero;
+        *reinterpret_cast<f16x8*>(s_bl + sw(srow, sslot)) = k0_ok ? bl0 : zero;
         if (BN == 128) {
-            *reinterpret_cast<f16x8*>(s_bh + sw(srow + 64, sslot)) = bh1;
-            *reinterpret_cast<f16x8*>(s_bl + sw(srow + 64, sslot)) = bl1;
+            *reinterpret_cast<f16x8*>(s_bh + sw(srow + 64, sslot)) = k1_ok ? bh1 : zero;
+            *reinterpret_cast<f16x8*>(s_bl + sw(srow + 64, sslot)) = k1_ok ? bl1 : zero;
         }
     };
 
@@ -314,16 +344,24 @@ int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float*
     const dim3 grid((N + bn - 1) / bn, (M + BM - 1) / BM, batch);
     const size_t lds = (shape == 2 ? 2 : 1) * 2 * stage_bytes(bn);
     hipStream_t st = (hipStream_t)stream;
-#define NNPOPS_LAUNCH_GEMM(E, P) \
-    do { if (shape == 0) hipLaunchKernelGGL((gemm_h2<E, P, 128, 1>), grid, dim3(256), lds, st, g); \
-         else if (shape == 1) hipLaunchKernelGGL((gemm_h2<E, P, 64, 1>), grid, dim3(256), lds, st, g); \
-         else hipLaunchKernelGGL((gemm_h2<E, P, 64, 2>), grid, dim3(512), lds, st, g); } while (0)
+    const long lda_eff = prologue == 1 ? ldpy : lda;
+    const float* a_eff = prologue == 1 ? PY : A;
+    const bool fast = (K % 8) == 0 && (lda_eff % 4) == 0 && ((uintptr_t)a_eff % 16) == 0 &&
+                      (batch == 1 || ((prologue == 1 ? stridePY : strideA) % 4) == 0) &&
+                      (prologue == 0 || (((uintptr_t)pv % 16) == 0 && (stridePv % 4) == 0)) &&
+                      !(std::getenv("NNPOPS_GEMM_FAST") && std::atoi(std::getenv("NNPOPS_GEMM_FAST")) == 0);
+#define NNPOPS_LAUNCH_GEMM_F(E, P, F) \
+    do { if (shape == 0) hipLaunchKernelGGL((gemm_h2<E, P, 128, 1, F>), grid, dim3(256), lds, st, g); \
+         else if (shape == 1) hipLaunchKernelGGL((gemm_h2<E, P, 64, 1, F>), grid, dim3(256), lds, st, g); \
+         else hipLaunchKernelGGL((gemm_h2<E, P, 64, 2, F>), grid, dim3(512), lds, st, g); } while (0)
+#define NNPOPS_LAUNCH_GEMM(E, P) do { if (fast) NNPOPS_LAUNCH_GEMM_F(E, P, true); else NNPOPS_LAUNCH_GEMM_F(E, P, false); } while (0)
     if (prologue == 0) {
         if (epilogue == 0) NNPOPS_LAUNCH_GEMM(0, 0); else if (epilogue == 1) NNPOPS_LAUNCH_GEMM(1, 0); else NNPOPS_LAUNCH_GEMM(2, 0);
     } else {
         if (epilogue == 0) NNPOPS_LAUNCH_GEMM(0, 1); else if (epilogue == 1) NNPOPS_LAUNCH_GEMM(1, 1); else NNPOPS_LAUNCH_GEMM(2, 1);
     }
 #undef NNPOPS_LAUNCH_GEMM
+#undef NNPOPS_LAUNCH_GEMM_F
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
