@@ -1447,20 +1447,20 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
             for (int q = 0; q < 4; q++) {
                 const int rr = grp * 4 + q;
                 const int p = 16 * t + rr;
-                if (p < pairs) {
-                    const int i = __float_as_int(ps[64 + rr]), j = __float_as_int(ps[80 + rr]);
-                    float sc = 0.f;
+                // (straight-line loads: a padding row of the last tile carries i = j = 0 and is simply not stored;
+                //  with a branch around them the compiler would drain the load queue where the paths meet)
+                const int i = __float_as_int(ps[64 + rr]), j = __float_as_int(ps[80 + rr]);
+                float sc = 0.f;
 #pragma unroll
-                    for (int cb = 0; cb < NCB; cb++) {
-                        const size_t c = (size_t)cb * 16 + col;
-                        const float xi = x[(size_t)i * W + c], gi = gout[(size_t)i * W + c];
-                        const float xj = x[(size_t)j * W + c], gj = gout[(size_t)j * W + c];
-                        sc += dacc[cb][q] * (xj * gi + xi * gj);                       // ref :286
-                    }
-                    sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
-                    sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
-                    if (col == 0) pair_s[p] = sc * ps[48 + rr];
+                for (int cb = 0; cb < NCB; cb++) {
+                    const size_t c = (size_t)cb * 16 + col;
+                    const float xi = x[(size_t)i * W + c], gi = gout[(size_t)i * W + c];
+                    const float xj = x[(size_t)j * W + c], gj = gout[(size_t)j * W + c];
+                    sc += dacc[cb][q] * (xj * gi + xi * gj);                           // ref :286
                 }
+                sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
+                sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 8, 64);
+                if (col == 0 && p < pairs) pair_s[p] = sc * ps[48 + rr];
                 if (q & 1) __builtin_amdgcn_sched_barrier(0);       // two pairs' gathers in flight at a time
             }
         }
