@@ -200,13 +200,16 @@ int nnpops_split_planes(void* stream, int rows, int cols, const float* w, long l
 /* batch: independent problems `stride*` elements apart (0 = shared operand).
  * epilogue 0: none; 1: C = CELU(C + bias[N], alpha); 2: C *= CELU'(Y) with Y [M][ldy] a saved CELU OUTPUT.
  * prologue 0: A as given; 1: A[m][k] = pv[k] * CELU'(PY[m][k]) (A itself is not read).
- * a_scale: A is multiplied by it before the split (and C divided by it): keep |A| * a_scale below 6e4. */
-/* out[m] = A[m][0..K) . w + bias (the networks' last layer: one output per member, summed over the members). */
-int nnpops_rows_dot(void* stream, int M, int K, const float* A, long lda, const float* w, float bias, float* out);
+ * a_scale: A is multiplied by it before the split (and C divided by it): keep |A| * a_scale below 6e4.
+ * a_rows / c_rows (optional, batch == 1): row m of A is read from row a_rows[m], row m of C is written to row c_rows[m]
+ * -- the atoms of a species need not be gathered into a contiguous block first, nor their gradients scattered back. */
+/* out[m] = A[m][0..K) . w + bias (the networks' last layer: one output per member, summed over the members); with
+ * out_rows the result of row m goes to out[out_rows[m]]. */
+int nnpops_rows_dot(void* stream, int M, int K, const float* A, long lda, const float* w, float bias, float* out, const int* out_rows);
 int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float* A, long lda, long strideA, const void* Bh,
                       const void* Bl, long ldb, long strideB, float* C, long ldc, long strideC, int epilogue, const float* bias,
                       long strideBias, const float* Y, long ldy, long strideY, int prologue, const float* PY, long ldpy,
-                      long stridePY, const float* pv, long stridePv, float alpha, float a_scale);
+                      long stridePY, const float* pv, long stridePv, float alpha, float a_scale, const int* a_rows, const int* c_rows);
 
 #ifdef __cplusplus
 }

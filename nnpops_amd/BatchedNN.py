@@ -169,6 +169,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         self.h3 = int(self.layer4_weights.shape[2])
         self.last_b: List[float] = []
         self.fused_ok = True
+        self.register_buffer('atom_order32', self.atom_order.to(torch.int32), persistent=False)
         for name in ('fwd_hi', 'fwd_lo', 'bwd_hi', 'bwd_lo', 'packed_biases', 'last_w'):
             self.register_buffer(name, torch.empty(0), persistent=False)
         self._refresh_planes()
@@ -210,10 +211,13 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
 
     def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
         species, aev = species_aev
-        if aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32 or self.fwd_hi.dtype != torch.float16 or not self.fused_ok:
+        if (aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32 or self.fwd_hi.dtype != torch.float16
+                or self.atom_order32.dtype != torch.int32 or not self.fused_ok):
             return self._grouped_forward(species_aev)
-        x = aev[0].index_select(0, self.atom_order)                         # [atoms, features], grouped by species
-        per_atom = torch.ops.NNPOpsBatchedNN.GroupedMLP(x, self.group_sizes, self.num_models, self.h1, self.h2, self.h3,
+        # (the op reads the atoms of a species through atom_order32 and writes their gradients back through it: no gather
+        #  into species order, no scatter back)
+        per_atom = torch.ops.NNPOpsBatchedNN.GroupedMLP(aev[0].contiguous(), self.atom_order32, self.group_sizes, self.num_models,
+                                                        self.h1, self.h2, self.h3,
                                                         self.fwd_hi, self.fwd_lo, self.bwd_hi, self.bwd_lo,
                                                         self.packed_biases, self.last_w, self.last_b)
         return SpeciesEnergies(species, per_atom.sum().reshape(1) / self.num_models)

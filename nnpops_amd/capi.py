@@ -55,11 +55,11 @@ SIGNATURES = {
     "nnpops_cfconv_backprop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "nnpops_split_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long]),
-    "nnpops_rows_dot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_float, C.c_void_p]),
+    "nnpops_rows_dot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "nnpops_gemm_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p,
                                     C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long,
                                     C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long,
-                                    C.c_float, C.c_float]),
+                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_workspace_bytes": (C.c_int64, [C.c_int]),
     "nnpops_neighbor_pairs_forward": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -403,18 +403,21 @@ def split_planes(w, transpose=False):
     return hi, lo
 
 
-def gemm_split(a, planes, bias=None, celu_of=None, alpha=0.1, a_scale=1.0, out=None):
+def gemm_split(a, planes, bias=None, celu_of=None, alpha=0.1, a_scale=1.0, out=None, a_rows=None, c_rows=None, rows=None):
     """out[M][N] = a[M][K] @ B, B = the planes of an [N][K] matrix (see split_planes).  ``bias``: add it and apply CELU;
     ``celu_of``: multiply by CELU'(.) of that saved activation instead.  Single problem (the batched / strided form is
     what the torch op uses)."""
     a = _dev_f32(a, "a")
     hi, lo = planes
     m, k = a.shape
+    if rows is not None:
+        m = int(rows)                                            # (with a_rows: the number of mapped rows)
     n = hi.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     epi = 1 if bias is not None else 2 if celu_of is not None else 0
     _check(lib().nnpops_gemm_split(_stream_ptr(a.device), m, n, k, 1, _ptr(a), k, 0, _ptr(hi), _ptr(lo), hi.shape[1], 0, _ptr(out), n, 0,
                                    epi, _ptr(bias) if bias is not None else None, 0, _ptr(celu_of) if celu_of is not None else None, n, 0,
-                                   0, None, 0, 0, None, 0, float(alpha), float(a_scale)))
+                                   0, None, 0, 0, None, 0, float(alpha), float(a_scale),
+                                   _ptr(a_rows) if a_rows is not None else None, _ptr(c_rows) if c_rows is not None else None))
     return out

@@ -52,6 +52,7 @@ struct GemmArgs {
     const float* PY; long ldpy, stridePY;                    // PRO 1: activation whose CELU' scales A ...
     const float* pv; long stridePv;                          // ... and the vector [K] that multiplies it (A itself is unused)
     float alpha, a_scale;
+    const int *a_rows, *c_rows;                             // optional row maps: A row m is a_rows[m], C row m goes to c_rows[m]
 };
 
 // EPI: 0 plain, 1 bias + CELU, 2 times CELU'(Y).   PRO: 0 A as given, 1 A[m][k] = pv[k] * CELU'(PY[m][k])
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256 * KS) void gemm_h2(GemmArgs g) {
     // staging roles: A: thread -> (row = tid / 4, slot = tid % 4): 8 consecutive k;  B: rows tid / 4 and tid / 4 + 64
     const int srow = tid >> 2, sslot = tid & 3;
     const bool a_row_ok = m0 + srow < g.M;
-    const float* a_src = A + (size_t)(m0 + (a_row_ok ? srow : 0)) * lda + sslot * 8;
+    const int a_row = m0 + (a_row_ok ? srow : 0);
+    const float* a_src = A + (size_t)(g.a_rows ? g.a_rows[a_row] : a_row) * lda + sslot * 8;
     const bool b_ok0 = n0 + srow < g.N, b_ok1 = BN == 128 && n0 + srow + 64 < g.N;
     const size_t b_off0 = (size_t)(n0 + (b_ok0 ? srow : 0)) * g.ldb + sslot * 8;
     const size_t b_off1 = (size_t)(n0 + (b_ok1 ? srow + 64 : 0)) * g.ldb + sslot * 8;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_h2(GemmArgs g) {
                 } else if (EPI == 2) {
                     v *= celu_grad_from_output(Y[(size_t)row * g.ldy + col], inv_alpha);
                 }
-                C[(size_t)row * g.ldc + col] = v;
+                C[(size_t)(g.c_rows ? g.c_rows[row] : row) * g.ldc + col] = v;
             }
     }
 }
@@ -276,10 +278,10 @@ __global__ __launch_bounds__(256) void split_planes(int rows, int cols, const fl
     }
 }
 
-// out[m] = A[m][0..K) . w + bias : the last layer of the networks (one output per member, summed over the members).
+// out[out_rows ? out_rows[m] : m] = A[m][0..K) . w + bias : the last layer of the networks (one output per member, summed over the members).
 // One wave per row, float4 loads.
 __global__ __launch_bounds__(256) void rows_dot(int M, int K, const float* __restrict__ A, long lda, const float* __restrict__ w,
-                                                float bias, float* __restrict__ out) {
+                                                float bias, float* __restrict__ out, const int* __restrict__ out_rows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* a = A + (size_t)row * lda;
@@ -294,16 +296,16 @@ __global__ __launch_bounds__(256) void rows_dot(int M, int K, const float* __res
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) out[row] = acc + bias;
+    if (lane == 0) out[out_rows ? out_rows[row] : row] = acc + bias;
 }
 
 }  // namespace
 
 extern "C" {
 
-int nnpops_rows_dot(void* stream, int M, int K, const float* A, long lda, const float* w, float bias, float* out) {
+int nnpops_rows_dot(void* stream, int M, int K, const float* A, long lda, const float* w, float bias, float* out, const int* out_rows) {
     NNPOPS_REQUIRE(M > 0 && K > 0 && A && w && out, "empty problem or NULL device pointer");
-    hipLaunchKernelGGL(rows_dot, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, M, K, A, lda, w, bias, out);
+    hipLaunchKernelGGL(rows_dot, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, M, K, A, lda, w, bias, out, out_rows);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
@@ -323,7 +325,7 @@ int nnpops_split_planes(void* stream, int rows, int cols, const float* w, long l
 int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float* A, long lda, long strideA, const void* Bh,
                       const void* Bl, long ldb, long strideB, float* C, long ldc, long strideC, int epilogue, const float* bias,
                       long strideBias, const float* Y, long ldy, long strideY, int prologue, const float* PY, long ldpy,
-                      long stridePY, const float* pv, long stridePv, float alpha, float a_scale) {
+                      long stridePY, const float* pv, long stridePv, float alpha, float a_scale, const int* a_rows, const int* c_rows) {
     NNPOPS_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "empty GEMM");
     NNPOPS_REQUIRE(Bh && Bl && C, "NULL device pointer");
     NNPOPS_REQUIRE(ldb % 8 == 0 && ldb >= ((K + 31) & ~31), "planes need ldb >= K rounded up to 32 (zero padded)");
@@ -332,8 +334,9 @@ int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float*
     NNPOPS_REQUIRE(epilogue != 1 || bias, "bias + CELU epilogue needs a bias");
     NNPOPS_REQUIRE(epilogue != 2 || Y, "CELU' epilogue needs the saved activation");
     NNPOPS_REQUIRE(alpha > 0 && a_scale > 0, "alpha and a_scale must be positive");
+    NNPOPS_REQUIRE((!a_rows && !c_rows) || batch == 1, "row maps are for single problems");
     GemmArgs g{M, N, K, A, lda, strideA, (const _Float16*)Bh, (const _Float16*)Bl, ldb, strideB, C, ldc, strideC, bias, strideBias,
-               Y, ldy, strideY, PY, ldpy, stridePY, pv, stridePv, alpha, a_scale};
+               Y, ldy, strideY, PY, ldpy, stridePY, pv, stridePv, alpha, a_scale, a_rows, c_rows};
     // 64 x 128 tiles, four waves, when they still give every CU a few workgroups; otherwise 64 x 64 tiles with eight waves
     // splitting every K step (the layers of one species of a 2 000-atom frame are 10-300 tiles: one wave per SIMD hides
     // nothing)

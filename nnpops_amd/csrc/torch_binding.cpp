@@ -663,8 +663,9 @@ Tensor BatchedLinear(const Tensor& vectors, const Tensor& weights, const Tensor&
 // (nnpops_gemm_split, batched_nn.hip).  Same function as BatchedNN.py:100-122 of the reference -- Linear, CELU(0.1),
 // Linear, CELU, Linear, CELU, Linear per atom and ensemble member -- with bias + CELU fused into the GEMM epilogues
 // and CELU' into the epilogues / prologue of the input-gradient pass: six GEMM launches per species and step, no
-// elementwise kernels in between.  Returns the per-atom energies summed over the ensemble members.
-//   x          [atoms, F] fp32, atoms sorted by kind        group_sizes  atoms per kind
+// elementwise kernels in between.  Returns the per-atom energies (atoms' own order) summed over the ensemble members.
+//   x          [atoms, F] fp32, atoms in their own order; order [atoms] int32: atoms grouped by kind (the layer-0 GEMM
+//              reads its rows through it, the last backward GEMM writes through it)      group_sizes  atoms per kind
 //   fwd_*      planes of the weights, per kind: [M*H1][Fp] | [M*H2][H1p] | [M*H3][H2p]   (p: rounded up to 32)
 //   bwd_*      planes of their transposes, per kind: [F][(M*H1)p] | M x [H1][H2p] | M x [H2][H3p]
 //   biases     per kind: [M*H1] | [M*H2] | [M*H3]           last_w per kind [M*H3], last_b per kind (summed over members)
@@ -685,11 +686,13 @@ void gemm_checked(int rc) { TORCH_CHECK(rc == NNPOPS_OK, nnpops_last_error()); }
 
 class GroupedMLPFunction : public torch::autograd::Function<GroupedMLPFunction> {
 public:
-    static Tensor forward(AutogradContext* ctx, const Tensor& x, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1,
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& order, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1,
                           int64_t h2, int64_t h3, const Tensor& fwd_hi, const Tensor& fwd_lo, const Tensor& bwd_hi,
                           const Tensor& bwd_lo, const Tensor& biases, const Tensor& last_w, std::vector<double> last_b_host) {
         require_device_tensor(x, "x");
         TORCH_CHECK(x.dim() == 2 && x.scalar_type() == torch::kFloat32 && x.is_contiguous(), "x must be a contiguous [atoms, features] float32 tensor");
+        TORCH_CHECK(order.dim() == 1 && order.size(0) == x.size(0) && order.scalar_type() == torch::kInt32 && order.is_contiguous() && order.device() == x.device(),
+                    "order must be an int32 permutation of the atoms on the same device");
         const MlpLayout L{x.size(1), num_models, h1, h2, h3};
         const int64_t kinds = (int64_t)group_sizes.size(), atoms = x.size(0);
         TORCH_CHECK(fwd_hi.numel() == kinds * L.fwd_kind() && bwd_hi.numel() == kinds * L.bwd_kind() &&
@@ -711,26 +714,26 @@ public:
                 const at::Half *h1p = h0 + L.M * L.H1 * up32(L.F), *l1p = l0 + L.M * L.H1 * up32(L.F);
                 const at::Half *h2p = h1p + L.M * L.H2 * up32(L.H1), *l2p = l1p + L.M * L.H2 * up32(L.H1);
                 const float* b0 = bs + k * L.bias_kind(); const float* b1 = b0 + L.M * L.H1; const float* b2 = b1 + L.M * L.H2;
-                const float* xs = x.data_ptr<float>() + first * L.F;
+                const int* rows = order.data_ptr<int>() + first;
                 float* p1 = y1.data_ptr<float>() + first * L.M * L.H1;
                 float* p2 = y2.data_ptr<float>() + first * L.M * L.H2;
                 float* p3 = y3.data_ptr<float>() + first * L.M * L.H3;
                 // layer 0: every member reads the same AEVs -> one GEMM, N = members * H1
-                gemm_checked(nnpops_gemm_split(stream, n, L.M * L.H1, L.F, 1, xs, L.F, 0, h0, l0, up32(L.F), 0, p1, L.M * L.H1, 0, 1, b0, 0,
-                                               nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                gemm_checked(nnpops_gemm_split(stream, n, L.M * L.H1, L.F, 1, x.data_ptr<float>(), L.F, 0, h0, l0, up32(L.F), 0, p1, L.M * L.H1, 0, 1, b0, 0,
+                                               nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale, rows, nullptr));
                 // layers 2 and 4: one problem per member
                 gemm_checked(nnpops_gemm_split(stream, n, L.H2, L.H1, L.M, p1, L.M * L.H1, L.H1, h1p, l1p, up32(L.H1), L.H2 * up32(L.H1), p2,
-                                               L.M * L.H2, L.H2, 1, b1, L.H2, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                                               L.M * L.H2, L.H2, 1, b1, L.H2, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale, nullptr, nullptr));
                 gemm_checked(nnpops_gemm_split(stream, n, L.H3, L.H2, L.M, p2, L.M * L.H2, L.H2, h2p, l2p, up32(L.H2), L.H3 * up32(L.H2), p3,
-                                               L.M * L.H3, L.H3, 1, b2, L.H3, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                                               L.M * L.H3, L.H3, 1, b2, L.H3, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale, nullptr, nullptr));
                 // layer 6: one output per member, summed over the members
                 gemm_checked(nnpops_rows_dot(stream, n, L.M * L.H3, p3, L.M * L.H3, last_w.data_ptr<float>() + k * L.M * L.H3, last_b_host[k],
-                                             energies.data_ptr<float>() + first));
+                                             energies.data_ptr<float>(), rows));
             }
             first += n;
         }
         TORCH_CHECK(first == atoms, "GroupedMLP: group sizes do not add up to the number of atoms");
-        ctx->save_for_backward({y1, y2, y3, bwd_hi, bwd_lo, last_w});
+        ctx->save_for_backward({y1, y2, y3, bwd_hi, bwd_lo, last_w, order});
         ctx->saved_data["group_sizes"] = group_sizes;
         ctx->saved_data["dims"] = std::vector<int64_t>{L.F, L.M, L.H1, L.H2, L.H3};
         return energies;
@@ -738,7 +741,7 @@ public:
 
     static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
         const auto saved = ctx->get_saved_variables();
-        const Tensor &y1 = saved[0], &y2 = saved[1], &y3 = saved[2], &bwd_hi = saved[3], &bwd_lo = saved[4], &last_w = saved[5];
+        const Tensor &y1 = saved[0], &y2 = saved[1], &y3 = saved[2], &bwd_hi = saved[3], &bwd_lo = saved[4], &last_w = saved[5], &order = saved[6];
         const std::vector<int64_t> group_sizes = ctx->saved_data["group_sizes"].toIntVector();
         const std::vector<int64_t> d = ctx->saved_data["dims"].toIntVector();
         const MlpLayout L{d[0], d[1], d[2], d[3], d[4]};
@@ -763,30 +766,30 @@ public:
                 const float* w6 = last_w.data_ptr<float>() + k * L.M * L.H3;
                 // dE/dy3 = w6 * CELU'(y3) is formed while it is staged (prologue); times W4, times CELU'(y2)
                 gemm_checked(nnpops_gemm_split(stream, n, L.H2, L.H3, L.M, nullptr, 0, 0, t2h, t2l, up32(L.H3), L.H2 * up32(L.H3), q2, L.M * L.H2,
-                                               L.H2, 2, nullptr, 0, p2, L.M * L.H2, L.H2, 1, p3, L.M * L.H3, L.H3, w6, L.H3, kCeluAlpha, kOperandScale));
+                                               L.H2, 2, nullptr, 0, p2, L.M * L.H2, L.H2, 1, p3, L.M * L.H3, L.H3, w6, L.H3, kCeluAlpha, kOperandScale, nullptr, nullptr));
                 gemm_checked(nnpops_gemm_split(stream, n, L.H1, L.H2, L.M, q2, L.M * L.H2, L.H2, t1h, t1l, up32(L.H2), L.H1 * up32(L.H2), q1, L.M * L.H1,
-                                               L.H1, 2, nullptr, 0, p1, L.M * L.H1, L.H1, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale));
+                                               L.H1, 2, nullptr, 0, p1, L.M * L.H1, L.H1, 0, nullptr, 0, 0, nullptr, 0, kCeluAlpha, kOperandScale, nullptr, nullptr));
                 // all members' first layers at once: K = members * H1
                 gemm_checked(nnpops_gemm_split(stream, n, L.F, L.M * L.H1, 1, q1, L.M * L.H1, 0, t0h, t0l, up32(L.M * L.H1), 0,
-                                               dx.data_ptr<float>() + first * L.F, L.F, 0, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0,
-                                               kCeluAlpha, kOperandScale));
+                                               dx.data_ptr<float>(), L.F, 0, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0,
+                                               kCeluAlpha, kOperandScale, nullptr, order.data_ptr<int>() + first));
             }
             first += n;
         }
-        Tensor gx = dx * grads[0].unsqueeze(1);             // upstream gradient of every atom's energy
-        return {gx, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        Tensor gx = dx * grads[0].unsqueeze(1);             // upstream gradient of every atom's energy (atoms' own order)
+        return {gx, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
-Tensor GroupedMLP(const Tensor& x, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1, int64_t h2, int64_t h3,
+Tensor GroupedMLP(const Tensor& x, const Tensor& order, std::vector<int64_t> group_sizes, int64_t num_models, int64_t h1, int64_t h2, int64_t h3,
                   const Tensor& fwd_hi, const Tensor& fwd_lo, const Tensor& bwd_hi, const Tensor& bwd_lo, const Tensor& biases,
                   const Tensor& last_w, std::vector<double> last_b) {
-    return GroupedMLPFunction::apply(x, group_sizes, num_models, h1, h2, h3, fwd_hi, fwd_lo, bwd_hi, bwd_lo, biases, last_w, last_b);
+    return GroupedMLPFunction::apply(x, order, group_sizes, num_models, h1, h2, h3, fwd_hi, fwd_lo, bwd_hi, bwd_lo, biases, last_w, last_b);
 }
 
 TORCH_LIBRARY(NNPOpsBatchedNN, m) {
     m.def("BatchedLinear", BatchedLinear);
-    m.def("GroupedMLP(Tensor x, int[] group_sizes, int num_models, int h1, int h2, int h3, Tensor fwd_hi, Tensor fwd_lo, "
+    m.def("GroupedMLP(Tensor x, Tensor order, int[] group_sizes, int num_models, int h1, int h2, int h3, Tensor fwd_hi, Tensor fwd_lo, "
           "Tensor bwd_hi, Tensor bwd_lo, Tensor biases, Tensor last_w, float[] last_b) -> Tensor", GroupedMLP);
 }
 

@@ -129,3 +129,18 @@ def test_networks_with_huge_weights_keep_the_library_gemms():
     sp = torch.tensor(species, device=DEV).unsqueeze(0)
     aev = torch.rand(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
     torch.testing.assert_close(fused((sp, aev)).energies, grouped((sp, aev)).energies, rtol=1e-6, atol=1e-6)
+
+
+def test_gemm_row_maps():
+    """a_rows / c_rows: the GEMM reads row m of A from a_rows[m] and writes row m of C to c_rows[m] (the atoms of a species
+    are used where they lie)."""
+    from nnpops_amd import capi
+    a, w = _rand((500, 256), 1.0, 11), _rand((96, 256), 1.0 / 16, 12)
+    pick = torch.randperm(500, generator=torch.Generator().manual_seed(13))[:321].to(torch.int32).to(DEV)
+    planes = capi.split_planes(w)
+    out = capi.gemm_split(a, planes, a_rows=pick, rows=321)
+    ref = a[pick.long()].double() @ w.double().t()
+    assert (out.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    scattered = torch.zeros((500, 96), device=DEV)
+    capi.gemm_split(a[pick.long()].contiguous(), planes, out=scattered, c_rows=pick)
+    assert (scattered[pick.long()].double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
