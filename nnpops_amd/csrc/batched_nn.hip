@@ -342,7 +342,7 @@ int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float*
     // nothing)
     const long tiles128 = (long)((N + 127) / 128) * ((M + BM - 1) / BM) * batch;
     const long tiles64 = (long)((N + 63) / 64) * ((M + BM - 1) / BM) * batch;
-    const int shape = tiles128 >= 512 ? 0 : tiles64 >= 600 ? 1 : 2;       // 0: 64x128 | 1: 64x64 | 2: 64x64, eight waves splitting K      // 0: 64x128 | 1: 64x64 | 2: 64x64, eight waves splitting K
+    const int shape = tiles128 >= 512 ? 0 : tiles64 >= 600 ? 1 : 2;       // 0: 64x128 | 1: 64x64 | 2: 64x64, eight waves splitting K
     const int bn = shape == 0 ? 128 : 64;
     const dim3 grid((N + bn - 1) / bn, (M + BM - 1) / BM, batch);
     const size_t lds = (shape == 2 ? 2 : 1) * 2 * stage_bytes(bn);
