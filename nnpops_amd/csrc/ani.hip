@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ani_kernels.h"
+#include "ani_angular_mfma.h"
 #include "host_common.h"
 
 using namespace nnpops;
@@ -33,6 +34,12 @@ struct nnpops_ani {
     int* d_tri = nullptr;           // [N][cap_angular*(cap_angular-1)/2] bucket-major triple words
     int* d_bucket_offsets = nullptr; // [N][NB + 1] first triple of every bucket (chunked forward view)
     bool chunked_forward = true;
+    int forward_kernel = 2;         // 2: matrix-core scatter (ani_angular_mfma.h), 1: chunked view, 0: run merging
+    bool mfma_ok = false;           // at most 32 species pairs can occur in this system
+    bool fwd_identity = false;      // angular function m sits at canonical slot m: 16-byte stores of the row
+    int fwd_chunk = 128;            // triples staged in LDS per chunk of the matrix-core forward kernel
+    int fwd_waves_per_atom = 2;     // 2: a 128-lane workgroup per atom (half the LDS per wave), 1: a wave per atom
+    int fwd_atoms_per_group = 1;    // > 1: every wave / workgroup walks that many atoms (amortises its prologue)
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
     int* d_status = nullptr;        // [kStatWords]
@@ -144,6 +151,7 @@ int factor_angular(AniParams& hp, const float* af, int nA) {
         hp.fz_zeta[z] = fz[z].first;
         hp.fz_cos[z] = (float)std::cos((double)fz[z].second);
         hp.fz_sin[z] = (float)std::sin((double)fz[z].second);
+        hp.fz_bias[z] = 1.0f - fz[z].first;
     }
     return NNPOPS_OK;
 }
@@ -172,7 +180,29 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
     const int wpg = waves_per_group(lds_wave);
     const size_t lds_group = (size_t)lds_wave * wpg;
     const dim3 grid(div_up(N, wpg)), block(64 * wpg);
-    if (forward) {
+    if (forward && h->forward_kernel == 2) {
+        const int CH = h->fwd_chunk;
+        const size_t lds2 = ang_fwd_mfma_lds_bytes<NFRP, NFZP>(h->cap_angular, CH);
+        const int lw = (int)((lds2 + 15) & ~(size_t)15);
+        const int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)out & 15) == 0;
+        if (h->fwd_waves_per_atom == 2) {                      // a 128-lane workgroup per atom
+            int groups = N;
+            if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
+            auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 2>;
+            if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
+            hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, h->stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw);
+        } else {
+            const int wpg2 = waves_per_group(lw);
+            const size_t lg = (size_t)lw * wpg2;
+            int groups = div_up(N, wpg2);
+            if (h->fwd_atoms_per_group > 1) groups = div_up(groups, h->fwd_atoms_per_group);
+            auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 1>;
+            if (lg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
+            hipLaunchKernelGGL(k, dim3(groups), dim3(64 * wpg2), lg, h->stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw);
+        }
+    } else if (forward) {
         auto k = h->chunked_forward ? ani_angular_forward_chunked<TA, NFRP, NFZP> : ani_angular_forward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB,
@@ -254,6 +284,38 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     h->nfrp = pad_pow2(hp.nFR, 4);
     h->nfzp = pad_pow2(hp.nFZ, 4);
     if (h->nfzp > 8) { delete h; return fail(NNPOPS_ERR_UNSUPPORTED, "more than 8 (zeta,thetas) factors (%d) not built", hp.nFZ); }
+    // Matrix-core forward kernel: quads are handed the species pairs that can occur among this system's atoms.
+    {
+        std::vector<char> present(num_species, 0);
+        for (int i = 0; i < num_atoms; i++) present[atom_species[i]] = 1;
+        std::vector<int> live;
+        hp.fwd_nabsent = 0;
+        for (int bk = 0; bk < hp.NB; bk++) {
+            if (present[hp.bkt_a[bk]] && present[hp.bkt_b[bk]]) live.push_back(bk);
+            else hp.fwd_absent[hp.fwd_nabsent++] = bk;
+        }
+        for (int q = 0; q < kFwdSlots; q++) hp.fwd_slot_bucket[q] = -1;
+        hp.fwd_split = 1;
+        h->mfma_ok = !live.empty() && (int)live.size() <= kFwdSlots;
+        if (h->mfma_ok) {
+            while (hp.fwd_split < 8 && (int)live.size() * hp.fwd_split * 2 <= kFwdSlots) hp.fwd_split *= 2;
+            for (size_t b = 0; b < live.size(); b++)
+                for (int p = 0; p < hp.fwd_split; p++) hp.fwd_slot_bucket[b * hp.fwd_split + p] = live[b];
+        }
+        for (int c = 0; c < kMaxAngularFns; c++) hp.m_of_c[c] = -1;
+        h->fwd_identity = num_angular == h->nfrp * h->nfzp;
+        for (int m = 0; m < num_angular; m++) {
+            hp.m_of_c[hp.c_of_m[m]] = m;
+            if (hp.c_of_m[m] != m) h->fwd_identity = false;
+        }
+        hp.fwd_zero_shift = 0;
+        while ((4 << hp.fwd_zero_shift) < num_angular && hp.fwd_zero_shift < 6) hp.fwd_zero_shift++;
+        h->fwd_identity = h->fwd_identity && num_angular <= 256;
+        h->forward_kernel = h->mfma_ok ? 2 : -1;
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_WPA")) h->fwd_waves_per_atom = std::atoi(e) == 1 ? 1 : 2;
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_APG")) h->fwd_atoms_per_group = std::max(1, std::atoi(e));
+    }
     h->device = device;
     if (const char* e = std::getenv("NNPOPS_ANI_DEBUG")) h->debug = std::atoi(e);
     h->cap = 128;
@@ -306,7 +368,12 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         // measured: water 0.93 and H/C/N/O 0.79 favour the chunked view, seven equally likely species 0.57 do not
         h->chunked_forward = hp.NB < 64 && useful >= 0.70 * padded;     // (the chunked view scans the buckets with one wave)
     }
-    if (const char* e = std::getenv("NNPOPS_ANI_FORWARD")) h->chunked_forward = hp.NB < 64 && std::atoi(e) != 0;   // tests / A-B: 0, 1
+    if (h->forward_kernel < 0) h->forward_kernel = h->chunked_forward ? 1 : 0;
+    if (const char* e = std::getenv("NNPOPS_ANI_FORWARD")) {          // tests / A-B: 0 run merging, 1 chunked view, 2 matrix cores
+        const int want = std::atoi(e);
+        if (want == 2 && h->mfma_ok) h->forward_kernel = 2;
+        else if (want != 2) { h->chunked_forward = hp.NB < 64 && want != 0; h->forward_kernel = h->chunked_forward ? 1 : 0; }
+    }
     if (hipMemcpy(h->d_params, &hp, sizeof(AniParams), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess ||

@@ -1,0 +1,282 @@
+// ani_angular_mfma.h -- angular AEV forward with the species-pair scatter done by the matrix cores.
+//
+// What is computed: reference src/ani/CpuANISymmetryFunctions.cpp:153-194 (angular[i][bucket][m] summed over the
+// neighbour pairs of atom i), with the function set factored as R_a(rbar) x Z_z(theta) (ani_kernels.h).
+//
+// Why a third forward kernel.  The arithmetic of a triple is 12 transcendentals and a 8 x 4 outer product; what made
+// the first two kernels slow was not that but the bookkeeping of adding the outer products of ~150 triples into 28
+// species-pair blocks of the output row with 64 lanes (run detection, segmented scans, LDS read-modify-writes:
+// ~270 vector instructions per batch of 64 triples against 32 FMAs of real work).  Here that scatter is the operand
+// shape of one instruction:
+//
+//     v_mfma_f32_4x4x1_16b_f32     16 INDEPENDENT 4x4 outer products per issue, D_b[i][j] += A_b[i] * B_b[j]
+//                                  (A: lane 4b+i, B: lane 4b+j, D: register i of lane 4b+j; exact fp32, vector rate)
+//
+// A quad of lanes (one of the 16 blocks) owns ONE species-pair bucket for the whole atom and walks that bucket's
+// triples -- contiguous in the builder's bucket-major list -- one per step: A = Z_z(t), B = R_a(t) (two issues for
+// a = 0..3 and 4..7).  The accumulators ARE the output block: no LDS row, no zero fill, no run logic, no shuffles,
+// and the row leaves the registers as 16-byte stores.  Two sets of 16 quads cover up to 32 buckets; when fewer
+// species pairs can occur in the system (water: 3) every bucket is split over K = 2, 4 or 8 quads (triples dealt
+// round-robin, partial blocks added with K-1 xor-shuffles at the end), so the number of steps is
+// max_b ceil(n_b / K) whatever the composition.
+//
+// Per atom: phase 1 (lane = triple, 64 per batch, CH triples staged per chunk) writes the 12 factors of every
+// triple to LDS as one 48-byte record; phase 2 (lane = (quad, column)) reads one 8-byte and one 4-byte piece per
+// step and issues two MFMAs.  Quads whose bucket is exhausted read an all-zero record.
+#pragma once
+
+#include "ani_kernels.h"
+
+namespace nnpops {
+
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFwdSlots = 32;          // 2 sets x 16 quads
+
+template <int NFRP, int NFZP>
+__host__ __device__ inline size_t ang_fwd_mfma_lds_bytes(int capA, int CH) {
+    return (size_t)capA * 2 * sizeof(float4) + (size_t)(CH + 1) * (NFRP + NFZP) * sizeof(float);
+}
+
+template <int W>
+__device__ __forceinline__ void lds_read_vec(const float* p, float (&v)[W]) {
+    if constexpr (W == 1) {
+        v[0] = p[0];
+    } else if constexpr (W == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+        static_assert(W == 4, "operand width");
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+}
+
+__device__ __forceinline__ const float* lds_ptr(int byte_address) {
+    return (const float*)(__attribute__((address_space(3))) const float*)(uintptr_t)(unsigned)byte_address;
+}
+
+// WPA = waves per atom.  1: a wave owns an atom (both quad sets).  2: a 128-lane workgroup owns an atom -- the two
+// waves stage alternate batches of phase 1 into ONE shared staging area, meet at a barrier, and each runs the step loop of
+// one quad set: same instructions in total, half the LDS per wave (twice the waves per CU) and half the latency per atom.
+template <bool TORCHANI, int NFRP, int NFZP, int WPA>
+__global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, WPA == 2 ? 6 : 5) void ani_angular_forward_mfma(
+    const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
+    const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
+    const int* __restrict__ cnt_ro, float* __restrict__ angular, int ld_angular, int vec_ok, int lds_per_atom) {
+    constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
+    constexpr int NS = 2 / WPA;                                // quad sets run by this wave
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = lane_id();
+    const int N = P->N, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
+    const int K = P->fwd_split, logK = 31 - __builtin_clz(K);
+
+    const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());        // wave-uniform: keeps per-atom addressing scalar
+    const int role = WPA == 2 ? wig : 0;                        // which half of the work of the atom
+    const int slot_in_group = WPA == 2 ? 0 : wig;               // which atom of the workgroup
+    auto sync = [&]() {
+        if constexpr (WPA == 2) __syncthreads();
+        else wave_fence();
+    };
+    char* cursor = lds_raw + (size_t)slot_in_group * lds_per_atom;
+    float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float* fac = (float*)cursor;          // [CH + 1][REC]; the last record stays zero
+    // (LDS addresses of phase 2 are kept as 32-bit byte offsets: one register per quad stream)
+    const int fac_addr = (int)(uintptr_t)fac + (lane & 3) * (NR4 * 4);             // this lane's R pieces in record 0
+    const int zdelta = NFRP * 4 + (lane & 3) * (NZ4 * 4) - (lane & 3) * (NR4 * 4);   // from the R pieces to the Z pieces
+    const int zero_addr = fac_addr + CH * (REC * 4);
+
+    // per-lane view of phase 2: quad = block of the MFMA, nn = column inside the block
+    const int quad = lane >> 2, nn = lane & 3;
+    int sbk[NS], spart[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        sbk[s] = P->fwd_slot_bucket[(role * NS + s) * 16 + quad];          // -1: unused slot
+        spart[s] = ((role * NS + s) * 16 + quad) & (K - 1);
+    }
+    // constants of the two factor families (wave-uniform: scalar registers)
+    float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];
+#pragma unroll
+    for (int a = 0; a < NFRP; a++) { frc[a] = a < nFR ? P->fr_c[a] : 0.f; frs[a] = a < nFR ? P->fr_rs[a] : 0.f; }
+#pragma unroll
+    for (int z = 0; z < NFZP; z++) {
+        zz[z] = z < nFZ ? P->fz_zeta[z] : 1.f;
+        zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
+        zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
+        zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;                 // 1 - zeta: the 2^(1-zeta) of ref :104-109 folded into the exponent
+    }
+    if (role == 0 && lane < REC) fac[CH * REC + lane] = 0.f;
+
+    const int natoms_group = WPA == 2 ? 1 : (blockDim.x >> 6);
+    const int stride_atoms = gridDim.x * natoms_group;
+    for (int i = blockIdx.x * natoms_group + slot_in_group; i < N; i += stride_atoms) {
+        int n, nro;
+        clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+        const int T = (n * (n - 1)) / 2;
+        const int* tri = tri_g + (size_t)i * triples_capacity(capA);
+        int word = role * 64 + lane < T ? tri[role * 64 + lane] : 0;        // my first batch of triple words, in flight early
+        const int* boff_g = P->bucket_offsets + (size_t)i * (NB + 1);
+        int sstart[NS], send[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int b = max(sbk[s], 0);
+            const int lo = boff_g[b], hi = boff_g[b + 1];
+            sstart[s] = (sbk[s] >= 0 && T > 0) ? lo : 0;
+            send[s] = (sbk[s] >= 0 && T > 0) ? hi : 0;
+        }
+        if constexpr (WPA == 2) {                               // one array each
+            const float4* src = (role == 0 ? recA_g : recB_g) + (size_t)i * capA;
+            float4* dst = role == 0 ? recA : recB;
+            for (int e = lane; e < n; e += 64) dst[e] = src[e];
+        } else {
+            load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
+        }
+
+        mfma_f4 acc[NS][NZ4][NR4];
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int zh = 0; zh < NZ4; zh++)
+#pragma unroll
+                for (int rh = 0; rh < NR4; rh++) acc[s][zh][rh] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+        sync();
+
+        for (int c0 = 0; c0 < T; c0 += CH) {
+            const int c1 = min(c0 + CH, T);
+            // ---------------- phase 1: lane = triple, records of the chunk to LDS ----------------
+            const int first_sub = c0 + role * 64;
+            if (c0 > 0 && (CH & (64 * WPA - 1)) != 0) word = first_sub + lane < T ? tri[first_sub + lane] : 0;   // (ragged chunks)
+            for (int sub = first_sub; sub < c1; sub += 64 * WPA) {
+                const int t = sub + lane;
+                const int next_word = (t + 64 * WPA < T) ? tri[t + 64 * WPA] : 0;
+                if (t < c1) {
+                    const int p = word & 0xff, q = (word >> 8) & 0xff;
+                    const float4 A = recA[p], B = recA[q];
+                    const float4 A2 = recB[p], B2 = recB[q];
+                    const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
+                    float vr[NFRP], vz[NFZP];
+#pragma unroll
+                    for (int a = 0; a < NFRP; a++) {           // stored so that column nn finds its NR4 values together
+                        const float sh = g.rbar - frs[a];
+                        vr[(a & 3) * NR4 + (a >> 2)] = fast_exp2(frc[a] * sh * sh);
+                    }
+#pragma unroll
+                    for (int z = 0; z < NFZP; z++) {
+                        const float x = fmaxf(1.0f + (g.c * zc[z] + g.s * zs[z]), 1e-30f);   // 1 + cos(theta - ths)
+                        vz[(z & 3) * NZ4 + (z >> 2)] = g.fcfc * fast_exp2(fmaf(zz[z], fast_log2(x), zb[z]));
+                    }
+                    float* dst = fac + (t - c0) * REC;
+#pragma unroll
+                    for (int a = 0; a < NFRP; a += 4)
+                        *reinterpret_cast<float4*>(dst + a) = make_float4(vr[a], vr[a + 1], vr[a + 2], vr[a + 3]);
+#pragma unroll
+                    for (int z = 0; z < NFZP; z += 4)
+                        *reinterpret_cast<float4*>(dst + NFRP + z) = make_float4(vz[z], vz[z + 1], vz[z + 2], vz[z + 3]);
+                }
+                word = next_word;
+            }
+            sync();
+            // ---------------- phase 2: lane = (quad, column); one triple per quad per step ----------------
+            // LDS byte addresses: `ra` of this lane's R pieces in the record of the quad's next triple, Z pieces at ra + zdelta
+            int cnt[NS], ra[NS];
+            int cmax = 0;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const int lo = max(sstart[s], c0), hi = min(send[s], c1);
+                const int first = lo + ((spart[s] - (lo - sstart[s])) & (K - 1));     // triples of a bucket are dealt round-robin
+                cnt[s] = max(0, (hi - first + K - 1) >> logK);
+                ra[s] = fac_addr + (first - c0) * (REC * 4);
+                cmax = max(cmax, cnt[s]);
+            }
+            const int steps = wave_max_nonneg(cmax);             // wave-uniform trip count
+            const int stride = K * REC * 4;
+            float ar[NS][NR4], az[NS][NZ4], br[NS][NR4], bz[NS][NZ4];      // operand registers, ping-pong
+            auto fetch = [&](int k, float (&r)[NS][NR4], float (&z)[NS][NZ4]) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const int at = k < cnt[s] ? ra[s] : zero_addr;     // an exhausted quad multiplies zeros
+                    ra[s] += stride;
+                    lds_read_vec<NR4>(lds_ptr(at), r[s]);
+                    lds_read_vec<NZ4>(lds_ptr(at + zdelta), z[s]);
+                }
+            };
+            auto issue = [&](const float (&r)[NS][NR4], const float (&z)[NS][NZ4]) {
+#pragma unroll
+                for (int s = 0; s < NS; s++)
+#pragma unroll
+                    for (int zh = 0; zh < NZ4; zh++)
+#pragma unroll
+                        for (int rh = 0; rh < NR4; rh++)
+                            acc[s][zh][rh] = __builtin_amdgcn_mfma_f32_4x4x1f32(z[s][zh], r[s][rh], acc[s][zh][rh], 0, 0, 0);
+            };
+            fetch(0, ar, az);
+            int k = 0;
+            for (; k + 1 < steps; k += 2) {                    // operands of the next step in flight during the MFMAs
+                fetch(k + 1, br, bz);
+                issue(ar, az);
+                fetch(k + 2, ar, az);
+                issue(br, bz);
+            }
+            if (k < steps) issue(ar, az);
+            if (c1 < T) sync();                                // (the staging area is about to be overwritten)
+        }
+
+        // the K quads of a bucket hold partial blocks: add them up (all end with the total)
+        for (int off = 4; off < 4 * K; off <<= 1) {
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+#pragma unroll
+                for (int zh = 0; zh < NZ4; zh++)
+#pragma unroll
+                    for (int rh = 0; rh < NR4; rh++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[s][zh][rh][r] += __shfl_xor(acc[s][zh][rh][r], off, 64);
+        }
+
+        // ---------------- epilogue: registers -> the atom's output row ----------------
+        // register r of lane (quad, nn) of block (zh, rh) is canonical slot (a = nn + 4 rh, z = r + 4 zh) of the quad's bucket
+        float* out = angular + (size_t)i * ld_angular;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (sbk[s] < 0 || spart[s] != 0) continue;
+            float* ob = out + sbk[s] * nA;
+#pragma unroll
+            for (int zh = 0; zh < NZ4; zh++)
+#pragma unroll
+                for (int rh = 0; rh < NR4; rh++) {
+                    const int c = (nn + 4 * rh) * NFZP + 4 * zh;
+                    const mfma_f4 v = acc[s][zh][rh];
+                    if (vec_ok) {                              // function m sits at canonical slot m: one 16-byte store
+                        *reinterpret_cast<float4*>(ob + c) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int m = P->m_of_c[c + r];
+                            if (m >= 0) ob[m] = v[r];
+                        }
+                    }
+                }
+        }
+        // species pairs that cannot occur in this system have no quad: their blocks are zero
+        const int nabs = P->fwd_nabsent;
+        if (nabs > 0 && role == 0) {
+            if (vec_ok) {                                      // 2^fwd_zero_shift lanes per block, one 16-byte piece each
+                const int sh = P->fwd_zero_shift, piece = lane & ((1 << sh) - 1), per_pass = 64 >> sh;
+                for (int a0 = 0; a0 < nabs; a0 += per_pass) {
+                    const int a = a0 + (lane >> sh);
+                    if (a < nabs && piece * 4 < nA)
+                        *reinterpret_cast<float4*>(out + P->fwd_absent[a] * nA + piece * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                for (int a = 0; a < nabs; a++) {
+                    float* ob = out + P->fwd_absent[a] * nA;
+                    for (int m = lane; m < nA; m += 64) ob[m] = 0.f;
+                }
+            }
+        }
+        sync();                                                // records and staging area are free for the next atom
+    }
+}
+
+}  // namespace nnpops

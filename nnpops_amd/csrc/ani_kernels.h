@@ -63,11 +63,19 @@ struct AniParams {
     float fz_zeta[kMaxFactor];
     float fz_cos[kMaxFactor];        // cos(thetas_z)
     float fz_sin[kMaxFactor];        // sin(thetas_z)
+    float fz_bias[kMaxFactor];       // 1 - zeta_z
     float scale_m[kMaxAngularFns];   // 2^(1-zeta_m) of angular function m                       ref :104-109
     int c_of_m[kMaxAngularFns];      // function m -> slot a*NFZP+z inside a padded canonical bucket block
     int bkt_a[kMaxBuckets];          // bucket b -> its species pair (A <= B), upper-triangular row-major
     int bkt_b[kMaxBuckets];          //                                                          ref :39-43
     int* bucket_offsets;             // [N][NB + 1] device array the builders fill: offsets of the buckets in an atom's triple list
+    // matrix-core forward kernel (ani_angular_mfma.h)
+    int m_of_c[kMaxAngularFns];      // canonical slot a*NFZP+z -> function m, -1 for padding slots
+    int fwd_split;                   // K: every species pair that can occur is shared by K quads (1, 2, 4 or 8)
+    int fwd_slot_bucket[32];         // quad slot (set * 16 + quad) -> bucket, -1 unused; slots of a bucket are consecutive
+    int fwd_nabsent;                 // species pairs that cannot occur in this system (their output blocks are zero)
+    int fwd_absent[kMaxBuckets];
+    int fwd_zero_shift;              // log2 of the lanes that zero one absent block (16 bytes each), <= 6
 };
 
 // status words reported by nnpops_ani_check

@@ -94,6 +94,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Largest value of a NON-NEGATIVE int over the wave, as a wave-uniform (scalar) value: a DPP scan inside each row
+// of 16 lanes, two row broadcasts, the result read from lane 63 (no LDS traffic, 13 instructions).
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));     // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));     // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));     // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));     // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));     // row_bcast:15 -> rows 1, 3
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));     // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Fast single-instruction transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32 /
 // v_rsq_f32, ~1 ulp).  Used only in the per-triple / per-pair inner loops; per-neighbour
 // quantities (cutoff function, distances) use the correctly-rounded library calls.

@@ -196,7 +196,7 @@ def test_denser_frame_after_the_last_check_is_still_exact():
     assert np.abs(grad.cpu().numpy() - g_ref).max() <= FORCE_RTOL * np.abs(g_ref).max()
 
 
-@pytest.mark.parametrize("kernel", ["0", "1"])
+@pytest.mark.parametrize("kernel", ["0", "1", "2"])
 @pytest.mark.parametrize("kind", ["water", "seven_species", "dense"])
 def test_both_angular_forward_kernels(monkeypatch, kernel, kind):
     """The handle picks one of two angular forward kernels from the species composition (chunked view of the triple
