@@ -11,6 +11,7 @@
 
 #include "ani_kernels.h"
 #include "ani_angular_mfma.h"
+#include "ani_angular_bwd.h"
 #include "host_common.h"
 
 using namespace nnpops;
@@ -37,8 +38,10 @@ struct nnpops_ani {
     int forward_kernel = 2;         // 2: matrix-core scatter (ani_angular_mfma.h), 1: chunked view, 0: run merging
     bool mfma_ok = false;           // at most 32 species pairs can occur in this system
     bool fwd_identity = false;      // angular function m sits at canonical slot m: 16-byte stores of the row
-    int fwd_chunk = 128;            // triples staged in LDS per chunk of the matrix-core forward kernel
+    int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel
     int fwd_waves_per_atom = 2;     // 2: a 128-lane workgroup per atom (half the LDS per wave), 1: a wave per atom
+    bool occ6 = false;              // register budget of the two-wave kernels: 6 (80 VGPRs) or 5 (96) waves per SIMD
+    int backward_kernel = 1;        // 1: two waves per atom, packed arithmetic (ani_angular_bwd.h), 0: the one-wave kernel
     int fwd_atoms_per_group = 1;    // > 1: every wave / workgroup walks that many atoms (amortises its prologue)
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
@@ -188,7 +191,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (h->fwd_waves_per_atom == 2) {                      // a 128-lane workgroup per atom
             int groups = N;
             if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
-            auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 2>;
+            auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
             hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, h->stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
                                h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw);
@@ -197,7 +200,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             const size_t lg = (size_t)lw * wpg2;
             int groups = div_up(N, wpg2);
             if (h->fwd_atoms_per_group > 1) groups = div_up(groups, h->fwd_atoms_per_group);
-            auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 1>;
+            auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 1, 5>;
             if (lg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
             hipLaunchKernelGGL(k, dim3(groups), dim3(64 * wpg2), lg, h->stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
                                h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw);
@@ -207,6 +210,24 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB,
                            h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, h->debug, lds_wave);
+    } else if (h->backward_kernel >= 1 && ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, true) <= 160 * 1024) {
+        // backward_kernel: 1 = one wave per atom, every triple reads its gradient block through the L1 (needs the 16-byte
+        // layout); 2 = one wave, gradient row staged in LDS; 3 / 4 = the same two with two waves per atom (A/B only)
+        const int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)grad_or_null & 15) == 0;
+        int mode = h->backward_kernel;
+        if (!vec_ok && (mode == 1 || mode == 3)) mode++;
+        const bool glds = mode == 2 || mode == 4;
+        const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, glds) + 15) & ~(size_t)15;
+        void (*k)(const AniParams*, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
+                  float4*, float4*, int, int, int) =
+            mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false> : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
+          : mode == 2 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, true>
+          : mode == 3 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false>
+                      : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, true>;
+        if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+        const int threads = mode >= 3 ? 128 : 64;
+        hipLaunchKernelGGL(k, dim3(N), dim3(threads), lb, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, N, h->hp.NB);
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
@@ -313,6 +334,8 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_OCC")) h->occ6 = std::atoi(e) >= 6;
+        if (const char* e = std::getenv("NNPOPS_ANI_BACKWARD")) h->backward_kernel = std::min(4, std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_WPA")) h->fwd_waves_per_atom = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_APG")) h->fwd_atoms_per_group = std::max(1, std::atoi(e));
     }

@@ -30,6 +30,7 @@
 namespace nnpops {
 
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kFwdSlots = 32;          // 2 sets x 16 quads
 
@@ -59,8 +60,8 @@ __device__ __forceinline__ const float* lds_ptr(int byte_address) {
 // WPA = waves per atom.  1: a wave owns an atom (both quad sets).  2: a 128-lane workgroup owns an atom -- the two
 // waves stage alternate batches of phase 1 into ONE shared staging area, meet at a barrier, and each runs the step loop of
 // one quad set: same instructions in total, half the LDS per wave (twice the waves per CU) and half the latency per atom.
-template <bool TORCHANI, int NFRP, int NFZP, int WPA>
-__global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, WPA == 2 ? 6 : 5) void ani_angular_forward_mfma(
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC>
+__global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
     const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
     const int* __restrict__ cnt_ro, float* __restrict__ angular, int ld_angular, int vec_ok, int lds_per_atom) {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, WPA == 2 ? 6 
                 }
             }
         }
-        sync();                                                // records and staging area are free for the next atom
+        if (i + stride_atoms < N) sync();                      // (another atom follows: records and staging area must be free)
     }
 }
 
