@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X NNPOps hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms 10000] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms 10000] [--no-cpu-baseline] [--no-side]
 
 Workload (BASELINE.json metric: "AEV+forces (energy+grad evals/sec) per GPU, 10k-atom box"):
 one *step* = one full ANI-2x symmetry-function evaluation of a 10 000-atom periodic box --
@@ -11,48 +11,56 @@ the upstream gradient already resident in HBM.  Everything goes through the C AB
 (include/nnpops_hip.h) on the current HIP stream; there is no host synchronisation inside the
 timed region.  Neighbour-buffer capacity is verified before and after the timed region.
 
-Multi-GPU (--gpus N under torch.distributed.run): the path shards over independent frames, so
-every rank evaluates its own 10k-atom frame (different seed) with no data-path collective
-("scaling": "weak"); value = total evaluations of all ranks / max-over-ranks time.
+Multi-GPU (`--gpus N`): when not already running under torch.distributed.run, bench.py re-executes
+itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`,
+one rank per GPU over RCCL.  The path shards over independent frames: every rank
+evaluates its own 10k-atom frame (different seed) and the per-atom forces of all frames are assembled
+with ONE all_gather per step (the only collective; "scaling": "weak");
+value = total evaluations of all ranks / max-over-ranks time.  BASELINE config 4 (1024 conformers, strong
+scaling over the same ranks) is run right after and reported under "side".
 
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries, under "side", short runs of the other
+BASELINE configurations (each with its own roofline and CPU baseline); `--workload X` runs one of them
+alone and prints its line instead.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from nnpops_amd import workloads  # noqa: E402
-from nnpops_amd.capi import AniSymmetryFunctions  # noqa: E402
-
-ROOFLINE_KERNELS = ("neighbors", "angular_forward", "angular_backward", "radial_backward")   # candidates for "dominant"
-ROCPROF_NAME = {"neighbors": "ani_neighbors_cells (neighbour rows + radial AEV)", "angular_forward": "ani_angular_forward",
-                "angular_backward": "ani_angular_backward", "radial_backward": "ani_radial_backward (+ force gather)"}
-
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP32_MATRIX_PEAK = 157.3   # TFLOP/s, v_mfma_f32_* with fp32 operands (same guide)
+F16_DENSE_PEAK = 2500.0    # TFLOP/s, dense fp16/bf16 MFMA (same guide)
+
+ROOFLINE_KERNELS = ("neighbors", "angular_forward", "angular_backward", "radial_backward")
+ROCPROF_NAME = {"neighbors": "ani_neighbors_cells (neighbour rows + radial AEV)", "angular_forward": "ani_angular_forward_mfma",
+                "angular_backward": "ani_angular_backward_pair", "radial_backward": "ani_radial_backward (+ force gather)"}
 
 
-def cpu_baseline(pos, species, box, rf, af, budget_s=25.0):
-    """Time the reference CPU path (oracle/_ref, the reference's own sources compiled in place) --
-    or, where that library is absent, this repository's C restatement -- on ONE host core, on a
-    bounded sample: as many fwd+bwd evaluations of the SAME 10k-atom frame as fit the budget
-    (at least one)."""
+# =============================================================================================
+# CPU legs (the reference's own CPU sources compiled in place under oracle/_ref, else the C restatement)
+# =============================================================================================
+def _cpu_classes():
     import oracle
     kind = "reference" if oracle.have_ref() else "port"
-    cls = oracle.RefAni if kind == "reference" else oracle.AniOracle
-    n = pos.shape[0]
-    obj = cls(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=True)
+    return kind, (oracle.RefAni if kind == "reference" else oracle.AniOracle)
+
+
+def _ani_eval_seconds(cls, pos, species, box, rf, af, repeats=1):
+    """Seconds per forward+backward evaluation of one frame on one core."""
+    import numpy as np
+    from nnpops_amd import workloads
+    obj = cls(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=box is not None)
     rng = np.random.default_rng(123)
     wr = wa = None
-    evals, t_total = 0, 0.0
-    while True:
+    best = None
+    for _ in range(repeats):
         t0 = time.perf_counter()
         r, a = obj.forward(pos, box)
         if wr is None:
@@ -60,58 +68,144 @@ def cpu_baseline(pos, species, box, rf, af, budget_s=25.0):
             wa = rng.standard_normal(a.shape).astype(np.float32)
         obj.backward(wr, wa)
         dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def cpu_worker_main(argv):
+    """`bench.py --cpu-worker N_ATOMS SEED`: one forward+backward of the reference CPU path on this core; prints the
+    seconds.  Started nproc times in parallel by cpu_baseline() for the 'all cores' figure (no torch import here)."""
+    from nnpops_amd import workloads
+    n, seed = int(argv[0]), int(argv[1])
+    _, cls = _cpu_classes()
+    pos, species, box = workloads.random_box(n, density=0.1, seed=seed, n_species=7)
+    rf, af = workloads.ani2x_functions()
+    print(_ani_eval_seconds(cls, pos, species, box, rf, af), flush=True)
+
+
+def cpu_baseline(pos, species, box, rf, af, budget_s=12.0, all_cores=True):
+    """The reference CPU path (single-threaded by construction: no OpenMP in the reference) on ONE host core, on a bounded
+    sample: as many fwd+bwd evaluations of the SAME frame as fit the budget (at least one); plus the only way the
+    reference can use more cores -- one independent frame per core, all cores at once."""
+    kind, cls = _cpu_classes()
+    n = pos.shape[0]
+    evals, t_total = 0, 0.0
+    while True:
+        dt = _ani_eval_seconds(cls, pos, species, box, rf, af)
         evals += 1
         t_total += dt
         if t_total + dt > budget_s:
             break
-    return {"value": evals / t_total, "unit": "evals/s", "cores": 1, "kind": kind,
-            "sample": f"{evals} fwd+bwd evaluation(s) of the same {n}-atom ANI-2x periodic frame, single thread "
-                      f"({t_total:.1f} s; host has {os.cpu_count()} cores, the reference CPU path is serial)"}
+    out = {"value": evals / t_total, "unit": "evals/s", "cores": 1, "kind": kind,
+           "sample": f"{evals} fwd+bwd evaluation(s) of the same {n}-atom ANI-2x periodic frame, single thread "
+                     f"({t_total:.1f} s; host has {os.cpu_count()} cores, the reference CPU path is serial)"}
+    if all_cores:
+        # One process per core, each evaluating its own frame, all started together.  Frames of 4000 atoms keep this leg
+        # to seconds (the reference is O(N^2)); the measured parallel speed-up over one core on the same frame size is
+        # applied to the single-core figure above.
+        ncpu, m = os.cpu_count() or 1, 4000
+        from nnpops_amd import workloads
+        p1, s1, b1 = workloads.random_box(m, density=0.1, seed=999, n_species=7)
+        t_single = _ani_eval_seconds(cls, p1, s1, b1, rf, af)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(m), str(1000 + k)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT) for k in range(ncpu)]
+        done, busy = 0, 0.0
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=300)
+                if p.returncode == 0 and o.strip():
+                    done += 1
+                    busy = max(busy, float(o.decode().strip()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        wall = time.perf_counter() - t0
+        if done:
+            speedup = (done / busy) * t_single               # frames per second with every core busy / one core alone
+            out["all_cores"] = {"value": out["value"] * speedup, "unit": "evals/s", "cores": ncpu, "parallel_speedup": round(speedup, 1),
+                                "sample": f"{done} independent {m}-atom frames, one process per core, started together: slowest frame "
+                                          f"{busy:.2f} s against {t_single:.2f} s alone ({wall:.1f} s wall with process start-up); the "
+                                          f"speed-up is applied to the single-core {n}-atom figure"}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)     # 0.07 s of GPU time: long enough for clocks and caches to settle
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--atoms", type=int, default=10000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="torchani / cfconv workloads: replay the step as one captured HIP graph")
-    ap.add_argument("--nn-layout", default="fused", choices=["fused", "grouped", "reference"],
-                    help="torchani workload: species-grouped GEMMs (default) or the reference's per-atom replicated weights")
-    ap.add_argument("--neighbor-algorithm", type=int, default=0)
-    ap.add_argument("--workload", default="aev", choices=["aev", "cfconv", "conformers", "neighbors", "torchani"],
-                    help="aev: the headline metric (default); cfconv: BASELINE config 3; conformers: BASELINE config 4; "
-                         "neighbors: BASELINE config 5; torchani: BASELINE config 2 (side measurements, same JSON shape)")
-    args = ap.parse_args()
-    if args.workload == "cfconv":
-        return main_cfconv(args)
-    if args.workload == "conformers":
-        return main_conformers(args)
-    if args.workload == "neighbors":
-        return main_neighbors(args)
-    if args.workload == "torchani":
-        return main_torchani(args)
+# =============================================================================================
+# process group / self-spawn
+# =============================================================================================
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # ---- synthetic frame of this rank ----
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks ourselves."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Ranks:
+    """rank / device / process group of this process (world 1: no process group)."""
+
+    def __init__(self):
+        import torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (there is no CPU fallback in the product path)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # "nccl" is RCCL on ROCm
+            self.dist = dist
+
+    def barrier(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        import torch
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        if self.dist:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# =============================================================================================
+# headline: ANI-2x AEV forward+backward, 10 000-atom periodic box
+# =============================================================================================
+def run_aev(args, R):
+    import numpy as np
+    import torch
+    from nnpops_amd import workloads
+    from nnpops_amd.capi import AniSymmetryFunctions, lib, OK
+    rank, world, dev, dist = R.rank, R.world, R.dev, R.dist
     n = args.atoms
     pos, species, box = workloads.random_box(n, density=0.1, seed=100 + rank, n_species=7)
     rf, af = workloads.ani2x_functions()
     sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=True,
-                               device=local_rank)
+                               device=R.local_rank)
     if args.neighbor_algorithm:
         sym.set_neighbor_algorithm(args.neighbor_algorithm)
     tpos = torch.tensor(pos, device=dev)
@@ -122,10 +216,13 @@ def main():
     g_rad = torch.randn(radial.shape, device=dev, generator=gen)
     g_ang = torch.randn(angular.shape, device=dev, generator=gen)
     grad = torch.empty((n, 3), device=dev)
+    all_forces = torch.empty((world * n, 3), device=dev) if dist else None
 
     def step():
         sym.compute(tpos, tbox, radial, angular, check=False)
         sym.backprop(g_rad, g_ang, grad)
+        if dist:                                              # the path's only exchange: per-atom forces of every frame
+            dist.all_gather_into_tensor(all_forces, grad)
 
     sym.compute(tpos, tbox, radial, angular, check=True)     # calibrates neighbour capacity (blocks)
     # Warm-up, with events around EVERY kernel: the per-kernel breakdown (diagnostic) and the choice of the
@@ -140,99 +237,150 @@ def main():
         step()
     kern_all = {k: (1e-3 * ms / max(c, 1)) for k, (ms, c) in breakdown.items()}
     dominant = max(ROOFLINE_KERNELS, key=lambda k: kern_all.get(k, 0.0))
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # what an event pair reports for an EMPTY bracket on this stream (marker processing, not kernel time): the
-    # per-kernel figures below are net of it, which is what makes them agree with rocprofv3's kernel durations
-    event_overhead = sym.timing_overhead()                                 # seconds
+    R.barrier()
+    event_overhead = sym.timing_overhead()                   # seconds reported for an EMPTY event bracket on this stream
     sym.enable_timing(True, only=[dominant])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    R.barrier()
     elapsed = time.perf_counter() - t0
     timing = sym.get_timing()
     sym.enable_timing(False)
-    max_row, max_ang = sym.neighbor_stats()                   # raises nothing; verify no overflow happened
-    from nnpops_amd.capi import lib, OK
+    max_row, max_ang = sym.neighbor_stats()
     assert lib().nnpops_ani_check(sym._h, None, None) == OK, "neighbour buffers overflowed inside the timed region"
     assert bool(torch.isfinite(grad).all())
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        assert bool(torch.equal(all_forces[rank * n:(rank + 1) * n], grad))
+    elapsed = R.max_over_ranks(elapsed)
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
-        # roofline of the dominant kernel family: the angular kernels move one 896-float row per atom
-        # (forward: written once; backward: read once) + positions/species.  SURVEY.md s8(d):
-        # forward N*16 + N*896*4 bytes, backward N*896*4 + N*12 bytes.
-        kern = {k: max(v - event_overhead, 0.0) if v > 0 else 0.0 for k, v in kern_all.items()}   # s per launch (warm-up pass)
-        ms_dom, c_dom = timing[dominant]
-        kern[dominant] = max(1e-3 * ms_dom / max(c_dom, 1) - event_overhead, 1e-9)  # ... the dominant one from the timed region
-        # Algorithmic bytes per launch: unique bytes in + bytes out, no re-reads.
-        #   angular forward   N*16 (records) + N*896*4 (row written once)
-        #   angular backward  N*896*4 (upstream row read once) + N*12
-        #   neighbours        N*16 in (cell-ordered positions) + per atom: row <n_Rcr>*16, records <n_Rca>*36,
-        #                     triple list <triples>*4, radial AEV S*nR*4, counts 8   (liquid-density means of s8)
-        #   radial backward   N*S*nR*4 (gradient row) + row <n_Rcr>*16 + legs <n_Rca>*20 + N*12
-        nb_na, nb_nr = sym.angular_width, sym.radial_width
-        n_rcr, n_rca, n_tri = 55.6, 18.0, 153.0
-        alg_bytes = {"angular_forward": n * 16 + n * nb_na * 4, "angular_backward": n * nb_na * 4 + n * 12,
-                     "neighbors": int(n * (16 + n_rcr * 16 + n_rca * 36 + n_tri * 4 + nb_nr * 4 + 8)),
-                     "radial_backward": int(n * (nb_nr * 4 + n_rcr * 16 + n_rca * 20 + 12))}
-        achieved = alg_bytes[dominant] / kern[dominant] / 1e9 if kern[dominant] > 0 else 0.0
-        traffic = None                                           # HBM bytes/launch from the committed PMC passes
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("atoms") == n:
-                traffic = tj.get(dominant)
-        except (OSError, ValueError):
-            pass
-        out = {
-            "metric": "AEV+forces evaluations/sec (ANI-2x symmetry functions, energy+gradient), 10k-atom periodic box",
-            "value": round(value, 3), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ANI-2x AEV forward+backward, {n}-atom periodic cubic box at 0.1 atoms/A^3, "
-                                   "7 species uniform, Rcr 5.1 / Rca 3.5, 16 radial + 32 angular functions (AEV width 1008); "
-                                   "one independent frame per GPU",
-                       "atoms": n, "frames_per_gpu": 1, "max_neighbors_rcr": max_row, "max_neighbors_rca": max_ang},
-            "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
-            "event_pair_overhead_us": round(1e6 * event_overhead, 2),
-            "roofline": {"bound": "hbm", "kernel": ROCPROF_NAME.get(dominant, dominant), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes[dominant]},
-        }
-        if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(pos, species, box, rf, af)
-        print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+    kern = {k: max(v - event_overhead, 0.0) if v > 0 else 0.0 for k, v in kern_all.items()}   # s per launch (warm-up pass)
+    ms_dom, c_dom = timing[dominant]
+    kern[dominant] = max(1e-3 * ms_dom / max(c_dom, 1) - event_overhead, 1e-9)  # ... the dominant one from the timed region
+    # ALGORITHMIC bytes per launch = SURVEY.md s8(d) bytes only (what an ideal implementation must move): inputs read
+    # once, outputs written once, nothing of this implementation's intermediate arrays.
+    na_w, nr_w = sym.angular_width, sym.radial_width
+    alg = {"angular_forward": n * 16 + n * na_w * 4,          # positions+species in, the 896-float row out
+           "angular_backward": n * na_w * 4 + n * 12,         # the upstream row in, forces out
+           "neighbors": n * 16 + n * nr_w * 4,                # positions+species in, the radial AEV out (it is fused here)
+           "radial_backward": n * nr_w * 4 + n * 12}          # the radial gradient row in, forces out
+    step_bytes = n * (16 + 2 * (na_w + nr_w) * 4 + 12)        # N * (16 + 2 * 4032 + 12)
+    traffic_all = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj.get("atoms") == n:
+            traffic_all = tj
+    except (OSError, ValueError):
+        pass
+
+    def roof(k):
+        ach = alg[k] / kern[k] / 1e9 if kern.get(k, 0) > 0 else 0.0
+        return {"kernel": ROCPROF_NAME[k], "us": round(1e6 * kern.get(k, 0.0), 2), "algorithmic_bytes_per_launch": alg[k],
+                "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(k)}
+
+    dom = roof(dominant)
+    out = {
+        "metric": "AEV+forces evaluations/sec (ANI-2x symmetry functions, energy+gradient), 10k-atom periodic box",
+        "value": round(value, 3), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ANI-2x AEV forward+backward, {n}-atom periodic cubic box at 0.1 atoms/A^3, "
+                               "7 species uniform, Rcr 5.1 / Rca 3.5, 16 radial + 32 angular functions (AEV width 1008); "
+                               "one independent frame per GPU" + (", forces of all frames all_gathered every step (RCCL)" if dist else ""),
+                   "atoms": n, "frames_per_gpu": 1, "max_neighbors_rcr": max_row, "max_neighbors_rca": max_ang},
+        "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
+        "event_pair_overhead_us": round(1e6 * event_overhead, 2),
+        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                     "limiter": "not HBM: every per-atom kernel of this path is bound by latency x occupancy and vector-instruction "
+                                "issue (DESIGN.md s6: ~10 KB of LDS per atom in flight, ~1000 VALU instructions per atom per kernel)",
+                     "angular": {"forward": roof("angular_forward"), "backward": roof("angular_backward")},
+                     "per_kernel": {k: roof(k) for k in ROOFLINE_KERNELS},
+                     "step": {"algorithmic_bytes": step_bytes, "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                              "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
+    }
+    if not args.no_cpu_baseline and world == 1:              # the CPU leg is timed on rank 0 at N = 1 only
+        out["cpu_baseline"] = cpu_baseline(pos, species, box, rf, af)
+    return out
 
 
-def main_neighbors(args):
-    """BASELINE config 5: getNeighborPairs (cutoff 5.2 A, compact mode) + ANI-2x AEV on the same 100 000-atom
-    periodic box (uniform 0.1 atoms/A^3, seed 6).  The reference cannot run this size at all (O(N^2) pair index
-    overflows int32, getNeighborPairsCUDA.cu:129).  One step = one neighbour-pair list + one AEV forward+backward.
-    Side measurement (not the headline metric)."""
-    from nnpops_amd.capi import neighbor_pairs_forward
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+# =============================================================================================
+# BASELINE config 1: 50-atom molecule in vacuum, latency per evaluation
+# =============================================================================================
+def run_latency(args, R):
+    import numpy as np
+    import torch
+    from nnpops_amd import workloads
+    from nnpops_amd.capi import AniSymmetryFunctions
+    dev = R.dev
+    pos, species = workloads.conformer(50, seed=0)
+    rf, af = workloads.ani2x_functions()
+    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, device=R.local_rank)
+    tpos = torch.tensor(pos, device=dev)
+    radial, angular = sym.compute(tpos, None, check=True)
+    g_rad, g_ang = torch.randn_like(radial), torch.randn_like(angular)
+    grad = torch.empty((50, 3), device=dev)
+
+    def step():
+        sym.compute(tpos, None, radial, angular, check=False)
+        sym.backprop(g_rad, g_ang, grad)
+
+    for _ in range(50):
+        step()
+    torch.cuda.synchronize()
+    k = 2000
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    eager_us = 1e6 * (time.perf_counter() - t0) / k
+    # the same five launches replayed from one HIP graph (what an MD loop would do)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        graph.replay()
+    torch.cuda.synchronize()
+    graph_us = 1e6 * (time.perf_counter() - t0) / k
+    out = {"metric": "ANI-2x AEV forward+backward latency, 50-atom molecule in vacuum", "value": round(min(eager_us, graph_us), 2),
+           "unit": "us/eval", "higher_is_better": False, "eager_us": round(eager_us, 2), "hip_graph_us": round(graph_us, 2),
+           "algorithmic_bytes": 50 * (16 + 2 * 1008 * 4 + 12),
+           "config": {"workload": "BASELINE config 1: 50-atom conformer (seed 0), non-periodic, all-pairs neighbour search, "
+                                  "5 launches per evaluation; latency-bound (0.4 MB of algorithmic traffic)"}}
+    if not args.no_cpu_baseline:
+        kind, cls = _cpu_classes()
+        dt = _ani_eval_seconds(cls, pos, species, None, rf, af, repeats=20)
+        out["cpu_baseline"] = {"value": round(1e6 * dt, 1), "unit": "us/eval", "cores": 1, "kind": kind,
+                               "sample": "best of 20 fwd+bwd evaluations of the same molecule, single thread"}
+    return out
+
+
+# =============================================================================================
+# BASELINE config 5: getNeighborPairs + AEV at 100 000 atoms
+# =============================================================================================
+def run_neighbors(args, R):
+    import numpy as np
+    import torch
+    from nnpops_amd import workloads
+    from nnpops_amd.capi import AniSymmetryFunctions, neighbor_pairs_forward
+    dev = R.dev
     n = args.atoms if args.atoms != 10000 else 100000
     cutoff, max_pairs = 5.2, int(32 * n)
     pos, species, box = workloads.random_box(n, density=0.1, seed=6, n_species=7)
     rf, af = workloads.ani2x_functions()
-    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=True, device=local_rank)
+    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, periodic=True, device=R.local_rank)
     tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
     radial = torch.empty((n, sym.radial_width), device=dev)
     angular = torch.empty((n, sym.angular_width), device=dev)
@@ -254,47 +402,71 @@ def main_neighbors(args):
         sym.backprop(g_rad, g_ang, grad)
         if ev: ev[3].record()
 
-    for _ in range(args.warmup):
+    steps, warm = min(args.steps, 50), min(args.warmup, 10)
+    for _ in range(warm):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    sym.enable_timing(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     step(ev)                                           # one extra, event-bracketed step for the phase split
     torch.cuda.synchronize()
+    kt = {k: 1e3 * ms / max(c, 1) for k, (ms, c) in sym.get_timing().items()}        # us per launch (event brackets included)
+    sym.enable_timing(False)
     t_nb, t_fwd, t_bwd = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
     nb_bytes = n * 12 + found * 24                      # positions in, (2 ints + 3 floats + 1 float) per pair out
+    ang_bytes = n * 16 + n * sym.angular_width * 4
     aev_bytes = n * (16 + 2 * (sym.radial_width + sym.angular_width) * 4 + 12)
-    print(json.dumps({
+    out = {
         "metric": "getNeighborPairs + ANI-2x AEV forward+backward evaluations/sec, 100k-atom periodic box, cutoff 5.2 A",
-        "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"getNeighborPairs(cutoff {cutoff}, max_num_pairs {max_pairs}) + ANI-2x AEV, {n} atoms periodic, "
                                "0.1 atoms/A^3, 7 species", "atoms": n, "pairs_found": found},
         "phases_ms": {"neighbor_pairs": round(t_nb, 4), "aev_forward": round(t_fwd, 4), "aev_backward": round(t_bwd, 4)},
+        "kernels_us": {k: round(v, 1) for k, v in kt.items()},
         "roofline": {"bound": "hbm", "kernel": "getNeighborPairs (3 launches + cell grid)", "achieved": round(nb_bytes / (t_nb * 1e-3) / 1e9, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb_bytes / (t_nb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "traffic": None, "algorithmic_bytes_per_launch": nb_bytes,
+                     "angular_forward": {"algorithmic_bytes": ang_bytes, "us": round(kt.get("angular_forward", 0.0), 1),
+                                         "achieved": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3, 2),
+                                         "frac": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3 / HBM_PEAK_GBS, 5)},
                      "aev_step": {"algorithmic_bytes": aev_bytes,
                                   "achieved": round(aev_bytes / ((t_fwd + t_bwd) * 1e-3) / 1e9, 2)}},
-    }), flush=True)
+    }
+    if not args.no_cpu_baseline:
+        # the reference cannot run getNeighborPairs at this size (int32 pair index); its AEV path is O(N^2): time it at
+        # three sizes and extrapolate t = a N^2 + b N (least squares) to N
+        kind, cls = _cpu_classes()
+        sizes, times = [2000, 4000, 8000], []
+        for m in sizes:
+            p, s, b = workloads.random_box(m, density=0.1, seed=6, n_species=7)
+            times.append(_ani_eval_seconds(cls, p, s, b, rf, af))
+        A = np.array([[m * m, m] for m in sizes], dtype=np.float64)
+        coef, *_ = np.linalg.lstsq(A, np.array(times), rcond=None)
+        t_n = float(coef[0] * n * n + coef[1] * n)
+        out["cpu_baseline"] = {"value": round(1.0 / t_n, 6), "unit": "evals/s (AEV fwd+bwd only)", "cores": 1, "kind": kind,
+                               "sample": f"extrapolated: reference AEV fwd+bwd timed at N = {sizes} ({', '.join(f'{t:.2f}' for t in times)} s), "
+                                         f"fit t = {coef[0]:.3e} N^2 + {coef[1]:.3e} N -> {t_n:.0f} s at N = {n}; the reference cannot "
+                                         "run getNeighborPairs at this size at all"}
+    return out
 
 
-def main_torchani(args):
-    """BASELINE config 2: OptimizedTorchANI (species converter + HIP AEV + BatchedNN + energy shifter) on a
-    2 001-atom periodic water box, fp32, 8 models with the ANI-2x layer widths and random weights (torchani and
-    its parameters are not available offline).  One step = energy forward + backward to the forces, through the
-    torch.ops / autograd surface exactly as a user calls it.  Side measurement (not the headline metric)."""
-    sys.path.insert(0, ROOT)
+# =============================================================================================
+# BASELINE config 2: OptimizedTorchANI, 2 001-atom periodic water box
+# =============================================================================================
+def run_torchani(args, R):
+    import numpy as np
+    import torch
+    from nnpops_amd import workloads
     from NNPOps import OptimizedTorchANI
     from NNPOps.BatchedNN import TorchANIBatchedNN
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = R.dev
     model = workloads.torchani_like_model(n_models=8, seed=2)
     pos, species, box = workloads.water_box(667, seed=1)
     numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=dev)
@@ -314,7 +486,8 @@ def main_torchani(args):
         energy.sum().backward()
         return energy
 
-    for _ in range(args.warmup):
+    steps, warm = min(args.steps, 200), min(args.warmup, 20)
+    for _ in range(max(warm, 3)):
         step()
     torch.cuda.synchronize()
     if args.graph:
@@ -338,7 +511,7 @@ def main_torchani(args):
         torch.cuda.synchronize()
         assert torch.allclose(g_energy, eager_e, rtol=1e-6, atol=1e-4) and torch.allclose(g_forces, eager_g, rtol=1e-4, atol=1e-5)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             graph.replay()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -346,7 +519,7 @@ def main_torchani(args):
         tpos.grad = g_forces
     else:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             energy = step()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -356,39 +529,47 @@ def main_torchani(args):
     macs = {s: 1008 * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}
     flops_fwd = 2.0 * 8 * sum(macs[int(s)] for s in species)
     nn_weight_bytes = sum(b.numel() * 4 for name, b in opt.neural_networks.named_buffers() if "layer" in name)
-    print(json.dumps({
+    tflops = 2 * flops_fwd / elapsed * steps / 1e12
+    fused = args.nn_layout == "fused"
+    out = {
         "metric": "OptimizedTorchANI energy+forces evaluations/sec, 2001-atom periodic water box, 8 models, fp32",
-        "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" + (" (network GEMMs: operands split into two fp16 planes, products exact, fp32 accumulation)" if args.nn_layout == "fused" else ""),
+        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" + (" (network GEMMs: operands split into two fp16 planes, products exact, fp32 accumulation)" if fused else ""),
         "data": "synthetic",
         "config": {"workload": f"OptimizedTorchANI, {n}-atom periodic water box (667 H2O), ANI-2x AEV + 8 x ANI-2x-shaped networks, "
                                f"random weights, BatchedNN layout = {args.nn_layout}" + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
                    "nn_weight_bytes": nn_weight_bytes},
-        "roofline": {"bound": "mfma", "kernel": ("gemm_h2 (batched_nn.hip: split-fp16 GEMMs with fused activations)" if args.nn_layout == "fused"
+        "roofline": {"bound": "mfma", "kernel": ("gemm_h2 (batched_nn.hip: split-fp16 GEMMs with fused activations)" if fused
                                                 else "BatchedNN GEMMs (hipBLASLt via torch.matmul)") + ", forward + input-gradient backward",
-                     "achieved": round(2 * flops_fwd / elapsed * args.steps / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": round(2 * flops_fwd / elapsed * args.steps / 1e12 / 157.3, 5), "traffic": None,
-                     "note": "whole step time (AEV + NN + autograd overhead) against the NN's algorithmic flops; fp32 matrix peak"},
-    }), flush=True)
+                     "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",
+                     "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,
+                     "issued": ({"instruction": "v_mfma_f32_16x16x32_f16, 3 products per fp32 product", "tflops": round(3 * tflops, 2),
+                                 "peak": F16_DENSE_PEAK, "frac": round(3 * tflops / F16_DENSE_PEAK, 5)} if fused else None),
+                     "note": "whole step time (AEV + NN + autograd overhead) against the NN's algorithmic flops; `frac` is against the "
+                             "fp32 matrix peak the reference's arithmetic would be priced at, `issued` against the dense fp16 peak of "
+                             "the instruction actually issued"},
+    }
+    if not args.no_cpu_baseline:
+        kind, cls = _cpu_classes()
+        rf, af = workloads.ani2x_functions()
+        dt = _ani_eval_seconds(cls, pos, species, box, rf, af)
+        out["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "evals/s (AEV fwd+bwd only)", "cores": 1, "kind": kind,
+                               "sample": f"one AEV fwd+bwd of the same {n}-atom water box ({dt:.2f} s); the reference's CPU BatchedNN "
+                                         "(ATen matmuls on 21.7 GB of per-atom replicated weights) is not timed"}
+    return out
 
 
-def main_conformers(args):
-    """BASELINE config 4: ANI-2x AEV forward+backward on 1 024 independent ~60-atom conformers, sharded over
-    the ranks by contiguous blocks of the batch (strong scaling: total work is fixed).  Each rank evaluates its
-    block with ONE batched handle (nnpops_ani_set_molecules); the only collective is the final all_gather of the
-    per-atom forces (RCCL over xGMI; ~0.74 MB in total)."""
+# =============================================================================================
+# BASELINE config 4: 1 024 conformers, strong scaling over the ranks
+# =============================================================================================
+def run_conformers(args, R):
+    import numpy as np
+    import torch
+    from nnpops_amd import workloads
+    from nnpops_amd.capi import AniSymmetryFunctions
     from nnpops_amd.parallel import gather_rows, shard_molecules
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rank, world, dev, dist = R.rank, R.world, R.dev, R.dist
     B = 1024
     rng = np.random.default_rng(5)
     sizes = rng.integers(50, 71, size=B).tolist()
@@ -401,7 +582,7 @@ def main_conformers(args):
     species = np.concatenate([m[1] for m in mols]).astype(np.int32)
     offsets = (offsets_all[lo:hi + 1] - offsets_all[lo]).astype(np.int32)
     rf, af = workloads.ani2x_functions()
-    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, device=local_rank)
+    sym = AniSymmetryFunctions(7, workloads.ANI2X["Rcr"], workloads.ANI2X["Rca"], species, rf, af, device=R.local_rank)
     sym.set_molecules(offsets)
     n = pos.shape[0]
     tpos = torch.tensor(pos, device=dev)
@@ -418,46 +599,52 @@ def main_conformers(args):
         return gather_rows(grad, rows) if dist else grad
 
     sym.compute(tpos, None, radial, angular, check=True)
-    for _ in range(args.warmup):
+    steps, warm = min(args.steps, 100), min(args.warmup, 10)
+    for _ in range(warm):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    R.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         forces = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    R.barrier()
+    elapsed = R.max_over_ranks(time.perf_counter() - t0)
     assert forces.shape[0] == int(offsets_all[-1]) and bool(torch.isfinite(forces).all())
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "AEV+forces evaluations/sec of a 1024-conformer batch (ANI-2x, ~60 atoms each)",
-            "value": round(args.steps / elapsed, 3), "unit": "batch evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ANI-2x AEV forward+backward, 1024 independent conformers of 50-70 atoms, contiguous batch "
-                                   "blocks per GPU, one all_gather of the forces per step", "conformers": B,
-                       "atoms_total": int(offsets_all[-1]), "atoms_this_rank": n}}), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    atoms_total = int(offsets_all[-1])
+    step_bytes = atoms_total * (16 + 2 * 1008 * 4 + 12)
+    out = {
+        "metric": "AEV+forces evaluations/sec of a 1024-conformer batch (ANI-2x, ~60 atoms each)",
+        "value": round(steps / elapsed, 3), "unit": "batch evals/s", "n_gpus": world, "steps": steps,
+        "warmup": warm, "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ANI-2x AEV forward+backward, 1024 independent conformers of 50-70 atoms, contiguous batch "
+                               "blocks per GPU, one batched handle per GPU, one all_gather of the forces per step", "conformers": B,
+                   "atoms_total": atoms_total, "atoms_this_rank": n},
+        "roofline": {"bound": "hbm", "kernel": "whole step (5 launches per GPU)", "achieved": round(step_bytes / elapsed * steps / 1e9, 2),
+                     "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(step_bytes / elapsed * steps / 1e9 / (HBM_PEAK_GBS * world), 5),
+                     "traffic": None, "algorithmic_bytes_per_launch": step_bytes},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        # the reference has no batch dimension (SymmetryFunctions.py:110): a loop over per-molecule objects on one core
+        kind, cls = _cpu_classes()
+        sample = 64
+        t_cpu = sum(_ani_eval_seconds(cls, mols[m][0], mols[m][1], None, rf, af) for m in range(sample))
+        out["cpu_baseline"] = {"value": round(1.0 / (t_cpu / sample * B), 4), "unit": "batch evals/s", "cores": 1, "kind": kind,
+                               "sample": f"{sample} of the 1024 molecules, one object each, fwd+bwd: {1e6 * t_cpu / sample:.0f} us per molecule, "
+                                         f"x 1024 = {t_cpu / sample * B:.2f} s per batch"}
+    return out
 
 
-def main_cfconv(args):
-    """BASELINE config 3: CFConv + CFConvNeighbors, W=128, G=50, 5 A cutoff, 10 000-atom periodic box.
-    One step = neighbour build + forward + backward.  Side measurement (not the headline metric)."""
+# =============================================================================================
+# BASELINE config 3: SchNet CFConv, 10 000-atom periodic box
+# =============================================================================================
+def run_cfconv(args, R):
+    import numpy as np
+    import torch
+    from nnpops_amd import workloads
     from nnpops_amd.capi import CFConv, CFConvNeighbors
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = R.dev
     n, W, G, cutoff, sigma = args.atoms, 128, 50, 5.0, 0.1
     pos, _, box = workloads.random_box(n, density=0.1, seed=3)
     rng = np.random.default_rng(4)
@@ -467,8 +654,8 @@ def main_cfconv(args):
     b2 = (0.1 * rng.standard_normal(W)).astype(np.float32)
     x = rng.standard_normal((n, W)).astype(np.float32)
     gy = rng.standard_normal((n, W)).astype(np.float32)
-    nb = CFConvNeighbors(n, cutoff, periodic=True, device=local_rank)
-    cf = CFConv(n, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True, device=local_rank)
+    nb = CFConvNeighbors(n, cutoff, periodic=True, device=R.local_rank)
+    cf = CFConv(n, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True, device=R.local_rank)
     tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
     tx, tg = torch.tensor(x, device=dev), torch.tensor(gy, device=dev)
     out = torch.empty_like(tx)
@@ -480,7 +667,8 @@ def main_cfconv(args):
         cf.compute(nb, tpos, tx, tbox, out)
         return cf.backprop(nb, tpos, tx, tg, tbox)
 
-    for _ in range(args.warmup):
+    steps, warm = min(args.steps, 200), min(args.warmup, 20)
+    for _ in range(max(warm, 2)):
         step()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -505,48 +693,104 @@ def main_cfconv(args):
         torch.cuda.synchronize()
         assert torch.equal(g_xg, eager_xg) and torch.equal(g_pg, eager_pg)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             graph.replay()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     else:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     flops_fwd = 2.0 * (G * W + W * W) * pairs            # per half pair
     split = os.environ.get("NNPOPS_CFCONV_SPLIT", "1") != "0" and os.environ.get("NNPOPS_CFCONV_HALF", "1") != "0"
+    tflops = flops_fwd / (tf * 1e-3) / 1e12
     out_json = {
         "metric": "CFConv build+forward+backward evaluations/sec, W=128 G=50 cutoff 5 A, 10k-atom periodic box",
-        "value": round(args.steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" + (" (dense layers: operands split into two fp16 planes, products exact, fp32 accumulation)" if split else ""),
         "data": "synthetic",
         "config": {"workload": f"SchNet CFConv + neighbour list, {n} atoms periodic, W={W}, G={G}, cutoff {cutoff} A, ssp"
                                + (", replayed as one HIP graph" if args.graph else ""), "half_pairs": pairs},
         "phases_ms": {"build": round(tb, 4), "forward": round(tf, 4), "backward": round(tbw, 4)},
-        "roofline": {"bound": "mfma", "kernel": ("cfconv_filters_h2" if split else "cfconv_filters_mfma") + " + cfconv_gather (forward)", "achieved": round(flops_fwd / (tf * 1e-3) / 1e12, 3),
-                     "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops_fwd / (tf * 1e-3) / 1e12 / 157.3, 5), "traffic": None,
-                     "note": "algorithmic flops (half-pair count) / measured forward time (filters kernel + gather kernel); fp32 matrix peak"},
+        "roofline": {"bound": "mfma", "kernel": ("cfconv_filters_h2" if split else "cfconv_filters_mfma") + " + cfconv_gather (forward)",
+                     "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s", "frac": round(tflops / FP32_MATRIX_PEAK, 5),
+                     "traffic": None,
+                     "issued": ({"instruction": "v_mfma_f32_16x16x32_f16, 3 products per fp32 product", "tflops": round(3 * tflops, 2),
+                                 "peak": F16_DENSE_PEAK, "frac": round(3 * tflops / F16_DENSE_PEAK, 5)} if split else None),
+                     "note": "algorithmic flops (half-pair count) / measured forward time (filters kernel + gather kernel); `frac` is "
+                             "against the fp32 matrix peak the reference's arithmetic would be priced at, `issued` against the dense "
+                             "fp16 peak of the instruction actually issued"},
     }
     if not args.no_cpu_baseline:
         import oracle
         kind = "reference" if oracle.have_ref() else "port"
         NB, CF = (oracle.RefCFConvNeighbors, oracle.RefCFConv) if kind == "reference" else (oracle.CFConvNeighborsOracle, oracle.CFConvOracle)
-        m = 2000                                        # bounded sample: the first 2000 atoms' worth of work scales ~linearly
+        m = 2000                                        # bounded sample: the work is linear in N at fixed density
         pos_s, _, box_s = workloads.random_box(m, density=0.1, seed=3)
         onb = NB(m, cutoff, True)
         ocf = CF(m, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True)
         t1 = time.perf_counter()
         onb.build(pos_s, box_s)
-        y = ocf.forward(onb, pos_s, x[:m], box_s)
+        ocf.forward(onb, pos_s, x[:m], box_s)
         ocf.backward(onb, pos_s, x[:m], gy[:m], box_s)
         dt = time.perf_counter() - t1
         out_json["cpu_baseline"] = {"value": round(1.0 / dt * m / n, 5), "unit": "evals/s", "cores": 1, "kind": kind,
                                     "sample": f"one build+fwd+bwd of a {m}-atom box of the same density ({dt:.1f} s), scaled by "
                                               f"{m}/{n} atoms (pair count is linear in N at fixed density)"}
-    print(json.dumps(out_json), flush=True)
+    return out_json
+
+
+WORKLOADS = {"aev": run_aev, "cfconv": run_cfconv, "conformers": run_conformers, "neighbors": run_neighbors,
+             "torchani": run_torchani, "latency": run_latency}
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker_main(sys.argv[2:])
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)     # 0.06 s of GPU time: long enough for clocks and caches to settle
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--atoms", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--graph", action="store_true", help="torchani / cfconv workloads: replay the step as one captured HIP graph")
+    ap.add_argument("--nn-layout", default="fused", choices=["fused", "grouped", "reference"],
+                    help="torchani workload: species-grouped GEMMs (default) or the reference's per-atom replicated weights")
+    ap.add_argument("--neighbor-algorithm", type=int, default=0)
+    ap.add_argument("--workload", default="aev", choices=sorted(WORKLOADS),
+                    help="aev: the headline metric (default, with the others attached under 'side'); the rest run one BASELINE "
+                         "configuration alone: latency = config 1, torchani = 2, cfconv = 3, conformers = 4, neighbors = 5")
+    args = ap.parse_args()
+    spawn_ranks_if_needed(args)
+    R = Ranks()
+    if args.workload != "aev":
+        out = WORKLOADS[args.workload](args, R)
+        if R.rank == 0:
+            print(json.dumps(out), flush=True)
+        R.close()
+        return
+    out = run_aev(args, R)
+    side = {}
+    if not args.no_side:
+        sargs = argparse.Namespace(**vars(args))
+        sargs.steps, sargs.warmup, sargs.atoms = min(args.steps, 100), min(args.warmup, 10), 10000
+        names = ["conformers"] if R.world > 1 else ["latency", "torchani", "cfconv", "conformers", "neighbors"]
+        for name in names:
+            try:
+                res = WORKLOADS[name](sargs, R)
+            except Exception as exc:                          # a side measurement must never cost the headline line
+                res = {"error": f"{type(exc).__name__}: {exc}"}
+            if R.rank == 0:
+                side[name] = res
+    if R.rank == 0:
+        if side:
+            out["side"] = side
+        print(json.dumps(out), flush=True)
+    R.close()
 
 
 if __name__ == "__main__":

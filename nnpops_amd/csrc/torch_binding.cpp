@@ -25,6 +25,7 @@
 #include <torch/serialize/archive.h>
 
 #include <cmath>
+#include <limits>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -628,11 +629,173 @@ TORCH_LIBRARY_IMPL(neighbors, AutogradCUDA, m) {
     });
 }
 
-TORCH_LIBRARY_IMPL(neighbors, CPU, m) {
-    m.impl("getNeighborPairs", [](const Tensor& positions, const torch::Scalar&, const torch::Scalar&, const Tensor&, bool)
-                                   -> std::tuple<Tensor, Tensor, Tensor, Tensor> {
-        require_device_tensor(positions, "positions");
-        return {};
+// ---------------------------------------------------------------------------------------------
+// Host tensors.  The reference registers a CPU kernel of this op next to the device one (reference
+// src/pytorch/neighbors/getNeighborPairsCPU.cpp:19-108, a composition of differentiable ATen calls that materialises
+// all N(N-1)/2 candidate pairs); a drop-in keeps that dispatch key alive.  This is NOT a fallback of the device path --
+// device tensors never come here, and a missing HIP library still fails at import -- it is what `positions.cpu()`
+// callers of the reference get.  Written as plain loops over the pairs (no N^2 temporaries), same results:
+//   * pair k <-> (row, column < row) in the reference's tril order, delta = positions[row] - positions[column],
+//     triclinic wrap z, y, x with one round() each (:66-68), distance in the positions' dtype;
+//   * max_num_pairs == -1: every slot kept, pairs beyond the cutoff masked with -1 / NaN (:72-78);
+//   * otherwise: pairs with distance <= cutoff in tril order, padded with -1 / NaN up to max_num_pairs and NOT
+//     truncated beyond it; num_pairs reports the length after padding, as the reference's CPU kernel does (:97-98).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+void neighbor_pairs_host(const Tensor& positions, const Tensor& box, double cutoff, int64_t max_pairs, bool check,
+                         Tensor& neighbors, Tensor& deltas, Tensor& distances) {
+    const int64_t n = positions.size(0);
+    const T* pos = positions.data_ptr<T>();
+    const bool periodic = box.defined();
+    T b[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    if (periodic) {
+        const Tensor bc = box.to(positions.scalar_type()).contiguous();
+        for (int i = 0; i < 9; i++) b[i / 3][i % 3] = bc.data_ptr<T>()[i];
+    }
+    const T cut = (T)cutoff;
+    auto pair = [&](int64_t row, int64_t col, T (&d)[3]) -> T {
+        for (int c = 0; c < 3; c++) d[c] = pos[3 * row + c] - pos[3 * col + c];
+        if (periodic)
+            for (int axis = 2; axis >= 0; axis--) {
+                const T s = std::round(d[axis] / b[axis][axis]);
+                for (int c = 0; c < 3; c++) d[c] -= s * b[axis][c];
+            }
+        return std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    };
+    const T nan = std::numeric_limits<T>::quiet_NaN();
+    const auto iopt = positions.options().dtype(torch::kInt32);
+    if (max_pairs == -1) {
+        const int64_t slots = n * (n - 1) / 2;
+        neighbors = torch::empty({2, slots}, iopt);
+        deltas = torch::empty({slots, 3}, positions.options());
+        distances = torch::empty({slots}, positions.options());
+        int32_t* nb = neighbors.data_ptr<int32_t>();
+        T* dl = deltas.data_ptr<T>();
+        T* ds = distances.data_ptr<T>();
+        int64_t k = 0;
+        for (int64_t row = 1; row < n; row++)
+            for (int64_t col = 0; col < row; col++, k++) {
+                T d[3];
+                const T r = pair(row, col, d);
+                const bool keep = !(r > cut);                  // the reference masks `distances > cutoff`
+                nb[k] = keep ? (int32_t)row : -1;
+                nb[slots + k] = keep ? (int32_t)col : -1;
+                for (int c = 0; c < 3; c++) dl[3 * k + c] = keep ? d[c] : nan;
+                ds[k] = keep ? r : nan;
+            }
+        return;
+    }
+    int64_t found = 0;
+    for (int64_t row = 1; row < n; row++)
+        for (int64_t col = 0; col < row; col++) {
+            T d[3];
+            found += pair(row, col, d) <= cut ? 1 : 0;
+        }
+    if (check)
+        TORCH_CHECK(found <= max_pairs, "The maximum number of pairs has been exceed! Increase \"max_num_pairs\"");
+    const int64_t slots = std::max(found, max_pairs);
+    neighbors = torch::full({2, slots}, -1, iopt);
+    deltas = torch::full({slots, 3}, nan, positions.options());
+    distances = torch::full({slots}, nan, positions.options());
+    int32_t* nb = neighbors.data_ptr<int32_t>();
+    T* dl = deltas.data_ptr<T>();
+    T* ds = distances.data_ptr<T>();
+    int64_t k = 0;
+    for (int64_t row = 1; row < n; row++)
+        for (int64_t col = 0; col < row; col++) {
+            T d[3];
+            const T r = pair(row, col, d);
+            if (!(r <= cut)) continue;
+            nb[k] = (int32_t)row;
+            nb[slots + k] = (int32_t)col;
+            for (int c = 0; c < 3; c++) dl[3 * k + c] = d[c];
+            ds[k++] = r;
+        }
+}
+
+template <typename T>
+void neighbor_pairs_host_backward(const Tensor& neighbors, const Tensor& deltas, const Tensor& distances, const Tensor& gd,
+                                  const Tensor& gr, Tensor& gpos) {
+    const int64_t slots = distances.size(0);
+    const int32_t* nb = neighbors.data_ptr<int32_t>();
+    const T* dl = deltas.data_ptr<T>();
+    const T* ds = distances.data_ptr<T>();
+    const T* pgd = gd.data_ptr<T>();
+    const T* pgr = gr.data_ptr<T>();
+    T* out = gpos.data_ptr<T>();
+    for (int64_t k = 0; k < slots; k++) {
+        const int32_t row = nb[k], col = nb[slots + k];
+        if (row < 0) continue;                                 // masked / padding slot: no gradient (as the device kernel)
+        for (int c = 0; c < 3; c++) {
+            const T g = pgd[3 * k + c] + (ds[k] > 0 ? dl[3 * k + c] / ds[k] * pgr[k] : (T)0);
+            out[3 * row + c] += g;
+            out[3 * col + c] -= g;
+        }
+    }
+}
+
+class NeighborPairsHostFunction : public torch::autograd::Function<NeighborPairsHostFunction> {
+public:
+    static tensor_list forward(AutogradContext* ctx, const Tensor& positions, const torch::Scalar& cutoff,
+                               const torch::Scalar& max_num_pairs, const Tensor& box_vectors, bool checkErrors) {
+        // checks and messages of the reference's CPU kernel (getNeighborPairsCPU.cpp:25-53)
+        TORCH_CHECK(positions.dim() == 2, "Expected \"positions\" to have two dimensions");
+        TORCH_CHECK(positions.size(0) > 0, "Expected the 1nd dimension size of \"positions\" to be more than 0");
+        TORCH_CHECK(positions.size(1) == 3, "Expected the 2nd dimension size of \"positions\" to be 3");
+        TORCH_CHECK(positions.is_contiguous(), "Expected \"positions\" to be contiguous");
+        TORCH_CHECK(positions.scalar_type() == torch::kFloat32 || positions.scalar_type() == torch::kFloat64,
+                    "Expected \"positions\" to be float32 or float64");
+        const double c = cutoff.toDouble();
+        TORCH_CHECK(c > 0, "Expected \"cutoff\" to be positive");
+        Tensor box;
+        if (box_vectors.size(0) != 0) {
+            TORCH_CHECK(box_vectors.dim() == 2, "Expected \"box_vectors\" to have two dimensions");
+            TORCH_CHECK(box_vectors.size(0) == 3 && box_vectors.size(1) == 3, "Expected \"box_vectors\" to have shape (3, 3)");
+            const Tensor v64 = box_vectors.to(torch::kFloat64).contiguous();
+            const double* v = v64.data_ptr<double>();
+            TORCH_CHECK(v[1] == 0, "Invalid box vectors: box_vectors[0][1] != 0");
+            TORCH_CHECK(v[2] == 0, "Invalid box vectors: box_vectors[0][2] != 0");
+            TORCH_CHECK(v[5] == 0, "Invalid box vectors: box_vectors[1][2] != 0");
+            TORCH_CHECK(v[0] >= 2 * c, "Invalid box vectors: box_vectors[0][0] < 2*cutoff");
+            TORCH_CHECK(v[4] >= 2 * c, "Invalid box vectors: box_vectors[1][1] < 2*cutoff");
+            TORCH_CHECK(v[8] >= 2 * c, "Invalid box vectors: box_vectors[2][2] < 2*cutoff");
+            TORCH_CHECK(v[0] >= 2 * v[3], "Invalid box vectors: box_vectors[0][0] < 2*box_vectors[1][0]");
+            TORCH_CHECK(v[0] >= 2 * v[6], "Invalid box vectors: box_vectors[0][0] < 2*box_vectors[2][0]");
+            TORCH_CHECK(v[4] >= 2 * v[7], "Invalid box vectors: box_vectors[1][1] < 2*box_vectors[2][1]");
+            box = box_vectors;
+        }
+        const int64_t max_pairs = max_num_pairs.toLong();
+        TORCH_CHECK(max_pairs > 0 || max_pairs == -1, "Expected \"max_num_pairs\" to be positive or equal to -1");
+        Tensor neighbors, deltas, distances;
+        if (positions.scalar_type() == torch::kFloat64)
+            neighbor_pairs_host<double>(positions, box, c, max_pairs, checkErrors, neighbors, deltas, distances);
+        else
+            neighbor_pairs_host<float>(positions, box, c, max_pairs, checkErrors, neighbors, deltas, distances);
+        Tensor num_pairs = torch::empty({1}, positions.options().dtype(torch::kInt32));
+        num_pairs.data_ptr<int32_t>()[0] = (int32_t)distances.size(0);
+        ctx->save_for_backward({neighbors, deltas, distances});
+        ctx->saved_data["num_atoms"] = positions.size(0);
+        return {neighbors, deltas, distances, num_pairs};
+    }
+
+    static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor neighbors = saved[0], deltas = saved[1], distances = saved[2];
+        const int64_t num_atoms = ctx->saved_data["num_atoms"].toInt();
+        const Tensor gd = grad_outputs[1].defined() ? grad_outputs[1].contiguous() : torch::zeros_like(deltas);
+        const Tensor gr = grad_outputs[2].defined() ? grad_outputs[2].contiguous() : torch::zeros_like(distances);
+        Tensor gpos = torch::zeros({num_atoms, 3}, deltas.options());
+        if (deltas.scalar_type() == torch::kFloat64) neighbor_pairs_host_backward<double>(neighbors, deltas, distances, gd, gr, gpos);
+        else neighbor_pairs_host_backward<float>(neighbors, deltas, distances, gd, gr, gpos);
+        return {gpos, Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+TORCH_LIBRARY_IMPL(neighbors, AutogradCPU, m) {
+    m.impl("getNeighborPairs", [](const Tensor& positions, const torch::Scalar& cutoff, const torch::Scalar& max_num_pairs,
+                                  const Tensor& box_vectors, bool checkErrors) {
+        const tensor_list r = NeighborPairsHostFunction::apply(positions, cutoff, max_num_pairs, box_vectors, checkErrors);
+        return std::make_tuple(r[0], r[1], r[2], r[3]);
     });
 }
 

@@ -144,3 +144,48 @@ def test_gemm_row_maps():
     scattered = torch.zeros((500, 96), device=DEV)
     capi.gemm_split(a[pick.long()].contiguous(), planes, out=scattered, c_rows=pick)
     assert (scattered[pick.long()].double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+
+
+def _golden_case(golden_dir, k):
+    from nnpops_amd import workloads
+    g = np.load(f"{golden_dir}/batched_nn_ref.npz")
+    c = {name[len(f"c{k}_"):]: g[name] for name in g.files if name.startswith(f"c{k}_")}
+    model = workloads.torchani_like_model(n_models=int(c["n_models"]), seed=int(c["model_seed"]))
+    return c, model
+
+
+@pytest.mark.parametrize("layout", ["fused", "grouped", "reference"])
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_reference_batched_linear_goldens(golden_dir, k, layout):
+    """Energies and dE/dAEV produced by the REFERENCE's BatchedLinear CPU op (src/pytorch/BatchedNN.cpp:30-42) in the
+    reference's composition (BatchedNN.py:97-119), committed as tests/golden/batched_nn_ref.npz, against every layout of
+    TorchANIBatchedNN: the species-grouped split-fp16 GEMMs (default), the same grouping on the library GEMMs, and the
+    reference's per-atom replicated weights through torch.ops.NNPOpsBatchedNN.BatchedLinear."""
+    from nnpops_amd import workloads
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    c, model = _golden_case(golden_dir, k)
+    species = c["species"]
+    numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]])
+    nn = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers, layout=layout).to(DEV)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    aev = torch.tensor(c["aev"], device=DEV).requires_grad_(True)
+    energy = nn((sp, aev)).energies
+    energy.sum().backward()
+    scale = float(c["energy_scale"])
+    assert abs(float(energy) - float(c["energy"][0])) <= 1e-5 * scale, (float(energy), float(c["energy"][0]), scale)
+    gref = torch.tensor(c["aev_grad"], device=DEV)
+    assert float((aev.grad - gref).abs().max()) <= 1e-4 * float(gref.abs().max())
+
+
+def test_batched_linear_op_matches_reference_first_layer(golden_dir):
+    """torch.ops.NNPOpsBatchedNN.BatchedLinear itself (same schema as the reference's op) on the packed first layer."""
+    import NNPOps  # noqa: F401  (registers the op)
+    from nnpops_amd import workloads
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    c, model = _golden_case(golden_dir, 0)
+    numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in c["species"]]])
+    nn = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers, layout="reference").to(DEV)
+    v = torch.tensor(c["aev"], device=DEV).unsqueeze(-2).unsqueeze(-1)
+    y = torch.ops.NNPOpsBatchedNN.BatchedLinear(v, nn[0].layer0_weights, nn[0].layer0_biases)
+    ref = torch.tensor(c["first_layer_atom0"], device=DEV)
+    torch.testing.assert_close(y[0, 0, :, :, 0], ref, rtol=2e-5, atol=2e-5)

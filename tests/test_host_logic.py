@@ -75,3 +75,18 @@ def test_species_grouped_nn_equals_per_atom_evaluation_cpu():
     want = torch.stack([sum(model[int(s)](aev[b, i]).sum() for model in ensemble for i, s in enumerate(species)) / 3
                         for b in range(2)])
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_batched_nn_golden_weights_regenerate():
+    """tests/golden/batched_nn_ref.npz was produced by the reference's BatchedLinear CPU op on seeded networks that the GPU
+    tests rebuild from the seed: the rebuilt weights must be the ones the fixture was made with."""
+    import os
+    import numpy as np
+    from nnpops_amd import workloads
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "batched_nn_ref.npz"))
+    assert int(g["num_cases"]) == 3
+    for k in range(3):
+        model = workloads.torchani_like_model(n_models=int(g[f"c{k}_n_models"]), seed=int(g[f"c{k}_model_seed"]))
+        checksum = sum(float(p.detach().double().abs().sum()) for net in model.neural_networks for p in net.parameters())
+        assert abs(checksum - float(g[f"c{k}_weights_checksum"])) <= 1e-9 * checksum
+        assert g[f"c{k}_aev"].shape == (1, len(g[f"c{k}_species"]), 1008) and g[f"c{k}_aev_grad"].shape == g[f"c{k}_aev"].shape
