@@ -21,11 +21,11 @@ public:
             hipTry(hipMemcpy(h, dBox, sizeof(h), hipMemcpyDefault), "box");
             triclinic = h[1] != 0 || h[2] != 0 || h[3] != 0 || h[5] != 0 || h[6] != 0 || h[7] != 0;   // CpuCFConv.cpp:72-77
         }
-        for (;;) {
+        for (int attempt = 0;; attempt++) {                  // a capacity error grows the buffers: build again (bounded)
             abiTry(nnpops_cfconv_neighbors_build(handle, dPos, dBox));
             const int rc = nnpops_cfconv_neighbors_check(handle, nullptr);
             if (rc == NNPOPS_OK) break;
-            if (rc != NNPOPS_ERR_CAPACITY) abiTry(rc);
+            if (rc != NNPOPS_ERR_CAPACITY || attempt >= 8) abiTry(rc);
         }
     }
     bool getTriclinic() const override { return triclinic; }

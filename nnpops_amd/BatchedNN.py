@@ -200,7 +200,12 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         bound = torch.full((1,), 64.0, device=w0.device)
         for w, b in ((w0, self.layer0_biases), (w2, self.layer2_biases), (w4, self.layer4_biases)):
             bound = (w.abs().sum(-1).amax() * bound + b.abs().amax()).reshape(1)
-        self.fused_ok = bool(torch.isfinite(bound).all()) and float(bound) < 1.0e6
+        # the backward operands take the same planes: |d3| <= |w6|, |d2| <= |d3| ||W4||_1, |d1| <= |d2| ||W2||_1 (CELU' <= 1)
+        back = w6.abs().amax().reshape(1)
+        for w in (w4, w2):
+            back = (w.abs().sum(-2).amax() * back).reshape(1)
+        self.fused_ok = (bool(torch.isfinite(bound).all()) and float(bound) < 1.0e6
+                         and bool(torch.isfinite(back).all()) and float(back) < 1.0e6)
         self.packed_biases = torch.cat(biases).float().contiguous()
         self.last_w = torch.cat(last_w).float().contiguous()
         self.last_b = last_b

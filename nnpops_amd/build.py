@@ -24,8 +24,33 @@ def _sources():
     return [os.path.join(CSRC, u) for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
 
 
-def _stale():
+def source_hash():
+    """sha256 over every source of the library (file names and contents), first 16 hex digits: embedded in
+    nnpops_version() at build time and checked by capi.lib() at load time, so a binary older than its sources -- the
+    .so files are git-ignored but travel to the GPU box -- cannot be used silently."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))
+    files.append(os.path.join(HERE, "..", "include", "nnpops_hip.h"))
+    for f in files:
+        if os.path.basename(f) == "torch_binding.cpp":
+            continue
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
+    """The hash recorded inside the existing binary, or None."""
     if not os.path.exists(LIB):
+        return None
+    import re
+    m = re.search(rb"nnpops_hip [0-9.]+ gfx950 src:([0-9a-f]{16})", open(LIB, "rb").read())
+    return m.group(1).decode() if m else None
+
+
+def _stale():
+    if not os.path.exists(LIB) or built_hash() != source_hash():
         return True
     t = os.path.getmtime(LIB)
     deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + \
@@ -44,7 +69,7 @@ def build(force=False, verbose=False):
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f'-DNNPOPS_SOURCE_HASH="{source_hash()}"', "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -92,6 +92,12 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = restype
         fn.argtypes = argtypes
+    # the binary must have been built from the sources next to it (build.py embeds their hash in nnpops_version())
+    from . import build as _build
+    have, want = handle.nnpops_version().decode(), _build.source_hash()
+    if not have.endswith("src:" + want):
+        raise ImportError(f"{LIB_PATH} is stale: it reports '{have}' but the sources hash to {want}; "
+                          "rebuild with `python -m nnpops_amd.build`")
     _lib = handle
     return _lib
 

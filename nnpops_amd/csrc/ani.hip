@@ -65,7 +65,6 @@ struct nnpops_ani {
     int tile = 32;                  // pair-matrix edge of the angular backward kernel (<= 32, sized in check())
     bool compact_bwd = false;       // check() saw no atom with more than `tile` angular neighbours: compact LDS layout
     bool computed = false;
-    int debug = 0;                  // kernel ablation bits from $NNPOPS_ANI_DEBUG (timing experiments only)
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
     int ld_radial = 0, ld_angular = 0;   // row strides (floats) of the AEV / gradient arrays of the call in progress
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
@@ -209,7 +208,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         auto k = h->chunked_forward ? ani_angular_forward_chunked<TA, NFRP, NFZP> : ani_angular_forward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB,
-                           h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, h->debug, lds_wave);
+                           h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, lds_wave);
     } else if (h->backward_kernel >= 1 && ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, true) <= 160 * 1024) {
         // backward_kernel: 1 = one wave per atom, every triple reads its gradient block through the L1 (needs the 16-byte
         // layout); 2 = one wave, gradient row staged in LDS; 3 / 4 = the same two with two waves per atom (A/B only)
@@ -232,7 +231,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
         hipLaunchKernelGGL(k, grid, block, lds_group, h->stream, h->d_params, h->cap, h->cap_angular, h->tile, h->d_recA,
-                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, h->debug,
+                           h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force,
                            lds_wave, (int)h->compact_bwd);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
@@ -340,7 +339,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_APG")) h->fwd_atoms_per_group = std::max(1, std::atoi(e));
     }
     h->device = device;
-    if (const char* e = std::getenv("NNPOPS_ANI_DEBUG")) h->debug = std::atoi(e);
     h->cap = 128;
     h->cap_angular = 32;
 
@@ -505,11 +503,11 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
         if (per)
             hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist, h->debug);
+                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist);
         else
             hipLaunchKernelGGL(ani_neighbors_cells<false>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
                                h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist, h->debug);
+                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist);
     } else if (per)
         hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
                            h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
@@ -580,7 +578,10 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
     // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
     h->tile = std::min(32, std::max(8, st[kStatMaxAngular]));      // exact: every row of LDS saved is occupancy
-    h->compact_bwd = st[kStatMaxAngular] <= h->tile && h->tile >= 16;     // (tiny tiles: nothing to gain, and the fallback needs room)
+    // (tiny tiles: nothing to gain; and the fallback of an atom that outgrows the tile needs the per-slot accumulators plus a
+    //  2 x 2 pair block inside the matrix region)
+    h->compact_bwd = st[kStatMaxAngular] <= h->tile && h->tile >= 16 &&
+                     h->tile * (h->tile + 1) + h->tile * (h->tile - 1) / 2 >= h->cap_angular * 4 + 12;
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
     if (st[kStatOverflow] & 4) {          // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins

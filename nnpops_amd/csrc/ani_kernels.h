@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
                                                           int* __restrict__ status, float* __restrict__ radial,
-                                                          int ld_radial, int lds_per_wave, int* __restrict__ cell_hist, int dbg) {
+                                                          int ld_radial, int lds_per_wave, int* __restrict__ cell_hist) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     // (stencil_slot reads other lanes' registers: every lane calls it, out-of-range lanes with a clamped index)
     const int last = max(st.total - 1, 0);
     float4 pj = sorted_pos[stencil_slot(st, min(lane, last))];
-    for (int base = 0; base < ((dbg & 256) ? 0 : st.total); base += 64) {
+    for (int base = 0; base < st.total; base += 64) {
         const int k = base + lane;
         const float4 cur = pj;
         const int next_slot = stencil_slot(st, min(k + 64, last));
@@ -486,8 +486,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
     flush_row(row, stage, cap, na, nro);
-    if (!(dbg & 64)) radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);
-    if (dbg & 128) return;
+    radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
                      tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G);
 }
@@ -717,13 +716,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
                                                           const int* __restrict__ tri_g,
                                                           const int* __restrict__ cnt_a,
                                                           const int* __restrict__ cnt_ro,
-                                                          float* __restrict__ angular, int ld_angular, int dbg, int lds_per_wave) {
+                                                          float* __restrict__ angular, int ld_angular, int lds_per_wave) {
     using L = FwdLayout<NFRP, NFZP>;
     constexpr int CH = L::CH, NSTREAM = L::NSTREAM, SR = L::SR, BLK = L::BLK;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int i = wave_global_id(), lane = lane_id();
     const int NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
-    if (i >= P->N || (dbg & 32)) return;                   // (dbg & 32: ablation, launch + dispatch floor)
+    if (i >= P->N) return;
 
     char* cursor = lds_raw + (size_t)wave_in_group() * lds_per_wave;
     float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
@@ -741,7 +740,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
     load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
     const int rowlen = NB * BLK;
     for (int q = lane; q < rowlen; q += 64) row[q] = 0.f;
-    if (dbg & 16) return;                                  // ablation: prologue only
 
     // per-lane constants of the two factor families
     float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP];
@@ -761,7 +759,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
         const int t = base + lane;
         const int next_word = (t + 64 < T) ? tri[t + 64] : 0;     // prefetch the next batch
         int bucket = -1;
-        if (t < T && !(dbg & 1)) {
+        if (t < T) {
             const int p = word & 0xff, q = (word >> 8) & 0xff;
             bucket = word >> 16;
             const float4 A = recA[p], B = recA[q];
@@ -795,8 +793,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
         wave_fence();
         // ---------------- phase 2: lane = (stream, a) ----------------
         const float* srcR = facR + stream * SR + a2;
-        if (dbg & 2) {
-        } else if (uniform) {
+        if (uniform) {
             float acc[NFZP];
 #pragma unroll
             for (int z = 0; z < NFZP; z++) acc[z] = 0.f;
@@ -918,7 +915,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward(const
 
     // ---------------- epilogue: canonical LDS row -> reference column order, coalesced rows ----------------
     float* out = angular + (size_t)i * ld_angular;
-    if (dbg & 4) return;
     if (nA <= 32) {                                        // two buckets per pass
         const int m = lane & 31, half = lane >> 5;
         const bool live = m < nA;
@@ -969,13 +965,13 @@ template <bool TORCHANI, int NFRP, int NFZP>
 __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunked(
     const AniParams* __restrict__ P, int cap, int capA, const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
     const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro, float* __restrict__ angular,
-    int ld_angular, int dbg, int lds_per_wave) {
+    int ld_angular, int lds_per_wave) {
     using L = FwdLayout<NFRP, NFZP>;
     constexpr int CH = L::CH, NSTREAM = L::NSTREAM, SR = L::SR, BLK = L::BLK;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int i = wave_global_id(), lane = lane_id();
     const int NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
-    if (i >= P->N || (dbg & 32)) return;
+    if (i >= P->N) return;
 
     char* cursor = lds_raw + (size_t)wave_in_group() * lds_per_wave;
     float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
@@ -1008,7 +1004,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunk
     if (lane <= NB) { boff[lane] = my_lo; cstart[lane] = my_first; }
     for (int c = 0; c < my_chunks; c++) cbkt[my_first + c] = lane;        // (lanes >= NB have no chunks)
     const int chunks = __shfl(incl, 63, 64);
-    if (dbg & 16) return;
 
     float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP];
 #pragma unroll
@@ -1036,7 +1031,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunk
         const int t_next = triple_of(cb + NSTREAM + lane / CH, lane % CH);
         const int next_word = t_next >= 0 ? tri[t_next] : 0;              // next batch in flight
         float* dstR = facR + (lane / CH) * SR + (lane % CH) * NFRP;
-        if (t_mine >= 0 && !(dbg & 1)) {
+        if (t_mine >= 0) {
             const int p = word & 0xff, q = (word >> 8) & 0xff;
             const float4 A = recA[p], B = recA[q];
             const float4 A2 = recB[p], B2 = recB[q];
@@ -1071,7 +1066,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunk
         t_mine = t_next;
         wave_fence();
         // ---------------- phase 2: lane = (stream, a), one bucket per stream ----------------
-        if (!(dbg & 2)) {
+        {
             const int chunk = cb + stream;
             const int bs = chunk < chunks ? cbkt[chunk] : -1;
             const float* srcR = facR + stream * SR + a2;
@@ -1108,7 +1103,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_forward_chunk
 
     // ---------------- epilogue: canonical LDS row -> reference column order, coalesced rows ----------------
     float* out = angular + (size_t)i * ld_angular;
-    if (dbg & 4) return;
     if (nA <= 32) {                                        // two buckets per pass
         const int m = lane & 31, half = lane >> 5;
         const bool live = m < nA;
@@ -1230,7 +1224,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
                                                            const float* __restrict__ angular_grad, int ld_angular,
                                                            float4* __restrict__ leg_force,      // [N][capA]
                                                            float4* __restrict__ centre_force,   // [N]
-                                                           int dbg, int lds_per_wave, int compact) {
+                                                           int lds_per_wave, int compact) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int i = wave_global_id(), lane = lane_id();
     const int S = P->S, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
@@ -1250,7 +1244,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
 
     int n, nro;
     clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
-    if (n < 2 || (dbg & 32)) {                             // no triples (wave-uniform): a lone leg carries no force
+    if (n < 2) {                             // no triples (wave-uniform): a lone leg carries no force
         if (n == 1 && lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
@@ -1292,7 +1286,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     if (!compact)                                          // (only the tile-pair fallback accumulates into facc)
         for (int q = lane; q < n * 4; q += 64) facc[q] = 0.f;
     load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
-    if (dbg & 16) return;                                  // ablation: prologue only
 
     float frc[NFRP], frs[NFRP], fre[NFRP], zz[NFZP], zc[NFZP], zs[NFZP];
 #pragma unroll
@@ -1312,7 +1305,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     float* fsum = facc;                                    // where the per-slot forces end up
     if (n <= tile) {
         // ---------------- common case: one tile, triples from the builder's list ----------------
-        for (int base = 0; base < T && !(dbg & 1); base += 64) {
+        for (int base = 0; base < T; base += 64) {
             const int t = base + lane;
             const int next_word = (t + 64 < T) ? tri[t + 64] : 0;
             if (t < T) {
@@ -1331,7 +1324,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
         //   F_e = (sum_x alpha[e][x]) * A_e + sum_x beta{e,x} * A_x
         const int e = lane & 31, half = lane >> 5;
         float fx = 0.f, fy = 0.f, fz = 0.f, as = 0.f;
-        if (e < n && !(dbg & 2)) {
+        if (e < n) {
             const int x0 = half * 16, x1 = min(n, x0 + 16);
             const float* ma = Ma + e * tstride;
             // index of beta{e,x} in the triangle: x < e: x(2T-x-1)/2 + e-x-1 (grows by T-x-2 per step), x > e: base_e + x-e-1
@@ -1426,7 +1419,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_angular_backward(cons
     // No scatter: the force on leg e of this atom is parked in leg_force[i][e] (record order) and the reaction
     // on the centre in centre_force[i]; ani_radial_backward_gather, which owns position_deriv[j], picks the
     // legs up from the other side.  No atomics, bitwise reproducible forces.
-    if (dbg & 4) return;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     float4* out = leg_force + (size_t)i * capA;
     for (int e = lane; e < n; e += 64) {

@@ -12,7 +12,12 @@ extern "C" {
 
 const char* nnpops_last_error(void) { return nnpops::last_error_slot().c_str(); }
 
-const char* nnpops_version(void) { return "nnpops_hip 0.1.0 gfx950"; }
+// NNPOPS_SOURCE_HASH: sha256 (first 16 hex digits) of the sources this binary was compiled from, passed by
+// nnpops_amd/build.py; the Python loader recomputes it from the tree and refuses a stale binary.
+#ifndef NNPOPS_SOURCE_HASH
+#define NNPOPS_SOURCE_HASH "unknown"
+#endif
+const char* nnpops_version(void) { return "nnpops_hip 0.2.0 gfx950 src:" NNPOPS_SOURCE_HASH; }
 
 int nnpops_device_count(void) {
     int n = 0;

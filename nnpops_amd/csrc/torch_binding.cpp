@@ -33,6 +33,13 @@
 
 #include "../../include/nnpops_hip.h"
 
+// hash of the sources this binding was compiled from (torch_binding.py embeds it and refuses a stale binary)
+#ifndef NNPOPS_BINDING_HASH
+#define NNPOPS_BINDING_HASH "unknown"
+#endif
+extern "C" __attribute__((used, visibility("default"))) const char nnpops_torch_binding_version[] =
+    "nnpops_torch_binding src:" NNPOPS_BINDING_HASH;
+
 namespace {
 
 using torch::Tensor;
@@ -575,6 +582,10 @@ public:
             box = box_vectors.to(positions.options()).contiguous();
         }
         const int64_t num_atoms = positions.size(0);
+        // (argument limits of the C ABI, checked before anything is allocated)
+        TORCH_CHECK(num_atoms <= std::numeric_limits<int32_t>::max(), "Too many atoms for getNeighborPairs");
+        TORCH_CHECK(max_pairs != -1 || num_atoms <= 65536,
+                    "max_num_pairs == -1 needs one slot per pair; beyond 65536 atoms use a compacted list");
         const int64_t slots = max_pairs == -1 ? num_atoms * (num_atoms - 1) / 2 : max_pairs;
         const auto options = positions.options();
         Tensor neighbors = torch::empty({2, slots}, options.dtype(torch::kInt32));

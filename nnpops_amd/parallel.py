@@ -12,15 +12,17 @@ import torch
 
 def shard_molecules(sizes: Sequence[int], world: int) -> List[Tuple[int, int]]:
     """Contiguous blocks of molecule indices, one per rank, balanced by atom count (the cost of an
-    AEV evaluation is linear in atoms at fixed density).  Returns [(lo, hi)] * world; blocks may be
-    empty only when there are fewer molecules than ranks."""
+    AEV evaluation is linear in atoms at fixed density).  Returns [(lo, hi)] * world.  Every rank gets at
+    least one molecule while there are enough of them (so one very large molecule at the end cannot starve
+    the ranks before it); blocks are empty only when there are fewer molecules than ranks."""
     total = float(sum(sizes))
     bounds, acc, lo = [], 0.0, 0
     n = len(sizes)
     for r in range(world):
         target = total * (r + 1) / world
         hi = lo
-        while hi < n and (acc + sizes[hi] <= target + 1e-9 or hi == lo and n - hi >= world - r):
+        # take molecules up to this rank's share of the atoms, at least one, and never so many that a later rank starves
+        while hi < n and n - hi - 1 >= world - r - 1 and (acc + sizes[hi] <= target + 1e-9 or hi == lo):
             acc += sizes[hi]
             hi += 1
         if r == world - 1:

@@ -22,12 +22,24 @@ LIB = os.path.join(HERE, "libNNPOpsPyTorch.so")
 _loaded = False
 
 
-def _stale():
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in (SRC, os.path.join(HERE, "..", "include", "nnpops_hip.h")):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
     if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [SRC, os.path.join(HERE, "..", "include", "nnpops_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+        return None
+    import re
+    m = re.search(rb"nnpops_torch_binding src:([0-9a-f]{16})", open(LIB, "rb").read())
+    return m.group(1).decode() if m else None
+
+
+def _stale():
+    return built_hash() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -38,7 +50,7 @@ def build(force=False, verbose=False):
     torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-w",
            "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
-           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f'-DNNPOPS_BINDING_HASH="{source_hash()}"']
     for inc in cpp_extension.include_paths(False) + ["/opt/rocm/include"]:
         cmd += ["-isystem", inc]
     cmd += [SRC, "-o", LIB, f"-L{HERE}", "-lnnpops_hip", f"-L{torch_lib}", "-ltorch", "-ltorch_cpu", "-lc10",
@@ -57,6 +69,9 @@ def load():
         return
     if not os.path.exists(LIB):
         raise ImportError(f"{LIB} is missing: build it with `python -m nnpops_amd.torch_binding`")
+    if built_hash() != source_hash():
+        raise ImportError(f"{LIB} is stale (built from other sources than the ones next to it): rebuild with "
+                          "`python -m nnpops_amd.torch_binding`")
     torch.ops.load_library(LIB)
     _loaded = True
 

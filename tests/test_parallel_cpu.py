@@ -53,3 +53,13 @@ def test_gather_rows_gloo_world2(tmp_path):
     expect = torch.arange(sum(sizes), dtype=torch.float32).unsqueeze(1).repeat(1, 3)
     for rank in range(2):
         assert torch.equal(torch.load(tmp_path / f"full_{rank}.pt"), expect)
+
+
+def test_shard_molecules_never_starves_a_rank():
+    """One huge molecule at the end used to leave the ranks before it empty (round-1 advisor finding)."""
+    blocks = shard_molecules([1, 1, 1, 100], 4)
+    assert blocks == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    for sizes, world in (([5] * 9, 8), ([100, 1, 1, 1, 1], 3), ([3, 50, 2, 2, 60, 1], 4)):
+        blocks = shard_molecules(sizes, world)
+        assert blocks[0][0] == 0 and blocks[-1][1] == len(sizes) and all(hi > lo for lo, hi in blocks)
+        assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
