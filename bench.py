@@ -72,6 +72,19 @@ def _ani_eval_seconds(cls, pos, species, box, rf, af, repeats=1):
     return best
 
 
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask, capped by the cgroup CPU quota when there is one
+    (os.cpu_count() reports the machine, not the container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_worker_main(argv):
     """`bench.py --cpu-worker N_ATOMS SEED`: one forward+backward of the reference CPU path on this core; prints the
     seconds.  Started nproc times in parallel by cpu_baseline() for the 'all cores' figure (no torch import here)."""
@@ -98,12 +111,12 @@ def cpu_baseline(pos, species, box, rf, af, budget_s=12.0, all_cores=True):
             break
     out = {"value": evals / t_total, "unit": "evals/s", "cores": 1, "kind": kind,
            "sample": f"{evals} fwd+bwd evaluation(s) of the same {n}-atom ANI-2x periodic frame, single thread "
-                     f"({t_total:.1f} s; host has {os.cpu_count()} cores, the reference CPU path is serial)"}
+                     f"({t_total:.1f} s; {usable_cores()} usable cores of {os.cpu_count()} on the host, the reference CPU path is serial)"}
     if all_cores:
         # One process per core, each evaluating its own frame, all started together.  Frames of 4000 atoms keep this leg
         # to seconds (the reference is O(N^2)); the measured parallel speed-up over one core on the same frame size is
         # applied to the single-core figure above.
-        ncpu, m = os.cpu_count() or 1, 4000
+        ncpu, m = usable_cores(), 4000
         from nnpops_amd import workloads
         p1, s1, b1 = workloads.random_box(m, density=0.1, seed=999, n_species=7)
         t_single = _ani_eval_seconds(cls, p1, s1, b1, rf, af)

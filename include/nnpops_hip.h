@@ -61,8 +61,10 @@ typedef struct nnpops_ani* nnpops_ani_t;
  * atom_species:             host, [num_atoms], values in [0, num_species)
  * periodic / torchani:      as the reference constructor flags
  * device:                   HIP device ordinal the handle lives on
- * The angular set must factor as {(eta,rs)} x {(zeta,thetas)} (every set the reference's torch
- * binding can build does: SymmetryFunctions.cpp:115-120); otherwise NNPOPS_ERR_UNSUPPORTED. */
+ * Any list of angular functions is accepted, like the reference core (CpuANISymmetryFunctions.cpp:153-194).  A list that
+ * is a full grid {(eta,rs)} x {(zeta,thetas)} of at most 16 x 8 distinct factors -- every set the reference's torch binding
+ * can build (SymmetryFunctions.cpp:115-120), ANI-1x/1ccx/2x included -- runs on the factored matrix-core kernels; any other
+ * list runs on generic kernels (same results, several times slower). */
 int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float radial_cutoff, float angular_cutoff,
                       int periodic, const int32_t* atom_species, int num_radial, const float* radial_eta_rs,
                       int num_angular, const float* angular_eta_rs_zeta_ths, int torchani, int device);

@@ -25,6 +25,8 @@ class TorchANISymmetryFunctions(torch.nn.Module):
         atomicNumbers: tensor of atomic numbers, shape [1, num_atoms]
     """
 
+    __jit_ignored_attributes__ = ["_ctor", "_species", "_batch_holders"]      # host-side state of forward_batch
+
     def __init__(self, converter, symmFunc, atomicNumbers: Tensor) -> None:
         super().__init__()
         self.num_species = int(symmFunc.num_species)
@@ -39,6 +41,11 @@ class TorchANISymmetryFunctions(torch.nn.Module):
             self.num_species, float(symmFunc.Rcr), float(symmFunc.Rca), lists["EtaR"], lists["ShfR"], lists["EtaA"],
             lists["Zeta"], lists["ShfA"], lists["ShfZ"], [int(s) for s in species])
         self.triu_index = torch.tensor([0])      # kept for TorchScript compatibility with torchani.AEVComputer users
+        # what an additive batched evaluation needs to build its own holder (forward_batch)
+        self._ctor = (self.num_species, float(symmFunc.Rcr), float(symmFunc.Rca), lists["EtaR"], lists["ShfR"], lists["EtaA"],
+                      lists["Zeta"], lists["ShfA"], lists["ShfZ"])
+        self._species = [int(s) for s in species]
+        self._batch_holders = {}
 
     @torch.jit.export
     def set_check_interval(self, interval: int) -> None:
@@ -46,6 +53,25 @@ class TorchANISymmetryFunctions(torch.nn.Module):
         instead of every call; 0 = only on the first.  Between checks an overflow goes unnoticed, exactly as inside a
         captured graph -- for production loops at known density (cf. ``check_errors`` of ``getNeighborPairs``)."""
         self.holder.set_check_interval(interval)
+
+    @torch.jit.unused
+    def forward_batch(self, species_positions: Tuple[Tensor, Tensor]) -> Tuple[Tensor, Tensor]:
+        """Extension (the reference rejects batches, SymmetryFunctions.py:110): B conformers of THE molecule this module was
+        built for, non-periodic.  (species[B, N], positions[B, N, 3]) -> (species, aev[B, N, W]), differentiable w.r.t.
+        positions.  All B x N atoms are evaluated by ONE batched holder (molecule offsets 0, N, 2N, ...; atoms of different
+        conformers never interact) in one launch sequence -- not B launches of a one-molecule holder."""
+        species, positions = species_positions
+        if positions.dim() != 3 or positions.shape[1] != len(self._species) or positions.shape[2] != 3:
+            raise ValueError(f'"positions" has to have the shape [batch, {len(self._species)}, 3]')
+        batch = int(positions.shape[0])
+        holder = self._batch_holders.get(batch)
+        if holder is None:
+            holder = torch.classes.NNPOpsANISymmetryFunctions.Holder(*self._ctor, self._species * batch)
+            holder.set_molecules([k * len(self._species) for k in range(batch + 1)])
+            self._batch_holders[batch] = holder
+        flat = positions.reshape(batch * len(self._species), 3)
+        features = torch.ops.NNPOpsANISymmetryFunctions.aev(holder, flat, None)
+        return species, features.reshape(batch, len(self._species), -1)
 
     def forward(self, species_positions: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
                 pbc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:

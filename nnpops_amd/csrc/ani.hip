@@ -12,6 +12,7 @@
 #include "ani_kernels.h"
 #include "ani_angular_mfma.h"
 #include "ani_angular_bwd.h"
+#include "ani_angular_generic.h"
 #include "host_common.h"
 
 using namespace nnpops;
@@ -36,6 +37,7 @@ struct nnpops_ani {
     int* d_bucket_offsets = nullptr; // [N][NB + 1] first triple of every bucket (chunked forward view)
     bool chunked_forward = true;
     int forward_kernel = 2;         // 2: matrix-core scatter (ani_angular_mfma.h), 1: chunked view, 0: run merging
+    bool generic = false;           // the angular functions do not factor (or have too many factors): generic kernels
     bool mfma_ok = false;           // at most 32 species pairs can occur in this system
     bool fwd_identity = false;      // angular function m sits at canonical slot m: 16-byte stores of the row
     int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel
@@ -129,15 +131,12 @@ int factor_angular(AniParams& hp, const float* af, int nA) {
         iz[m] = (int)q;
     }
     const int nFR = (int)fr.size(), nFZ = (int)fz.size();
-    if (nFR * nFZ != nA || nFR > kMaxFactor || nFZ > kMaxFactor)
-        return fail(NNPOPS_ERR_UNSUPPORTED,
-                    "angular functions must factor as {(eta,rs)} x {(zeta,thetas)} with at most %d factors each "
-                    "(got %d x %d for %d functions)", kMaxFactor, nFR, nFZ, nA);
+    if (nFR * nFZ != nA || nFR > kMaxFactor || nFZ > 8) return 1;      // not a (small enough) full grid: generic kernels
     std::vector<int> seen(nA, -1);
     const int nfzp = pad_pow2(nFZ, 4);
     for (int m = 0; m < nA; m++) {
         const int c = ia[m] * nFZ + iz[m];
-        if (seen[c] >= 0) return fail(NNPOPS_ERR_UNSUPPORTED, "duplicate angular function %d", m);
+        if (seen[c] >= 0) return 1;                            // a duplicated function: not a grid either
         seen[c] = m;
         hp.c_of_m[m] = ia[m] * nfzp + iz[m];
         hp.scale_m[m] = powf(2.0f, 1.0f - af[4 * m + 2]);
@@ -253,8 +252,29 @@ int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out) {
     }
 }
 
+template <bool TA>
+int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out) {
+    const int N = h->hp.N;
+    if (forward) {
+        const int lw = (int)((ang_fwd_generic_lds_bytes(h->cap_angular) + 15) & ~(size_t)15);
+        const int wpg = waves_per_group(lw);
+        hipLaunchKernelGGL(ani_angular_forward_generic<TA>, dim3(div_up(N, wpg)), dim3(64 * wpg), (size_t)lw * wpg, h->stream, h->d_params,
+                           h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, lw);
+    } else {
+        const size_t lb = (ang_bwd_pair_lds_bytes<4, 4>(h->cap_angular, h->hp.NB, false) + 15) & ~(size_t)15;
+        if (lb > 160 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "generic angular backward needs %zu bytes of LDS (cap_angular %d)", lb, h->cap_angular);
+        auto k = ani_angular_backward_pair<TA, 4, 4, 4, 1, false, true>;
+        if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, N, h->hp.NB);
+    }
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
 int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out) {
     KernelTimer timer(h, forward ? NNPOPS_ANI_K_ANGULAR_FWD : NNPOPS_ANI_K_ANGULAR_BWD);
+    if (h->generic) return h->hp.torchani ? launch_generic<true>(h, forward, g, out) : launch_generic<false>(h, forward, g, out);
     return h->hp.torchani ? dispatch_factors<true>(h, forward, g, out) : dispatch_factors<false>(h, forward, g, out);
 }
 
@@ -299,11 +319,22 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     }
     for (int a = 0, bk = 0; a < num_species; a++)
         for (int b = a; b < num_species; b++, bk++) { hp.bkt_a[bk] = a; hp.bkt_b[bk] = b; }
+    for (int m = 0; m < num_angular; m++) {                    // the list as given, for the generic kernels
+        const float* f = angular_eta_rs_zeta_ths + 4 * m;
+        hp.af_eta[m] = f[0]; hp.af_rs[m] = f[1]; hp.af_zeta[m] = f[2];
+        hp.af_c[m] = -f[0] * kLog2e;
+        hp.af_cos[m] = (float)std::cos((double)f[3]);
+        hp.af_sin[m] = (float)std::sin((double)f[3]);
+    }
     int rc = factor_angular(hp, angular_eta_rs_zeta_ths, num_angular);
-    if (rc != NNPOPS_OK) { delete h; return rc; }
+    h->generic = rc != NNPOPS_OK;
+    if (h->generic) {                                          // (factor fields are not used; keep them harmless)
+        hp.nFR = hp.nFZ = 1;
+        for (int m = 0; m < num_angular; m++) { hp.c_of_m[m] = 0; hp.scale_m[m] = 1.f; }
+    }
+    if (const char* e = std::getenv("NNPOPS_ANI_GENERIC")) h->generic = h->generic || std::atoi(e) != 0;      // tests: force
     h->nfrp = pad_pow2(hp.nFR, 4);
     h->nfzp = pad_pow2(hp.nFZ, 4);
-    if (h->nfzp > 8) { delete h; return fail(NNPOPS_ERR_UNSUPPORTED, "more than 8 (zeta,thetas) factors (%d) not built", hp.nFZ); }
     // Matrix-core forward kernel: quads are handed the species pairs that can occur among this system's atoms.
     {
         std::vector<char> present(num_species, 0);

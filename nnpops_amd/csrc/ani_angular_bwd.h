@@ -21,6 +21,7 @@
 //     since the last check() is handled like any other), and the row sums split the columns in two equal halves.
 #pragma once
 
+#include "ani_angular_generic.h"
 #include "ani_angular_mfma.h"
 
 namespace nnpops {
@@ -103,7 +104,9 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
            ((size_t)capA * (capA + 1) + (size_t)capA * (capA - 1) / 2) * sizeof(float);
 }
 
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS>
+// GENERIC: the function list does not factor (ani_angular_generic.h): functions evaluated one by one, gradients read from
+// global memory in the caller's order (GLDS must be false, NFRP / NFZP are not used).
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false>
 __global__ __launch_bounds__(64 * WPA, OCC) void ani_angular_backward_pair(
     const AniParams* __restrict__ P, int cap, int capA, const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
     const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(64 * WPA, OCC) void ani_angular_backward_pair(
     float* Ma = (float*)cursor;           // alpha[tile][tile + 1]: Ma[e][x] = coefficient of A_e in the force of triple {e, x} on e
     float* Mb = Ma + tile * tstride;      // beta, once per unordered pair (p < q), triangular
 
+    static_assert(!(GENERIC && GLDS), "generic function lists read their gradients from global memory");
     float frc[NFRP], frs[NFRP], fren[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];
 #pragma unroll
     for (int a = 0; a < NFRP; a++) {
@@ -184,9 +188,13 @@ __global__ __launch_bounds__(64 * WPA, OCC) void ani_angular_backward_pair(
             if (t < T) {
                 const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;
                 float ap, aq, bt;
-                const float* Gb = GLDS ? grow + bucket * BLK : g + bucket * BLK;
-                triple_forces_pk<TORCHANI, NFRP, NFZP>(recA[p], recB[p], recA[q], recB[q], Gb, frc, frs, fren,
-                                                       zz, zc, zs, zb, ap, aq, bt);
+                if constexpr (GENERIC) {
+                    triple_forces_generic<TORCHANI>(P, nA, recA[p], recB[p], recA[q], recB[q], g + bucket * nA, ap, aq, bt);
+                } else {
+                    const float* Gb = GLDS ? grow + bucket * BLK : g + bucket * BLK;
+                    triple_forces_pk<TORCHANI, NFRP, NFZP>(recA[p], recB[p], recA[q], recB[q], Gb, frc, frs, fren,
+                                                           zz, zc, zs, zb, ap, aq, bt);
+                }
                 Ma[p * tstride + q] = ap;
                 Ma[q * tstride + p] = aq;
                 Mb[p * (2 * tile - p - 1) / 2 + (q - p - 1)] = bt;            // p < q: once per unordered pair

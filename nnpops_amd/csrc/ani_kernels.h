@@ -68,6 +68,13 @@ struct AniParams {
     int c_of_m[kMaxAngularFns];      // function m -> slot a*NFZP+z inside a padded canonical bucket block
     int bkt_a[kMaxBuckets];          // bucket b -> its species pair (A <= B), upper-triangular row-major
     int bkt_b[kMaxBuckets];          //                                                          ref :39-43
+    // the angular functions as given (generic kernels for sets that do not factor; function m of the caller's list)
+    float af_c[kMaxAngularFns];      // -eta_m * log2(e)
+    float af_eta[kMaxAngularFns];
+    float af_rs[kMaxAngularFns];
+    float af_zeta[kMaxAngularFns];
+    float af_cos[kMaxAngularFns];    // cos(thetas_m)
+    float af_sin[kMaxAngularFns];    // sin(thetas_m)
     int* bucket_offsets;             // [N][NB + 1] device array the builders fill: offsets of the buckets in an atom's triple list
     // matrix-core forward kernel (ani_angular_mfma.h)
     int m_of_c[kMaxAngularFns];      // canonical slot a*NFZP+z -> function m, -1 for padding slots

@@ -97,6 +97,17 @@ public:
         checkInterval = interval;
     }
 
+    // Additive (the reference has no batch dimension, SymmetryFunctions.py:110): the atoms of this Holder
+    // are `offsets.size() - 1` independent NON-PERIODIC molecules, molecule m = atoms [offsets[m], offsets[m+1]); atoms of
+    // different molecules never see each other, forward/backward evaluate the whole batch in one launch sequence
+    // (nnpops_ani_set_molecules).  An empty list restores the single-system behaviour.
+    void setMolecules(const std::vector<int64_t>& offsets) {
+        if (!offsets.empty() && (offsets.front() != 0 || offsets.back() != (int64_t)atomSpecies.size()))
+            throw std::runtime_error("molecule offsets have to start at 0 and end at the number of atoms");
+        moleculeOffsets = offsets;
+        if (impl) applyMolecules();
+    }
+
     tensor_list forward(const Tensor& positions, const c10::optional<Tensor>& cellOpt) { return forwardImpl(positions, cellOpt, false); }
 
     // fused = true: ONE output, aev [N, S*nR + S(S+1)/2*nA] = (radial | angular) per row -- what TorchANI's AEVComputer
@@ -140,6 +151,7 @@ public:
                 raise_last("NNPOpsANISymmetryFunctions");
             numRadial = (int64_t)(radial.size() / 2);
             numAngular = (int64_t)(angular.size() / 4);
+            if (!moleculeOffsets.empty()) applyMolecules();
         }
         if (positions.device() != device) throw std::runtime_error("The device of \"positions\" has changed");
         if (periodic && !cellOpt) throw std::runtime_error("\"cell\" is required: this Holder was first used with periodic box vectors");
@@ -244,10 +256,17 @@ public:
     }
 
 private:
+    void applyMolecules() {
+        std::vector<int32_t> off(moleculeOffsets.begin(), moleculeOffsets.end());
+        if (nnpops_ani_set_molecules(impl, off.empty() ? 0 : (int)off.size() - 1, off.empty() ? nullptr : off.data()) != NNPOPS_OK)
+            raise_last("NNPOpsANISymmetryFunctions::set_molecules");
+    }
+
     int64_t numSpecies;
     double Rcr, Rca;
     std::vector<double> EtaR, ShfR, EtaA, Zeta, ShfA, ShfZ;
     std::vector<int64_t> atomSpecies;
+    std::vector<int64_t> moleculeOffsets;   // additive: batched molecules (setMolecules)
     torch::Device device = torch::kCPU;
     bool periodic = false;
     int64_t numRadial = 0, numAngular = 0;
@@ -302,6 +321,7 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
         .def("forward", &Holder::forward)
         .def("backward", &Holder::backward)
         .def("set_check_interval", &Holder::setCheckInterval)
+        .def("set_molecules", &Holder::setMolecules)
         .def_pickle([](const HolderPtr& self) -> std::string { return Holder::serialize(self); },
                     [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
     m.def("operation", operation);

@@ -11,6 +11,6 @@ shipped.  ``nnpops_amd`` must not import it (tests/test_layout.py enforces that)
     from oracle import AniOracle, CFConvOracle, CFConvNeighborsOracle, neighbor_pairs_oracle
     from oracle import have_ref, RefAni, RefCFConv, RefCFConvNeighbors
 """
-from .bindings import (AniOracle, CFConvNeighborsOracle, CFConvOracle, RefAni, RefCFConv,  # noqa: F401
+from .bindings import (AniOracle, AniOracle64, CFConvNeighborsOracle, CFConvOracle, RefAni, RefCFConv,  # noqa: F401
                        RefCFConvNeighbors, build_oracle, have_ref, oracle_lib_path, ref_lib_path)
 from .neighbors_oracle import neighbor_pairs_oracle, neighbor_pairs_backward_oracle  # noqa: F401

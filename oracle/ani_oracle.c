@@ -30,21 +30,51 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Precision of the restatement.  The default, float with the float maths functions, is the reference's arithmetic and the
+ * build every parity test and the CPU baseline use (bit-for-bit equal to oracle/_ref).  -DORACLE_DOUBLE builds the same
+ * algorithm in double precision (liboracle64.so, exported with an ani_oracle64_ prefix): an "exact" answer against which the
+ * fp32 reference's OWN rounding error can be measured, for the ill-conditioned corner of paper-mode angle gradients. */
+#ifdef ORACLE_DOUBLE
+typedef double real;
+#define R_ACOS(x) acos(x)
+#define R_ASIN(x) asin(x)
+#define R_COS(x) cos(x)
+#define R_EXP(x) exp(x)
+#define R_POW(x, y) pow(x, y)
+#define R_ROUND(x) round(x)
+#define R_SIN(x) sin(x)
+#define R_SQRT(x) sqrt(x)
+#define ani_oracle_create ani_oracle64_create
+#define ani_oracle_destroy ani_oracle64_destroy
+#define ani_oracle_forward ani_oracle64_forward
+#define ani_oracle_backward ani_oracle64_backward
+#else
+typedef float real;
+#define R_ACOS(x) acosf(x)
+#define R_ASIN(x) asinf(x)
+#define R_COS(x) cosf(x)
+#define R_EXP(x) expf(x)
+#define R_POW(x, y) powf(x, y)
+#define R_ROUND(x) roundf(x)
+#define R_SIN(x) sinf(x)
+#define R_SQRT(x) sqrtf(x)
+#endif
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
 
 typedef struct {
     int n_atoms, n_species, n_radial, n_angular;
-    float rc_radial, rc_angular;
+    real rc_radial, rc_angular;
     int periodic, torchani;
     int *species;          /* [n_atoms] */
-    float *rad_eta, *rad_rs;                       /* [n_radial] */
-    float *ang_eta, *ang_rs, *ang_zeta, *ang_ths;  /* [n_angular] */
+    real *rad_eta, *rad_rs;                       /* [n_radial] */
+    real *ang_eta, *ang_rs, *ang_zeta, *ang_ths;  /* [n_angular] */
     int *bucket;           /* [n_species*n_species] species pair -> angular block */
     /* state left by the last forward(), consumed by backward() (ref ANISymmetryFunctions.h:83-84) */
-    float *pos;            /* [n_atoms*3] */
-    float box[9], inv_diag[3];
+    real *pos;            /* [n_atoms*3] */
+    real box[9], inv_diag[3];
     int triclinic;
     int *nbr_start;        /* [n_atoms+1] */
     int *nbr_count;        /* [n_atoms]   */
@@ -56,10 +86,10 @@ typedef struct {
 
 void ani_oracle_destroy(ani_oracle *o);
 
-ani_oracle *ani_oracle_create(int n_atoms, int n_species, float rc_radial, float rc_angular,
+ani_oracle *ani_oracle_create(int n_atoms, int n_species, real rc_radial, real rc_angular,
                               int periodic, const int *species,
-                              int n_radial, const float *radial_eta_rs,         /* [n_radial][2]  */
-                              int n_angular, const float *angular_eta_rs_zeta_ths, /* [n_angular][4] */
+                              int n_radial, const real *radial_eta_rs,         /* [n_radial][2]  */
+                              int n_angular, const real *angular_eta_rs_zeta_ths, /* [n_angular][4] */
                               int torchani) {
     ani_oracle *o = (ani_oracle *)calloc(1, sizeof(ani_oracle));
     o->n_atoms = n_atoms; o->n_species = n_species;
@@ -68,16 +98,16 @@ ani_oracle *ani_oracle_create(int n_atoms, int n_species, float rc_radial, float
     o->periodic = periodic; o->torchani = torchani;
     o->species = (int *)malloc(sizeof(int) * (n_atoms > 0 ? n_atoms : 1));
     memcpy(o->species, species, sizeof(int) * n_atoms);
-    o->rad_eta = (float *)malloc(sizeof(float) * (n_radial + 1));
-    o->rad_rs = (float *)malloc(sizeof(float) * (n_radial + 1));
+    o->rad_eta = (real *)malloc(sizeof(real) * (n_radial + 1));
+    o->rad_rs = (real *)malloc(sizeof(real) * (n_radial + 1));
     for (int k = 0; k < n_radial; k++) {
         o->rad_eta[k] = radial_eta_rs[2 * k];
         o->rad_rs[k] = radial_eta_rs[2 * k + 1];
     }
-    o->ang_eta = (float *)malloc(sizeof(float) * (n_angular + 1));
-    o->ang_rs = (float *)malloc(sizeof(float) * (n_angular + 1));
-    o->ang_zeta = (float *)malloc(sizeof(float) * (n_angular + 1));
-    o->ang_ths = (float *)malloc(sizeof(float) * (n_angular + 1));
+    o->ang_eta = (real *)malloc(sizeof(real) * (n_angular + 1));
+    o->ang_rs = (real *)malloc(sizeof(real) * (n_angular + 1));
+    o->ang_zeta = (real *)malloc(sizeof(real) * (n_angular + 1));
+    o->ang_ths = (real *)malloc(sizeof(real) * (n_angular + 1));
     for (int m = 0; m < n_angular; m++) {
         o->ang_eta[m] = angular_eta_rs_zeta_ths[4 * m];
         o->ang_rs[m] = angular_eta_rs_zeta_ths[4 * m + 1];
@@ -93,7 +123,7 @@ ani_oracle *ani_oracle_create(int n_atoms, int n_species, float rc_radial, float
             o->bucket[b * n_species + a] = next;
             next++;
         }
-    o->pos = (float *)malloc(sizeof(float) * 3 * (n_atoms > 0 ? n_atoms : 1));
+    o->pos = (real *)malloc(sizeof(real) * 3 * (n_atoms > 0 ? n_atoms : 1));
     o->nbr_start = (int *)calloc(n_atoms + 1, sizeof(int));
     o->nbr_count = (int *)calloc(n_atoms + 1, sizeof(int));
     o->tmp_lists = (int **)calloc(n_atoms + 1, sizeof(int *));
@@ -113,59 +143,59 @@ void ani_oracle_destroy(ani_oracle *o) {
 }
 
 /* ref :355-379.  d = p2 - p1, then (periodic) at most one lattice translation per axis. */
-static inline float displacement(const ani_oracle *o, const float *p1, const float *p2, float d[3]) {
+static inline real displacement(const ani_oracle *o, const real *p1, const real *p2, real d[3]) {
     d[0] = p2[0] - p1[0];
     d[1] = p2[1] - p1[1];
     d[2] = p2[2] - p1[2];
     if (o->periodic) {
-        const float *b = o->box;
+        const real *b = o->box;
         if (o->triclinic) {
-            float s3 = roundf(d[2] * o->inv_diag[2]);
+            real s3 = R_ROUND(d[2] * o->inv_diag[2]);
             d[0] -= s3 * b[6]; d[1] -= s3 * b[7]; d[2] -= s3 * b[8];
-            float s2 = roundf(d[1] * o->inv_diag[1]);
+            real s2 = R_ROUND(d[1] * o->inv_diag[1]);
             d[0] -= s2 * b[3]; d[1] -= s2 * b[4];
-            float s1 = roundf(d[0] * o->inv_diag[0]);
+            real s1 = R_ROUND(d[0] * o->inv_diag[0]);
             d[0] -= s1 * b[0];
         } else {
-            d[0] -= roundf(d[0] * o->inv_diag[0]) * b[0];
-            d[1] -= roundf(d[1] * o->inv_diag[1]) * b[4];
-            d[2] -= roundf(d[2] * o->inv_diag[2]) * b[8];
+            d[0] -= R_ROUND(d[0] * o->inv_diag[0]) * b[0];
+            d[1] -= R_ROUND(d[1] * o->inv_diag[1]) * b[4];
+            d[2] -= R_ROUND(d[2] * o->inv_diag[2]) * b[8];
         }
     }
     return d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
 }
 
 /* ref :381-387 (the argument is evaluated in double, then narrowed for cosf/sinf) */
-static inline float fcut(float r, float rc) { return 0.5f * cosf(M_PI * r / rc) + 0.5f; }
-static inline float fcut_deriv(float r, float rc) { return -(0.5f * M_PI / rc) * sinf(M_PI * r / rc); }
+static inline real fcut(real r, real rc) { return 0.5f * R_COS(M_PI * r / rc) + 0.5f; }
+static inline real fcut_deriv(real r, real rc) { return -(0.5f * M_PI / rc) * R_SIN(M_PI * r / rc); }
 
 /* ref :389-408 */
-static inline float angle_between(const ani_oracle *o, const float *u, const float *v, float ru, float rv) {
-    float dot = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+static inline real angle_between(const ani_oracle *o, const real *u, const real *v, real ru, real rv) {
+    real dot = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
     if (o->torchani) dot *= 0.95f;
-    float c = dot / (ru * rv);
+    real c = dot / (ru * rv);
     if (!o->torchani && (c > 0.99f || c < -0.99f)) {
-        float x[3] = { u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0] };
-        float a = asinf(sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / (ru * rv));
+        real x[3] = { u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0] };
+        real a = R_ASIN(R_SQRT(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / (ru * rv));
         if (c < 0) a = M_PI - a;
         return a;
     }
-    return acosf(c);
+    return R_ACOS(c);
 }
 
 /* ref :410-433 */
-static inline void angle_gradients(const ani_oracle *o, const float *u, const float *v, float ru, float rv,
-                                   float gu[3], float gv[3]) {
-    float dot = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
-    float iu = 1 / ru, iv = 1 / rv;
-    float iprod = iu * iv, iu2 = iu * iu, iv2 = iv * iv;
-    float dadd;
+static inline void angle_gradients(const ani_oracle *o, const real *u, const real *v, real ru, real rv,
+                                   real gu[3], real gv[3]) {
+    real dot = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+    real iu = 1 / ru, iv = 1 / rv;
+    real iprod = iu * iv, iu2 = iu * iu, iv2 = iv * iv;
+    real dadd;
     if (o->torchani) {
-        float sd = 0.95f * dot * iprod;
-        dadd = -0.95f / sqrtf(1 - sd * sd);
+        real sd = 0.95f * dot * iprod;
+        dadd = -0.95f / R_SQRT(1 - sd * sd);
     } else {
-        float sd = dot * iprod;
-        dadd = -1 / sqrtf(1 - sd * sd);
+        real sd = dot * iprod;
+        dadd = -1 / R_SQRT(1 - sd * sd);
     }
     for (int k = 0; k < 3; k++) {
         gu[k] = dadd * iprod * (v[k] - dot * iu2 * u[k]);
@@ -181,13 +211,13 @@ static void tmp_push(ani_oracle *o, int atom, int value) {
     o->tmp_lists[atom][o->tmp_len[atom]++] = value;
 }
 
-void ani_oracle_forward(ani_oracle *o, const float *positions, const float *box, float *radial, float *angular) {
+void ani_oracle_forward(ani_oracle *o, const real *positions, const real *box, real *radial, real *angular) {
     const int N = o->n_atoms, S = o->n_species, nR = o->n_radial, nA = o->n_angular;
     const int nB = S * (S + 1) / 2;
-    memcpy(o->pos, positions, sizeof(float) * 3 * N);
+    memcpy(o->pos, positions, sizeof(real) * 3 * N);
     o->triclinic = 0;
     if (o->periodic) {                                       /* ref :49-64 */
-        memcpy(o->box, box, sizeof(float) * 9);
+        memcpy(o->box, box, sizeof(real) * 9);
         o->inv_diag[0] = 1 / o->box[0];
         o->inv_diag[1] = 1 / o->box[4];
         o->inv_diag[2] = 1 / o->box[8];
@@ -195,26 +225,26 @@ void ani_oracle_forward(ani_oracle *o, const float *positions, const float *box,
             for (int b = 0; b < 3; b++)
                 if (a != b && o->box[3 * a + b] != 0) o->triclinic = 1;
     }
-    memset(radial, 0, sizeof(float) * (size_t)N * S * nR);    /* ref :68-69 */
-    memset(angular, 0, sizeof(float) * (size_t)N * nB * nA);
+    memset(radial, 0, sizeof(real) * (size_t)N * S * nR);    /* ref :68-69 */
+    memset(angular, 0, sizeof(real) * (size_t)N * nB * nA);
 
     /* ---- radial pass, ref :112-151 ---- */
-    const float rc2_rad = o->rc_radial * o->rc_radial;
-    const float rc2_ang = o->rc_angular * o->rc_angular;
+    const real rc2_rad = o->rc_radial * o->rc_radial;
+    const real rc2_ang = o->rc_angular * o->rc_angular;
     for (int i = 0; i < N; i++) o->tmp_len[i] = 0;
     for (int i = 0; i < N; i++) {
         for (int j = i + 1; j < N; j++) {
-            float d[3];
-            float r2 = displacement(o, &o->pos[3 * i], &o->pos[3 * j], d);
+            real d[3];
+            real r2 = displacement(o, &o->pos[3 * i], &o->pos[3 * j], d);
             if (!(r2 < rc2_rad)) continue;
             if (r2 < rc2_ang) { tmp_push(o, i, j); tmp_push(o, j, i); }
-            float r = sqrtf(r2);
-            float fc = fcut(r, o->rc_radial);
-            float *row_i = &radial[((size_t)i * S + o->species[j]) * nR];
-            float *row_j = &radial[((size_t)j * S + o->species[i]) * nR];
+            real r = R_SQRT(r2);
+            real fc = fcut(r, o->rc_radial);
+            real *row_i = &radial[((size_t)i * S + o->species[j]) * nR];
+            real *row_j = &radial[((size_t)j * S + o->species[i]) * nR];
             for (int k = 0; k < nR; k++) {
-                float sh = r - o->rad_rs[k];
-                float v = fc * expf(-o->rad_eta[k] * sh * sh);
+                real sh = r - o->rad_rs[k];
+                real v = fc * R_EXP(-o->rad_eta[k] * sh * sh);
                 row_i[k] += v;
                 row_j[k] += v;
             }
@@ -232,24 +262,24 @@ void ani_oracle_forward(ani_oracle *o, const float *positions, const float *box,
     for (int i = 0; i < N; i++) {
         const int *list = &o->nbr[o->nbr_start[i]];
         const int n = o->nbr_count[i];
-        float *out_i = &angular[(size_t)i * nB * nA];
+        real *out_i = &angular[(size_t)i * nB * nA];
         for (int a = 0; a < n; a++) {
             int j = list[a];
-            float dj[3];
-            float rj = sqrtf(displacement(o, &o->pos[3 * i], &o->pos[3 * j], dj));
-            float fcj = fcut(rj, o->rc_angular);
+            real dj[3];
+            real rj = R_SQRT(displacement(o, &o->pos[3 * i], &o->pos[3 * j], dj));
+            real fcj = fcut(rj, o->rc_angular);
             for (int b = a + 1; b < n; b++) {
                 int k = list[b];
-                float dk[3];
-                float rk = sqrtf(displacement(o, &o->pos[3 * i], &o->pos[3 * k], dk));
-                float fck = fcut(rk, o->rc_angular);
-                float rmean = 0.5f * (rj + rk);
-                float theta = angle_between(o, dj, dk, rj, rk);
-                float *blk = &out_i[o->bucket[o->species[j] * S + o->species[k]] * nA];
+                real dk[3];
+                real rk = R_SQRT(displacement(o, &o->pos[3 * i], &o->pos[3 * k], dk));
+                real fck = fcut(rk, o->rc_angular);
+                real rmean = 0.5f * (rj + rk);
+                real theta = angle_between(o, dj, dk, rj, rk);
+                real *blk = &out_i[o->bucket[o->species[j] * S + o->species[k]] * nA];
                 for (int m = 0; m < nA; m++) {
-                    float cos_term = powf(1 + cosf(theta - o->ang_ths[m]), o->ang_zeta[m]);
-                    float sh = rmean - o->ang_rs[m];
-                    float exp_term = expf(-o->ang_eta[m] * sh * sh);
+                    real cos_term = R_POW(1 + R_COS(theta - o->ang_ths[m]), o->ang_zeta[m]);
+                    real sh = rmean - o->ang_rs[m];
+                    real exp_term = R_EXP(-o->ang_eta[m] * sh * sh);
                     blk[m] += fcj * fck * cos_term * exp_term;
                 }
             }
@@ -263,36 +293,36 @@ void ani_oracle_forward(ani_oracle *o, const float *positions, const float *box,
     }
     size_t cnt = (size_t)N * nB * nA;
     for (int m = 0; m < nA; m++) {
-        float scale = powf(2, 1 - o->ang_zeta[m]);
+        real scale = R_POW(2, 1 - o->ang_zeta[m]);
         for (size_t q = m; q < cnt; q += nA) angular[q] *= scale;
     }
 }
 
-void ani_oracle_backward(ani_oracle *o, const float *radial_grad, const float *angular_grad, float *pos_grad) {
+void ani_oracle_backward(ani_oracle *o, const real *radial_grad, const real *angular_grad, real *pos_grad) {
     const int N = o->n_atoms, S = o->n_species, nR = o->n_radial, nA = o->n_angular;
     const int nB = S * (S + 1) / 2;
-    memset(pos_grad, 0, sizeof(float) * 3 * N);              /* ref :199 */
+    memset(pos_grad, 0, sizeof(real) * 3 * N);              /* ref :199 */
 
     /* ---- radial, ref :228-263 ---- */
-    const float rc2_rad = o->rc_radial * o->rc_radial;
-    const float gscale = o->torchani ? 0.25f : 1.0f;
+    const real rc2_rad = o->rc_radial * o->rc_radial;
+    const real gscale = o->torchani ? 0.25f : 1.0f;
     for (int i = 0; i < N; i++) {
         for (int j = i + 1; j < N; j++) {
-            float d[3];
-            float r2 = displacement(o, &o->pos[3 * i], &o->pos[3 * j], d);
+            real d[3];
+            real r2 = displacement(o, &o->pos[3 * i], &o->pos[3 * j], d);
             if (!(r2 < rc2_rad)) continue;
-            float r = sqrtf(r2), rinv = 1 / r;
-            float fc = fcut(r, o->rc_radial), dfc = fcut_deriv(r, o->rc_radial);
-            const float *gi = &radial_grad[((size_t)i * S + o->species[j]) * nR];
-            const float *gj = &radial_grad[((size_t)j * S + o->species[i]) * nR];
+            real r = R_SQRT(r2), rinv = 1 / r;
+            real fc = fcut(r, o->rc_radial), dfc = fcut_deriv(r, o->rc_radial);
+            const real *gi = &radial_grad[((size_t)i * S + o->species[j]) * nR];
+            const real *gj = &radial_grad[((size_t)j * S + o->species[i]) * nR];
             for (int k = 0; k < nR; k++) {
-                float sh = r - o->rad_rs[k];
-                float e = expf(-o->rad_eta[k] * sh * sh);
-                float dvdr = dfc * e - fc * 2 * o->rad_eta[k] * sh * e;
-                float dedv = gi[k] + gj[k];
-                float sc = gscale * dedv * dvdr * rinv;
+                real sh = r - o->rad_rs[k];
+                real e = R_EXP(-o->rad_eta[k] * sh * sh);
+                real dvdr = dfc * e - fc * 2 * o->rad_eta[k] * sh * e;
+                real dedv = gi[k] + gj[k];
+                real sc = gscale * dedv * dvdr * rinv;
                 for (int c = 0; c < 3; c++) {
-                    float t = sc * d[c];
+                    real t = sc * d[c];
                     pos_grad[3 * i + c] -= t;
                     pos_grad[3 * j + c] += t;
                 }
@@ -304,58 +334,58 @@ void ani_oracle_backward(ani_oracle *o, const float *radial_grad, const float *a
     for (int i = 0; i < N; i++) {
         const int *list = &o->nbr[o->nbr_start[i]];
         const int n = o->nbr_count[i];
-        const float *g_i = &angular_grad[(size_t)i * nB * nA];
+        const real *g_i = &angular_grad[(size_t)i * nB * nA];
         for (int a = 0; a < n; a++) {
             int j = list[a];
-            float dj[3];
-            float rj = sqrtf(displacement(o, &o->pos[3 * i], &o->pos[3 * j], dj));
-            float rinv_j = 1 / rj;
-            float fcj = fcut(rj, o->rc_angular), dfcj = fcut_deriv(rj, o->rc_angular);
+            real dj[3];
+            real rj = R_SQRT(displacement(o, &o->pos[3 * i], &o->pos[3 * j], dj));
+            real rinv_j = 1 / rj;
+            real fcj = fcut(rj, o->rc_angular), dfcj = fcut_deriv(rj, o->rc_angular);
             for (int b = a + 1; b < n; b++) {
                 int k = list[b];
-                float dk[3];
-                float rk = sqrtf(displacement(o, &o->pos[3 * i], &o->pos[3 * k], dk));
-                float rinv_k = 1 / rk;
-                float fck = fcut(rk, o->rc_angular), dfck = fcut_deriv(rk, o->rc_angular);
-                float rmean = 0.5f * (rj + rk);
-                float theta = angle_between(o, dj, dk, rj, rk);
-                float gj[3], gk[3];
+                real dk[3];
+                real rk = R_SQRT(displacement(o, &o->pos[3 * i], &o->pos[3 * k], dk));
+                real rinv_k = 1 / rk;
+                real fck = fcut(rk, o->rc_angular), dfck = fcut_deriv(rk, o->rc_angular);
+                real rmean = 0.5f * (rj + rk);
+                real theta = angle_between(o, dj, dk, rj, rk);
+                real gj[3], gk[3];
                 angle_gradients(o, dj, dk, rj, rk, gj, gk);
-                const float *g = &g_i[o->bucket[o->species[j] * S + o->species[k]] * nA];
+                const real *g = &g_i[o->bucket[o->species[j] * S + o->species[k]] * nA];
                 for (int m = 0; m < nA; m++) {
-                    float zeta = o->ang_zeta[m], ths = o->ang_ths[m];
-                    float cos_term = powf(1 + cosf(theta - ths), zeta);
-                    float sh = rmean - o->ang_rs[m];
-                    float exp_term = expf(-o->ang_eta[m] * sh * sh);
-                    float dexp = -o->ang_eta[m] * sh * exp_term;   /* half of 2*eta: rmean carries 1/2 (ref :306) */
-                    float dedv = g[m];
-                    float zscale = powf(2, 1 - zeta);
+                    real zeta = o->ang_zeta[m], ths = o->ang_ths[m];
+                    real cos_term = R_POW(1 + R_COS(theta - ths), zeta);
+                    real sh = rmean - o->ang_rs[m];
+                    real exp_term = R_EXP(-o->ang_eta[m] * sh * sh);
+                    real dexp = -o->ang_eta[m] * sh * exp_term;   /* half of 2*eta: rmean carries 1/2 (ref :306) */
+                    real dedv = g[m];
+                    real zscale = R_POW(2, 1 - zeta);
                     {   /* via r_ij, ref :311-320 */
-                        float dvdr = dfcj * fck * cos_term * exp_term + fcj * fck * cos_term * dexp;
-                        float sc = zscale * dedv * dvdr * rinv_j;
+                        real dvdr = dfcj * fck * cos_term * exp_term + fcj * fck * cos_term * dexp;
+                        real sc = zscale * dedv * dvdr * rinv_j;
                         for (int c = 0; c < 3; c++) {
-                            float t = sc * dj[c];
+                            real t = sc * dj[c];
                             pos_grad[3 * i + c] -= t;
                             pos_grad[3 * j + c] += t;
                         }
                     }
                     {   /* via r_ik, ref :324-332 */
-                        float dvdr = fcj * dfck * cos_term * exp_term + fcj * fck * cos_term * dexp;
-                        float sc = zscale * dedv * dvdr * rinv_k;
+                        real dvdr = fcj * dfck * cos_term * exp_term + fcj * fck * cos_term * dexp;
+                        real sc = zscale * dedv * dvdr * rinv_k;
                         for (int c = 0; c < 3; c++) {
-                            float t = sc * dk[c];
+                            real t = sc * dk[c];
                             pos_grad[3 * i + c] -= t;
                             pos_grad[3 * k + c] += t;
                         }
                     }
                     {   /* via the angle, ref :336-348 */
-                        float dcos = -zeta * powf(1 + cosf(theta - ths), zeta - 1) * sinf(theta - ths);
-                        float dvda = fcj * fck * dcos * exp_term;
-                        float s2 = zscale * dedv * dvda;
-                        float s3 = zscale * dedv * dvda;
+                        real dcos = -zeta * R_POW(1 + R_COS(theta - ths), zeta - 1) * R_SIN(theta - ths);
+                        real dvda = fcj * fck * dcos * exp_term;
+                        real s2 = zscale * dedv * dvda;
+                        real s3 = zscale * dedv * dvda;
                         for (int c = 0; c < 3; c++) {
-                            float t2 = s2 * gj[c];
-                            float t3 = s3 * gk[c];
+                            real t2 = s2 * gj[c];
+                            real t3 = s3 * gk[c];
                             pos_grad[3 * j + c] += t2;
                             pos_grad[3 * k + c] += t3;
                             pos_grad[3 * i + c] -= t2 + t3;

@@ -147,6 +147,56 @@ class AniOracle(_AniBase):
     _which = "oracle"
 
 
+class AniOracle64:
+    """oracle/ani_oracle.c compiled with -DORACLE_DOUBLE (liboracle64.so): the reference algorithm evaluated in double
+    precision on the same float32 inputs and parameters.  Not a parity target -- the yardstick for how far the fp32
+    reference itself is from the exact answer (used where the problem is ill conditioned, e.g. paper-mode angle gradients
+    of nearly collinear triples).  Same stateful interface as AniOracle; float64 arrays out."""
+
+    def __init__(self, n_species, rc_radial, rc_angular, species, radial_functions, angular_functions,
+                 periodic=False, torchani=True):
+        path = os.path.join(_HERE, "_build", "liboracle64.so")
+        if not os.path.exists(path):
+            build_oracle(with_ref=False)
+        lib = C.CDLL(path)
+        f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        lib.ani_oracle64_create.restype = C.c_void_p
+        lib.ani_oracle64_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _i32p, C.c_int, f64p, C.c_int, f64p, C.c_int]
+        lib.ani_oracle64_destroy.argtypes = [C.c_void_p]
+        lib.ani_oracle64_forward.argtypes = [C.c_void_p, f64p, C.c_void_p, f64p, f64p]
+        lib.ani_oracle64_backward.argtypes = [C.c_void_p, f64p, f64p, f64p]
+        self.lib = lib
+        self.species = np.ascontiguousarray(species, dtype=np.int32)
+        self.n_atoms, self.n_species = int(self.species.shape[0]), int(n_species)
+        # float32 parameters, widened exactly
+        self.rf = np.ascontiguousarray(_f32(radial_functions).reshape(-1, 2), dtype=np.float64)
+        self.af = np.ascontiguousarray(_f32(angular_functions).reshape(-1, 4), dtype=np.float64)
+        self.periodic = bool(periodic)
+        self.handle = C.c_void_p(lib.ani_oracle64_create(self.n_atoms, self.n_species, float(np.float32(rc_radial)),
+                                                         float(np.float32(rc_angular)), int(self.periodic), self.species,
+                                                         self.rf.shape[0], self.rf, self.af.shape[0], self.af, int(bool(torchani))))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.ani_oracle64_destroy(self.handle)
+            self.handle = None
+
+    def forward(self, positions, box=None):
+        pos = np.ascontiguousarray(_f32(positions).reshape(self.n_atoms, 3), dtype=np.float64)
+        nb = self.n_species * (self.n_species + 1) // 2
+        radial = np.empty((self.n_atoms, self.n_species * self.rf.shape[0]), np.float64)
+        angular = np.empty((self.n_atoms, nb * self.af.shape[0]), np.float64)
+        b = np.ascontiguousarray(_f32(box).reshape(3, 3), dtype=np.float64) if (self.periodic and box is not None) else None
+        self.lib.ani_oracle64_forward(self.handle, pos, b.ctypes.data_as(C.c_void_p) if b is not None else None, radial, angular)
+        return radial, angular
+
+    def backward(self, radial_grad, angular_grad):
+        out = np.empty((self.n_atoms, 3), np.float64)
+        self.lib.ani_oracle64_backward(self.handle, np.ascontiguousarray(radial_grad, dtype=np.float64),
+                                       np.ascontiguousarray(angular_grad, dtype=np.float64), out)
+        return out
+
+
 class RefAni(_AniBase):
     _which = "ref"
 

@@ -45,6 +45,10 @@ def _run_case(n_species, rcr, rca, species, rf, af, pos, box, torchani=True, see
     e = float((r.astype(np.float64) * wr).sum() + (a.astype(np.float64) * wa).sum())
     scale = float(np.abs(r_ref.astype(np.float64) * wr).sum() + np.abs(a_ref.astype(np.float64) * wa).sum())
     assert abs(e - e_ref) <= ENERGY_RTOL * scale, (e, e_ref, scale)
+    # north_star's energy gate in its plainest form: E = sum of the AEV (all terms >= 0, nothing cancels), 1e-5 relative
+    e_sum_ref = float(r_ref.astype(np.float64).sum() + a_ref.astype(np.float64).sum())
+    e_sum = float(r.astype(np.float64).sum() + a.astype(np.float64).sum())
+    assert abs(e_sum - e_sum_ref) <= ENERGY_RTOL * abs(e_sum_ref), (e_sum, e_sum_ref)
     fmax = np.abs(g_ref).max()
     assert np.abs(g - g_ref).max() <= FORCE_RTOL * fmax, (np.abs(g - g_ref).max(), fmax)
     return r, a, g
@@ -333,3 +337,27 @@ def test_strided_rows_write_one_aev_array():
     assert torch.equal(grad2, grad)
     with pytest.raises(NNPOpsHipError, match="row strides"):
         _check(L.nnpops_ani_compute_strided(sym._h, _ptr(tpos), _ptr(tbox), aev.data_ptr(), wr - 1, aev.data_ptr(), ld))
+
+
+@pytest.mark.parametrize("torchani", [True, False])
+@pytest.mark.parametrize("kind", ["irregular", "too_many_factors", "forced_grid"])
+def test_arbitrary_angular_function_lists(monkeypatch, kind, torchani):
+    """The reference core evaluates ANY vector of AngularFunction records one by one (CpuANISymmetryFunctions.cpp:153-194).
+    Lists that are not a full {(eta,rs)} x {(zeta,thetas)} grid -- here: a grid with holes, a duplicate and shuffled order;
+    and a grid with more distinct (zeta, thetas) factors than the factored kernels take -- run on the generic kernels
+    instead of being refused; `forced_grid` pushes the ANI-2x grid itself through them ($NNPOPS_ANI_GENERIC)."""
+    rng = np.random.default_rng(77)
+    rf, af = workloads.ani2x_functions()
+    if kind == "irregular":
+        keep = rng.permutation(len(af))[:19]
+        af = np.concatenate([af[keep], af[keep[:1]]]).astype(np.float32)          # 20 functions, one of them twice
+        af[3, 0] = 9.5                                                             # a (eta, rs) pair nobody else has
+    elif kind == "too_many_factors":
+        zs = [(float(z), float(t)) for z in (1.0, 4.0, 14.1) for t in np.linspace(0.3, 2.8, 4)]      # 12 (zeta, thetas) factors
+        af = np.array([[12.5, r, z, t] for r in (0.8, 1.9, 3.0) for z, t in zs], dtype=np.float32)    # 36 functions
+    else:
+        monkeypatch.setenv("NNPOPS_ANI_GENERIC", "1")
+    pos, species, box = workloads.random_box(420, seed=91)
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, box, torchani=torchani)
+    mol, sp = workloads.conformer(45, seed=92)
+    _run_case(7, 5.1, 3.5, sp, rf, af, mol, None, torchani=torchani)

@@ -116,6 +116,46 @@ def test_cfconv_10k_forces_sum_to_zero_and_match_vector_kernels(monkeypatch):
     assert gp0.double().sum(0).abs().max().item() <= 1e-3 * fmax
 
 
+def test_cfconv_10k_against_the_oracle_at_full_size():
+    """BASELINE config 3 at full size (10 000 atoms periodic, W=128, G=50, N(0, 0.1^2) weights, ssp) against the CPU ORACLE
+    (~15 s of single-core work), not against this repository's own vector kernels: the split-fp16 dense layers the handle
+    picks by default must hold the same bars as everything else -- outputs and input gradients 2e-5 of the largest entry
+    (element-wise), "energy" <gy, y> 1e-5 relative to the sum of its absolute terms, position gradients 1e-4 of the largest
+    component."""
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    from oracle import CFConvNeighborsOracle, CFConvOracle
+    n, W, G, cutoff, sigma = 10000, 128, 50, 5.0, 0.1
+    pos, _, box = workloads.random_box(n, density=0.1, seed=3)
+    rng = np.random.default_rng(4)
+    w1 = (0.1 * rng.standard_normal((W, G))).astype(np.float32)
+    w2 = (0.1 * rng.standard_normal((W, W))).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(W)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(W)).astype(np.float32)
+    x = rng.standard_normal((n, W)).astype(np.float32)
+    gy = rng.standard_normal((n, W)).astype(np.float32)
+    onb = CFConvNeighborsOracle(n, cutoff, True)
+    ocf = CFConvOracle(n, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True)
+    onb.build(pos, box)
+    y_ref = ocf.forward(onb, pos, x, box)
+    xg_ref, pg_ref = ocf.backward(onb, pos, x, gy, box)
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    tx, tg = torch.tensor(x, device=dev), torch.tensor(gy, device=dev)
+    nb = CFConvNeighbors(n, cutoff, periodic=True)
+    nb.build(tpos, tbox, check=True)
+    assert nb.num_pairs() == onb.num_pairs()
+    cf = CFConv(n, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True)
+    y = torch.empty_like(tx)
+    cf.compute(nb, tpos, tx, tbox, y)
+    gx, gpos = cf.backprop(nb, tpos, tx, tg, tbox)
+    y, gx, gpos = y.cpu().numpy(), gx.cpu().numpy(), gpos.cpu().numpy()
+    np.testing.assert_allclose(y, y_ref, rtol=2e-5, atol=2e-5 * np.abs(y_ref).max())
+    np.testing.assert_allclose(gx, xg_ref, rtol=2e-5, atol=2e-5 * np.abs(xg_ref).max())
+    e_ref, e = float((y_ref.astype(np.float64) * gy).sum()), float((y.astype(np.float64) * gy).sum())
+    assert abs(e - e_ref) <= 1e-5 * float(np.abs(y_ref.astype(np.float64) * gy).sum())
+    assert np.abs(gpos - pg_ref).max() <= 1e-4 * np.abs(pg_ref).max()
+
+
 def test_headline_workload_against_the_oracle_at_full_size():
     """The benchmark's own frame (10 000 atoms, periodic, 7 species uniform, seed 100) element by element against the
     CPU oracle (O(N^2), a few seconds): AEV rtol 2e-5 / atol 2e-6, energy 1e-5, forces 1e-4 of the largest component."""

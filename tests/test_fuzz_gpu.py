@@ -78,12 +78,23 @@ def test_ani_random_configuration(seed):
     r, a, g = radial.cpu().numpy(), angular.cpu().numpy(), grad.cpu().numpy()
     np.testing.assert_allclose(r, r_ref, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(a, a_ref, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(a_ref).max())))
-    fmax = float(np.abs(g_ref).max())
-    # paper mode (torchani=False, reachable only through the core API) has no 0.95 damping of cos(theta): the angle
-    # gradient carries 1 / sin(theta) and is ill-conditioned for nearly collinear legs -- in dense systems the fp32
-    # reference itself is only good to a few 1e-4 of the largest force there (seen on 4 of 5 400 soak cases).
-    force_tol = 1e-4 if torchani else 5e-4
-    assert np.abs(g - g_ref).max() <= force_tol * max(fmax, 1e-6)
+    e_ref, e_gpu = float(r_ref.astype(np.float64).sum() + a_ref.astype(np.float64).sum()), float(r.astype(np.float64).sum() + a.astype(np.float64).sum())
+    assert abs(e_gpu - e_ref) <= 1e-5 * abs(e_ref) + 1e-12            # E = sum of the AEV, 1e-5 relative
+    fmax = max(float(np.abs(g_ref).max()), 1e-6)
+    err = float(np.abs(g - g_ref).max())
+    if err > 1e-4 * fmax:
+        # North_star's gate is 1e-4 of the largest force.  The only cases ever seen beyond it are dense PAPER-mode systems
+        # (torchani=False, reachable through the core API only): without TorchANI's 0.95 damping the angle gradient
+        # carries 1 / sin(theta) and is ill conditioned for nearly collinear legs -- for the fp32 reference too.  Such a
+        # case is judged against the algorithm evaluated in DOUBLE precision (oracle.AniOracle64): the HIP result must be
+        # within 1e-4 of the exact forces, or at least as close to them as the fp32 reference manages to be.
+        assert not torchani, (err, fmax)
+        from oracle import AniOracle64
+        o64 = AniOracle64(S, rcr, rca, species, rf, af, periodic=periodic, torchani=torchani)
+        o64.forward(pos, box)
+        g64 = o64.backward(wr, wa)
+        err_ref, err_gpu = float(np.abs(g_ref - g64).max()), float(np.abs(g - g64).max())
+        assert err_gpu <= max(1e-4 * fmax, 1.5 * err_ref), (err_gpu, err_ref, fmax)
 
 
 @pytest.mark.parametrize("seed", range(24 * SCALE))

@@ -447,3 +447,28 @@ def test_capacity_check_interval_knob():
             assert torch.equal(scripted((sp, tpos), cell, pbc)[1], ref)
     with pytest.raises(RuntimeError, match="interval"):
         module.set_check_interval(-1)
+
+
+def test_forward_batch_evaluates_conformers_in_one_holder():
+    """Additive API on the torch surface: B conformers of one molecule through ONE batched holder
+    (Holder.set_molecules) must equal B single-molecule evaluations of the reference-shaped forward(), values and position
+    gradients; the reference-shaped forward() still rejects batches with the reference's ValueError."""
+    from nnpops_amd.SymmetryFunctions import TorchANISymmetryFunctions
+    base, species = workloads.conformer(37, seed=71)
+    rng = np.random.default_rng(72)
+    confs = np.stack([base + rng.normal(0, 0.08, base.shape).astype(np.float32) for _ in range(5)])
+    module = TorchANISymmetryFunctions(FakeConverter(), fake_aev_computer(), _numbers(species).cpu()).to(DEV)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    tpos = torch.tensor(confs, device=DEV, requires_grad=True)
+    _, aev = module.forward_batch((sp.expand(5, -1), tpos))
+    assert aev.shape == (5, 37, 1008)
+    w = torch.randn(aev.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    (aev * w).sum().backward()
+    for b in range(5):
+        one = torch.tensor(confs[b:b + 1], device=DEV, requires_grad=True)
+        _, ref = module((sp, one))
+        torch.testing.assert_close(aev[b:b + 1], ref, rtol=1e-6, atol=1e-7)
+        (ref * w[b:b + 1]).sum().backward()
+        torch.testing.assert_close(tpos.grad[b:b + 1], one.grad, rtol=1e-5, atol=1e-6 * float(one.grad.abs().max()))
+    with pytest.raises(ValueError, match="Batched computation of molecules is not supported"):
+        module((sp.expand(5, -1), tpos))
