@@ -8,7 +8,7 @@ from nnpops_amd import torch_binding as _binding
 _binding.load()      # torch.ops.load_library(libNNPOpsPyTorch.so), as the reference does at import
 
 for _name in ("SymmetryFunctions", "SpeciesConverter", "EnergyShifter", "BatchedNN", "OptimizedTorchANI", "CFConv",
-              "CFConvNeighbors", "neighbors", "neighbors.getNeighborPairs"):
+              "CFConvNeighbors", "neighbors", "neighbors.getNeighborPairs", "pme", "pme.pme"):
     sys.modules[f"NNPOps.{_name}"] = importlib.import_module(f"nnpops_amd.{_name}")
 
 from nnpops_amd.OptimizedTorchANI import OptimizedTorchANI  # noqa: E402,F401

@@ -431,6 +431,20 @@ def run_neighbors(args, R):
     kt = {k: 1e3 * ms / max(c, 1) for k, (ms, c) in sym.get_timing().items()}        # us per launch (event brackets included)
     sym.enable_timing(False)
     t_nb, t_fwd, t_bwd = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    # the list's immediate consumer in the reference: direct-space PME (src/pytorch/pme/pme.py:163-165)
+    from nnpops_amd.capi import pme_direct
+    charges = torch.randn(n, device=dev, generator=gen) * 0.3
+    no_excl = torch.full((n, 1), -1, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        pme_direct(tpos, charges, nb, dl, ds, no_excl, 0.6, 332.063713)
+    pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    pe[0].record()
+    for _ in range(20):
+        pme_direct(tpos, charges, nb, dl, ds, no_excl, 0.6, 332.063713)
+    pe[1].record()
+    torch.cuda.synchronize()
+    t_pme = pe[0].elapsed_time(pe[1]) / 20
+    pme_bytes = max_pairs * 12 + found * 16 + n * 16 + n * 16      # list read (neighbor ids of every slot, delta + r of live ones), q + derivatives
     nb_bytes = n * 12 + found * 24                      # positions in, (2 ints + 3 floats + 1 float) per pair out
     ang_bytes = n * 16 + n * sym.angular_width * 4
     aev_bytes = n * (16 + 2 * (sym.radial_width + sym.angular_width) * 4 + 12)
@@ -441,7 +455,8 @@ def run_neighbors(args, R):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"getNeighborPairs(cutoff {cutoff}, max_num_pairs {max_pairs}) + ANI-2x AEV, {n} atoms periodic, "
                                "0.1 atoms/A^3, 7 species", "atoms": n, "pairs_found": found},
-        "phases_ms": {"neighbor_pairs": round(t_nb, 4), "aev_forward": round(t_fwd, 4), "aev_backward": round(t_bwd, 4)},
+        "phases_ms": {"neighbor_pairs": round(t_nb, 4), "aev_forward": round(t_fwd, 4), "aev_backward": round(t_bwd, 4),
+                      "pme_direct": round(t_pme, 4)},
         "kernels_us": {k: round(v, 1) for k, v in kt.items()},
         "roofline": {"bound": "hbm", "kernel": "getNeighborPairs (3 launches + cell grid)", "achieved": round(nb_bytes / (t_nb * 1e-3) / 1e9, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb_bytes / (t_nb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -449,6 +464,9 @@ def run_neighbors(args, R):
                      "angular_forward": {"algorithmic_bytes": ang_bytes, "us": round(kt.get("angular_forward", 0.0), 1),
                                          "achieved": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3, 2),
                                          "frac": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3 / HBM_PEAK_GBS, 5)},
+                     "pme_direct": {"algorithmic_bytes": pme_bytes, "achieved": round(pme_bytes / (t_pme * 1e-3) / 1e9, 2),
+                                    "frac": round(pme_bytes / (t_pme * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "note": "energy + dE/dpositions + dE/dcharges on the pair list above (float atomics on the second atom)"},
                      "aev_step": {"algorithmic_bytes": aev_bytes,
                                   "achieved": round(aev_bytes / ((t_fwd + t_bwd) * 1e-3) / 1e9, 2)}},
     }

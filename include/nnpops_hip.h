@@ -15,6 +15,7 @@
  *   nnpops_cfconv_create / compute / backprop   CFConv ctor / compute / backprop   src/schnet/CFConv.h:109-217
  *   nnpops_neighbor_pairs_forward / _backward   neighbors::getNeighborPairs forward/backward kernels
  *                                               src/pytorch/neighbors/getNeighborPairsCUDA.cu:31-101
+ *   nnpops_pme_direct                           pme::pme_direct (computeDirect)   src/pytorch/pme/pmeCUDA.cu:30-100
  *
  * Conventions
  *   - plain C: opaque handles, raw pointers, sizes.  No torch / C++ types cross this boundary.
@@ -191,6 +192,23 @@ int nnpops_neighbor_pairs_forward(int dtype, int num_atoms, const void* position
 int nnpops_neighbor_pairs_backward(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors,
                                    const void* deltas, const void* distances, const void* grad_deltas,
                                    const void* grad_distances, void* grad_positions, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PME, direct-space part (replaces computeDirect: src/pytorch/pme/pmeCUDA.cu:30-100, pmeCPU.cpp:75-163) -- the immediate
+ * consumer of the pair list above (src/pytorch/pme/pme.py:163-165).  The reciprocal-space part is not built.
+ * ------------------------------------------------------------------------------------------ */
+/* positions: device [num_atoms][3]; charges: device [num_atoms]; neighbors int32 [2][num_pairs], deltas [num_pairs][3],
+ * distances [num_pairs]: the outputs of nnpops_neighbor_pairs_forward (float32), slots holding -1 are skipped;
+ * exclusions: device int32 [num_atoms][max_exclusions], every row sorted in DESCENDING order and padded with -1, symmetric
+ * (pme.py:66-73,93); may be NULL when max_exclusions == 0.  alpha: Ewald splitting parameter; coulomb: 1/(4 pi eps0) in the
+ * caller's units.  energy: device float[1]; position_deriv: device [num_atoms][3] = dE/dpositions; charge_deriv: device
+ * [num_atoms] = dE/dcharges; all three fully overwritten.  workspace: device scratch of at least
+ * nnpops_pme_direct_workspace_bytes(...) bytes.  Graph-capturable. */
+int64_t nnpops_pme_direct_workspace_bytes(int64_t num_pairs, int num_atoms, int max_exclusions);
+int nnpops_pme_direct(int num_atoms, int64_t num_pairs, int max_exclusions, const float* positions, const float* charges,
+                      const int32_t* neighbors, const float* deltas, const float* distances, const int32_t* exclusions,
+                      float alpha, float coulomb, float* energy, float* position_deriv, float* charge_deriv, void* workspace,
+                      void* stream);
 
 /* ---- dense layers of the ANI atomic networks (reference src/pytorch/BatchedNN.cpp:30-50, BatchedNN.py:37-122) ----
  * C[M x N] = A[M x K] B with fp32 in and out; the products run on the half-precision matrix instruction with every

@@ -63,6 +63,9 @@ SIGNATURES = {
     "nnpops_neighbor_pairs_workspace_bytes": (C.c_int64, [C.c_int]),
     "nnpops_neighbor_pairs_forward": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_pme_direct_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "nnpops_pme_direct": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_backward": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -289,6 +292,28 @@ def neighbor_pairs_backward(num_atoms, neighbors, deltas, distances, grad_deltas
                                                     _ptr(grad_deltas.contiguous()), _ptr(grad_distances.contiguous()),
                                                     _ptr(grad_positions), _stream_ptr(dev)))
     return grad_positions
+
+
+def pme_direct(positions, charges, neighbors, deltas, distances, exclusions, alpha, coulomb):
+    """Direct-space PME on a pair list (reference src/pytorch/pme/pmeCUDA.cu:30-100) through the C ABI.
+    -> (energy float32[1], dE/dpositions [N, 3], dE/dcharges [N]); `exclusions` int32 [N, max], rows sorted descending."""
+    _dev_f32(positions, "positions")
+    _dev_f32(charges, "charges")
+    n, pairs = positions.size(0), neighbors.size(1)
+    dev = positions.device
+    exclusions = exclusions.to(device=dev, dtype=torch.int32).contiguous()
+    max_excl = exclusions.size(1)
+    energy = torch.empty((1,), dtype=torch.float32, device=dev)
+    pos_deriv = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    charge_deriv = torch.empty((n,), dtype=torch.float32, device=dev)
+    L = lib()
+    ws = torch.empty((int(L.nnpops_pme_direct_workspace_bytes(pairs, n, max_excl)),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(L.nnpops_pme_direct(n, pairs, max_excl, _ptr(positions), _ptr(charges), _ptr(neighbors.contiguous()),
+                                   _ptr(deltas.contiguous()), _ptr(distances.contiguous()), _ptr(exclusions) if max_excl else None,
+                                   float(alpha), float(coulomb), _ptr(energy), _ptr(pos_deriv), _ptr(charge_deriv), _ptr(ws),
+                                   _stream_ptr(dev)))
+    return energy, pos_deriv, charge_deriv
 
 
 # ---------------------------------------------------------------------------------------------

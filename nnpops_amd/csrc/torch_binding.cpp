@@ -831,6 +831,96 @@ TORCH_LIBRARY_IMPL(neighbors, AutogradCPU, m) {
 }
 
 // =============================================================================================
+// PME, direct-space part (reference src/pytorch/pme/pme.cpp:4, pmeCUDA.cu:30-100,236-290, pmeCPU.cpp:75-175): same op
+// name and schema; the energy's autograd backward scales the derivatives computed in the forward pass, exactly as the
+// reference does.  The reciprocal-space op (pme_reciprocal) is not built.
+// =============================================================================================
+class PmeDirectFunction : public torch::autograd::Function<PmeDirectFunction> {
+public:
+    static Tensor forward(AutogradContext* ctx, const Tensor& positions, const Tensor& charges, const Tensor& neighbors,
+                          const Tensor& deltas, const Tensor& distances, const Tensor& exclusions, const torch::Scalar& alpha,
+                          const torch::Scalar& coulomb) {
+        TORCH_CHECK(positions.dim() == 2 && positions.size(1) == 3, "positions must have shape (atoms, 3)");
+        TORCH_CHECK(charges.dim() == 1 && charges.size(0) == positions.size(0), "charges must be 1D, one per atom");
+        TORCH_CHECK(neighbors.dim() == 2 && neighbors.size(0) == 2, "neighbors must have shape (2, pairs)");
+        TORCH_CHECK(exclusions.dim() == 2 && exclusions.size(0) == positions.size(0), "exclusions must have shape (atoms, max_exclusions)");
+        TORCH_CHECK(positions.scalar_type() == torch::kFloat32 && charges.scalar_type() == torch::kFloat32 &&
+                    deltas.scalar_type() == torch::kFloat32 && distances.scalar_type() == torch::kFloat32, "pme_direct computes in float32");
+        const int64_t n = positions.size(0), pairs = neighbors.size(1), max_excl = exclusions.size(1);
+        const Tensor pos = positions.contiguous(), q = charges.contiguous(), nb = neighbors.to(torch::kInt32).contiguous(),
+                     dl = deltas.contiguous(), ds = distances.contiguous(), ex = exclusions.to(torch::kInt32).contiguous();
+        const auto opts = positions.options();
+        Tensor energy = torch::empty({}, opts), pos_deriv = torch::empty({n, 3}, opts), charge_deriv = torch::empty({n}, opts);
+        const float a = (float)alpha.toDouble(), k = (float)coulomb.toDouble();
+        if (positions.is_cuda()) {
+            Tensor workspace = torch::empty({nnpops_pme_direct_workspace_bytes(pairs, (int)n, (int)max_excl)}, opts.dtype(torch::kUInt8));
+            c10::hip::HIPGuard guard(positions.device().index());
+            if (nnpops_pme_direct((int)n, pairs, (int)max_excl, pos.data_ptr<float>(), q.data_ptr<float>(), nb.data_ptr<int32_t>(),
+                                  dl.data_ptr<float>(), ds.data_ptr<float>(), max_excl ? ex.data_ptr<int32_t>() : nullptr, a, k,
+                                  energy.data_ptr<float>(), pos_deriv.data_ptr<float>(), charge_deriv.data_ptr<float>(),
+                                  workspace.data_ptr(), current_stream(positions.device())) != NNPOPS_OK)
+                raise_last("pme::pme_direct");
+        } else {
+            // host tensors: the reference registers a CPU kernel too (pmeCPU.cpp:75-163); plain loops, double energy
+            pos_deriv.zero_();
+            charge_deriv.zero_();
+            const float* P = pos.data_ptr<float>(); const float* Q = q.data_ptr<float>();
+            const int32_t* N0 = nb.data_ptr<int32_t>(); const int32_t* N1 = N0 + pairs; const int32_t* E = ex.data_ptr<int32_t>();
+            float* PD = pos_deriv.data_ptr<float>(); float* CD = charge_deriv.data_ptr<float>();
+            const float* DL = dl.data_ptr<float>(); const float* DS = ds.data_ptr<float>();
+            const float two_over_sqrt_pi = 1.12837916709551257390f;
+            double e = 0.0;
+            for (int64_t i = 0; i < pairs; i++) {
+                const int a1 = N0[i], a2 = N1[i];
+                bool include = a1 > -1;
+                for (int64_t j = 0; include && j < max_excl && E[a1 * max_excl + j] >= a2; j++)
+                    if (E[a1 * max_excl + j] == a2) include = false;
+                if (!include) continue;
+                const float r = DS[i], inv_r = 1 / r, ar = a * r, pre = k * inv_r, er = std::erfc(ar);
+                e += pre * er * Q[a1] * Q[a2];
+                CD[a1] += pre * er * Q[a2];
+                CD[a2] += pre * er * Q[a1];
+                const float dedr = pre * Q[a1] * Q[a2] * (er + ar * std::exp(-ar * ar) * two_over_sqrt_pi) * inv_r * inv_r;
+                for (int c = 0; c < 3; c++) { PD[3 * a1 + c] -= dedr * DL[3 * i + c]; PD[3 * a2 + c] += dedr * DL[3 * i + c]; }
+            }
+            for (int64_t a1 = 0; a1 < n; a1++)
+                for (int64_t j = 0; j < max_excl && E[a1 * max_excl + j] > a1; j++) {
+                    const int a2 = E[a1 * max_excl + j];
+                    float d[3];
+                    for (int c = 0; c < 3; c++) d[c] = P[3 * a1 + c] - P[3 * a2 + c];
+                    const float r = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), inv_r = 1 / r, ar = a * r, pre = k * inv_r, er = std::erf(ar);
+                    e -= pre * er * Q[a1] * Q[a2];
+                    CD[a1] -= pre * er * Q[a2];
+                    CD[a2] -= pre * er * Q[a1];
+                    const float dedr = pre * Q[a1] * Q[a2] * (er - ar * std::exp(-ar * ar) * two_over_sqrt_pi) * inv_r * inv_r;
+                    for (int c = 0; c < 3; c++) { PD[3 * a1 + c] += dedr * d[c]; PD[3 * a2 + c] -= dedr * d[c]; }
+                }
+            energy.fill_((float)e);
+        }
+        ctx->save_for_backward({pos_deriv, charge_deriv});
+        return energy;
+    }
+
+    static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+        const auto saved = ctx->get_saved_variables();
+        return {saved[0] * grad_outputs[0], saved[1] * grad_outputs[0], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+TORCH_LIBRARY(pme, m) {
+    m.def("pme_direct(Tensor positions, Tensor charges, Tensor neighbors, Tensor deltas, Tensor distances, Tensor exclusions, "
+          "Scalar alpha, Scalar coulomb) -> Tensor");
+}
+
+Tensor pme_direct_entry(const Tensor& positions, const Tensor& charges, const Tensor& neighbors, const Tensor& deltas,
+                        const Tensor& distances, const Tensor& exclusions, const torch::Scalar& alpha, const torch::Scalar& coulomb) {
+    return PmeDirectFunction::apply(positions, charges, neighbors, deltas, distances, exclusions, alpha, coulomb);
+}
+
+TORCH_LIBRARY_IMPL(pme, AutogradCUDA, m) { m.impl("pme_direct", pme_direct_entry); }
+TORCH_LIBRARY_IMPL(pme, AutogradCPU, m) { m.impl("pme_direct", pme_direct_entry); }
+
+// =============================================================================================
 // BatchedLinear (reference src/pytorch/BatchedNN.cpp:30-50): y = W v + b broadcast over
 // [molecules, atoms, models]; the backward skips the parameter gradients.
 // =============================================================================================

@@ -13,4 +13,5 @@ shipped.  ``nnpops_amd`` must not import it (tests/test_layout.py enforces that)
 """
 from .bindings import (AniOracle, AniOracle64, CFConvNeighborsOracle, CFConvOracle, RefAni, RefCFConv,  # noqa: F401
                        RefCFConvNeighbors, build_oracle, have_ref, oracle_lib_path, ref_lib_path)
+from .pme_oracle import pme_direct_oracle  # noqa: F401
 from .neighbors_oracle import neighbor_pairs_oracle, neighbor_pairs_backward_oracle  # noqa: F401

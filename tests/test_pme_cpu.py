@@ -1,0 +1,56 @@
+"""Direct-space PME without a GPU: the numpy oracle and the op's host (CPU-tensor) path against vectors produced by the
+reference's own CPU op (tests/golden/pme_ref.npz) and the OpenMM energies the reference's test holds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pme_direct_oracle
+
+
+def _cases(golden_dir):
+    g = np.load(f"{golden_dir}/pme_ref.npz")
+    for k in range(int(g["num_cases"])):
+        yield k, {name[len(f"c{k}_"):]: g[name] for name in g.files if name.startswith(f"c{k}_")}
+
+
+def _sorted_excl(excl):
+    return -np.sort(-excl.astype(np.int64), axis=1) if excl.shape[1] else excl.astype(np.int64)
+
+
+def test_oracle_is_pinned_to_the_reference_op(golden_dir):
+    for k, c in _cases(golden_dir):
+        e, pd, cd = pme_direct_oracle(c["positions"], c["charges"], c["neighbors"], c["deltas"], c["distances"],
+                                      _sorted_excl(c["exclusions"]), c["alpha"], c["coulomb"])
+        scale = np.abs(c["pos_grad"]).max()
+        assert abs(e - float(c["energy"])) <= 2e-6 * max(abs(float(c["energy"])), 1.0), k
+        np.testing.assert_allclose(pd, c["pos_grad"], rtol=2e-5, atol=2e-6 * scale)
+        np.testing.assert_allclose(cd, c["charge_grad"], rtol=2e-5, atol=2e-6 * np.abs(c["charge_grad"]).max())
+        if np.isfinite(c["openmm_energy"]):                  # the reference test's own bar: np.allclose (rtol 1e-5, atol 1e-8)
+            assert np.allclose(float(c["openmm_energy"]), e, rtol=1e-5)
+
+
+def test_pme_class_on_host_tensors(golden_dir):
+    """NNPOps.pme.PME.compute_direct end to end on CPU tensors: our getNeighborPairs CPU key + pme_direct host path + autograd."""
+    from NNPOps.pme import PME
+    for k, c in _cases(golden_dir):
+        pme = PME(14, 15, 16, 5, float(c["alpha"]), float(c["coulomb"]), torch.tensor(c["exclusions"].astype(np.int32)).reshape(len(c["positions"]), -1))
+        pos = torch.tensor(c["positions"], requires_grad=True)
+        q = torch.tensor(c["charges"], requires_grad=True)
+        e = pme.compute_direct(pos, q, float(c["cutoff"]), torch.tensor(c["box"]))
+        e.backward()
+        assert abs(float(e) - float(c["energy"])) <= 1e-5 * max(abs(float(c["energy"])), 1.0)
+        np.testing.assert_allclose(pos.grad.numpy(), c["pos_grad"], rtol=1e-4, atol=1e-5 * np.abs(c["pos_grad"]).max())
+        np.testing.assert_allclose(q.grad.numpy(), c["charge_grad"], rtol=1e-4, atol=1e-5 * np.abs(c["charge_grad"]).max())
+
+
+def test_pme_argument_errors_match_the_reference():
+    from NNPOps.pme import PME
+    with pytest.raises(ValueError, match="alpha must be positive"):
+        PME(8, 8, 8, 4, 0.0, 1.0, torch.zeros(3, 0, dtype=torch.int32))
+    pme = PME(8, 8, 8, 4, 3.0, 1.0, torch.zeros(3, 0, dtype=torch.int32))
+    with pytest.raises(ValueError, match="charges must be 1D"):
+        pme.compute_direct(torch.zeros(3, 3), torch.zeros(3, 1), 0.4, torch.eye(3))
+    with pytest.raises(ValueError, match="must all have the same length"):
+        pme.compute_direct(torch.zeros(4, 3), torch.zeros(4), 0.4, torch.eye(3))
+    with pytest.raises(RuntimeError, match="reciprocal-space"):
+        pme.compute_reciprocal(torch.zeros(3, 3), torch.zeros(3), torch.eye(3))

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of ANI kernel variants in ONE process (box-to-box and DVFS noise is ~1 us per kernel, so variants
+must be measured side by side).  Every variant is a set of environment variables read at handle creation.
+
+    python tools/ab.py "NNPOPS_ANI_FWD_CHUNK=128" "NNPOPS_ANI_FWD_CHUNK=192" [--atoms 10000] [--rounds 9] [--steps 40] [--species 7]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nnpops_amd import workloads  # noqa: E402
+from nnpops_amd.capi import AniSymmetryFunctions  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="+")
+    ap.add_argument("--atoms", type=int, default=10000)
+    ap.add_argument("--rounds", type=int, default=9)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--water", action="store_true", help="a water box (2 species present) instead of 7 uniform species")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    if args.water:
+        pos, species, box = workloads.water_box(args.atoms // 3, seed=1)
+    else:
+        pos, species, box = workloads.random_box(args.atoms, density=0.1, seed=100, n_species=7)
+    n = len(species)
+    rf, af = workloads.ani2x_functions()
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    handles = []
+    for v in args.variants:
+        saved = dict(os.environ)
+        for kv in v.split():
+            if "=" in kv:
+                k, val = kv.split("=", 1)
+                os.environ[k] = val
+        sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+        os.environ.clear(); os.environ.update(saved)
+        radial = torch.empty((n, sym.radial_width), device=dev)
+        angular = torch.empty((n, sym.angular_width), device=dev)
+        g_r, g_a = torch.randn_like(radial), torch.randn_like(angular)
+        grad = torch.empty((n, 3), device=dev)
+        sym.compute(tpos, tbox, radial, angular, check=True)
+        handles.append((v, sym, radial, angular, g_r, g_a, grad))
+    results = {v: [] for v in args.variants}
+    walls = {v: [] for v in args.variants}
+    for r in range(args.rounds):
+        for v, sym, radial, angular, g_r, g_a, grad in handles:
+            sym.enable_timing(True)
+            for _ in range(args.steps):
+                sym.compute(tpos, tbox, radial, angular, check=False)
+                sym.backprop(g_r, g_a, grad)
+            t = sym.get_timing()
+            sym.enable_timing(False)
+            results[v].append({k: 1e3 * ms / max(c, 1) for k, (ms, c) in t.items()})
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                sym.compute(tpos, tbox, radial, angular, check=False)
+                sym.backprop(g_r, g_a, grad)
+            e1.record(); torch.cuda.synchronize()
+            walls[v].append(1e3 * e0.elapsed_time(e1) / args.steps)
+    ovh = 1e6 * handles[0][1].timing_overhead()
+    for v in args.variants:
+        med = {k: float(np.median([x[k] for x in results[v]])) - ovh for k in results[v][0] if results[v][0][k] > 0}
+        print(f"{v or '(default)':60s} step {np.median(walls[v]):7.2f} us | " + "  ".join(f"{k} {val:6.2f}" for k, val in med.items()))
+
+
+if __name__ == "__main__":
+    main()
