@@ -42,6 +42,7 @@ struct nnpops_ani {
     bool fwd_identity = false;      // angular function m sits at canonical slot m: 16-byte stores of the row
     int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel
     int fwd_waves_per_atom = 2;     // 2: a 128-lane workgroup per atom (half the LDS per wave), 1: a wave per atom
+    int store_mode = 3;             // A/B: 0 plain, 1 sc1, 2 sc0 sc1, 3 nt stores of the angular rows
     bool occ6 = false;              // register budget of the two-wave kernels: 6 (80 VGPRs) or 5 (96) waves per SIMD
     int backward_kernel = 1;        // 1: two waves per atom, packed arithmetic (ani_angular_bwd.h), 0: the one-wave kernel
     int fwd_atoms_per_group = 1;    // > 1: every wave / workgroup walks that many atoms (amortises its prologue)
@@ -185,7 +186,8 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const int CH = h->fwd_chunk;
         const size_t lds2 = ang_fwd_mfma_lds_bytes<NFRP, NFZP>(h->cap_angular, CH);
         const int lw = (int)((lds2 + 15) & ~(size_t)15);
-        const int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)out & 15) == 0;
+        int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)out & 15) == 0;
+        if (vec_ok) vec_ok |= h->store_mode << 1;              // (bits above 0: flavour of the row stores)
         if (h->fwd_waves_per_atom == 2) {                      // a 128-lane workgroup per atom
             int groups = N;
             if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
@@ -364,6 +366,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_STORE")) h->store_mode = std::atoi(e) & 3;
         if (const char* e = std::getenv("NNPOPS_ANI_OCC")) h->occ6 = std::atoi(e) >= 6;
         if (const char* e = std::getenv("NNPOPS_ANI_BACKWARD")) h->backward_kernel = std::min(4, std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_WPA")) h->fwd_waves_per_atom = std::atoi(e) == 1 ? 1 : 2;
