@@ -42,6 +42,17 @@ struct nnpops_ani {
     bool fwd_identity = false;      // angular function m sits at canonical slot m: 16-byte stores of the row
     int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel
     int fwd_waves_per_atom = 2;     // 2: a 128-lane workgroup per atom (half the LDS per wave), 1: a wave per atom
+    // Atoms are evaluated in `nstreams` spans on as many HIP streams (fork after the cell grid, join before the caller's
+    // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
+    // the tail of every launch overlap with the steady state of the other spans' launches (two half-size evaluations on two
+    // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
+    bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
+    int fwd_occ = 7;                // A/B: register budget of the forward kernel (waves per SIMD)
+    int nstreams = 1;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    bool can_split = false;         // the selected kernels take atom ranges
+    int bwd_atoms_per_group = 1;    // one-wave backward kernel: atoms (waves) per workgroup
     int store_mode = 3;             // A/B: 0 plain, 1 sc1, 2 sc0 sc1, 3 nt stores of the angular rows
     bool occ6 = false;              // register budget of the two-wave kernels: 6 (80 VGPRs) or 5 (96) waves per SIMD
     int backward_kernel = 1;        // 1: two waves per atom, packed arithmetic (ani_angular_bwd.h), 0: the one-wave kernel
@@ -82,7 +93,8 @@ namespace {
 struct KernelTimer {
     nnpops_ani* h;
     int id;
-    KernelTimer(nnpops_ani* h_, int id_) : h(h_), id(id_) {
+    hipStream_t stream;
+    KernelTimer(nnpops_ani* h_, int id_, hipStream_t s_ = nullptr) : h(h_), id(id_), stream(s_ ? s_ : h_->stream) {
         if (!(h->timing_mask >> id & 1)) return;
         if (h->ev_used[id] == h->ev_start[id].size()) {
             hipEvent_t a, b;
@@ -92,12 +104,13 @@ struct KernelTimer {
             h->ev_start[id].push_back(a);
             h->ev_stop[id].push_back(b);
         }
-        (void)hipEventRecord(h->ev_start[id][h->ev_used[id]], h->stream);
+        slot = h->ev_used[id]++;
+        (void)hipEventRecord(h->ev_start[id][slot], stream);
     }
+    size_t slot = 0;
     ~KernelTimer() {
         if (!(h->timing_mask >> id & 1)) return;
-        (void)hipEventRecord(h->ev_stop[id][h->ev_used[id]], h->stream);
-        h->ev_used[id]++;
+        (void)hipEventRecord(h->ev_stop[id][slot], stream);
     }
 };
 
@@ -169,10 +182,18 @@ int alloc_rows(nnpops_ani* h) {
     return dev_alloc(&h->d_tri, (size_t)h->hp.N * triples_capacity(h->cap_angular));
 }
 
+// A contiguous stretch of the atoms, in cell order when the build used the cell grid (order = sorted atom ids) or in index
+// order (order = NULL), and the stream its kernels are launched on.
+struct Span {
+    hipStream_t stream;
+    const int* order;
+    int w0, nw;
+};
+
 // ---- kernel dispatch over (TORCHANI, NFRP, NFZP) ----
 template <bool TA, int NFRP, int NFZP>
-int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float* out) {
-    const int N = h->hp.N;
+int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float* out, const Span& sp) {
+    const int N = sp.nw;                                       // atoms of this launch
     const size_t lds = forward ? (h->chunked_forward ? ang_fwd_chunked_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB)
                                                     : ang_fwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB))
                                : ang_bwd_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, h->tile, h->compact_bwd);
@@ -187,14 +208,14 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const size_t lds2 = ang_fwd_mfma_lds_bytes<NFRP, NFZP>(h->cap_angular, CH);
         const int lw = (int)((lds2 + 15) & ~(size_t)15);
         int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)out & 15) == 0;
-        if (vec_ok) vec_ok |= h->store_mode << 1;              // (bits above 0: flavour of the row stores)
+        if (vec_ok) vec_ok |= (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);     // (bits 1-2: flavour of the row stores, bit 3: row assembled in LDS)
         if (h->fwd_waves_per_atom == 2) {                      // a 128-lane workgroup per atom
             int groups = N;
             if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
-            auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
+            auto k = h->fwd_occ == 6 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 6> : h->fwd_occ == 8 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 8> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
-            hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, h->stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw);
+            hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.order, sp.w0, sp.nw);
         } else {
             const int wpg2 = waves_per_group(lw);
             const size_t lg = (size_t)lw * wpg2;
@@ -202,8 +223,8 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             if (h->fwd_atoms_per_group > 1) groups = div_up(groups, h->fwd_atoms_per_group);
             auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 1, 5>;
             if (lg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
-            hipLaunchKernelGGL(k, dim3(groups), dim3(64 * wpg2), lg, h->stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw);
+            hipLaunchKernelGGL(k, dim3(groups), dim3(64 * wpg2), lg, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.order, sp.w0, sp.nw);
         }
     } else if (forward) {
         auto k = h->chunked_forward ? ani_angular_forward_chunked<TA, NFRP, NFZP> : ani_angular_forward<TA, NFRP, NFZP>;
@@ -219,15 +240,17 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const bool glds = mode == 2 || mode == 4;
         const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, glds) + 15) & ~(size_t)15;
         void (*k)(const AniParams*, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
-                  float4*, float4*, int, int, int) =
+                  float4*, float4*, int, int, int, const int*, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false> : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
           : mode == 2 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, true>
           : mode == 3 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false>
                       : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, true>;
-        if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-        const int threads = mode >= 3 ? 128 : 64;
-        hipLaunchKernelGGL(k, dim3(N), dim3(threads), lb, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, N, h->hp.NB);
+        const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
+        const int threads = mode >= 3 ? 128 : 64 * apg;
+        if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
+        hipLaunchKernelGGL(k, dim3(div_up(N, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
+                           sp.order, sp.w0, sp.nw);
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
@@ -240,23 +263,23 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
 }
 
 template <bool TA>
-int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out) {
+int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out, const Span& sp) {
     const int key = h->nfrp * 100 + h->nfzp;
     switch (key) {
-        case 404:  return launch_angular<TA, 4, 4>(h, forward, g, out);
-        case 408:  return launch_angular<TA, 4, 8>(h, forward, g, out);
-        case 804:  return launch_angular<TA, 8, 4>(h, forward, g, out);
-        case 808:  return launch_angular<TA, 8, 8>(h, forward, g, out);
-        case 1604: return launch_angular<TA, 16, 4>(h, forward, g, out);
-        case 1608: return launch_angular<TA, 16, 8>(h, forward, g, out);
+        case 404:  return launch_angular<TA, 4, 4>(h, forward, g, out, sp);
+        case 408:  return launch_angular<TA, 4, 8>(h, forward, g, out, sp);
+        case 804:  return launch_angular<TA, 8, 4>(h, forward, g, out, sp);
+        case 808:  return launch_angular<TA, 8, 8>(h, forward, g, out, sp);
+        case 1604: return launch_angular<TA, 16, 4>(h, forward, g, out, sp);
+        case 1608: return launch_angular<TA, 16, 8>(h, forward, g, out, sp);
         default:
             return fail(NNPOPS_ERR_UNSUPPORTED, "no angular kernel for %d x %d factors", h->hp.nFR, h->hp.nFZ);
     }
 }
 
 template <bool TA>
-int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out) {
-    const int N = h->hp.N;
+int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, const Span& sp) {
+    const int N = h->hp.N;                                     // (the generic forward kernel has no ranges: spans are never split)
     if (forward) {
         const int lw = (int)((ang_fwd_generic_lds_bytes(h->cap_angular) + 15) & ~(size_t)15);
         const int wpg = waves_per_group(lw);
@@ -267,17 +290,59 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out) {
         if (lb > 160 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "generic angular backward needs %zu bytes of LDS (cap_angular %d)", lb, h->cap_angular);
         auto k = ani_angular_backward_pair<TA, 4, 4, 4, 1, false, true>;
         if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, h->stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, N, h->hp.NB);
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+                           h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, h->hp.NB, (int)lb, nullptr, 0, N);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
 
-int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out) {
-    KernelTimer timer(h, forward ? NNPOPS_ANI_K_ANGULAR_FWD : NNPOPS_ANI_K_ANGULAR_BWD);
-    if (h->generic) return h->hp.torchani ? launch_generic<true>(h, forward, g, out) : launch_generic<false>(h, forward, g, out);
-    return h->hp.torchani ? dispatch_factors<true>(h, forward, g, out) : dispatch_factors<false>(h, forward, g, out);
+int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out, const Span& sp) {
+    KernelTimer timer(h, forward ? NNPOPS_ANI_K_ANGULAR_FWD : NNPOPS_ANI_K_ANGULAR_BWD, sp.stream);
+    if (h->generic) return h->hp.torchani ? launch_generic<true>(h, forward, g, out, sp) : launch_generic<false>(h, forward, g, out, sp);
+    return h->hp.torchani ? dispatch_factors<true>(h, forward, g, out, sp) : dispatch_factors<false>(h, forward, g, out, sp);
+}
+
+bool pair_backward_fits(const nnpops_ani* h) {
+    const size_t m = (size_t)h->cap_angular * (h->cap_angular + 1) + (size_t)h->cap_angular * (h->cap_angular - 1) / 2;
+    return (size_t)h->cap_angular * 32 + (size_t)h->hp.NB * h->nfrp * h->nfzp * 4 + m * 4 <= 160 * 1024;
+}
+
+// The spans of one evaluation: nstreams stretches of the (cell-ordered) atoms when the kernels in use take ranges, else one.
+int make_spans(nnpops_ani* h, Span (&spans)[4]) {
+    const int N = h->hp.N;
+    const int* order = h->last_used_cells ? h->d_sorted_atom : nullptr;
+    int k = h->can_split && N >= 2048 ? std::max(1, std::min(4, h->nstreams)) : 1;
+    if (k > 1 && (!h->ev_fork || !h->side[k - 2])) {           // first use: streams cannot be created while the caller captures a graph
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) k = 1;
+    }
+    for (int q = 1; q < k; q++) {                              // side streams and fork / join events, created on first use
+        if (!h->side[q - 1] && hipStreamCreateWithFlags(&h->side[q - 1], hipStreamNonBlocking) != hipSuccess) k = 1;
+        if (k > 1 && !h->ev_join[q - 1] && hipEventCreateWithFlags(&h->ev_join[q - 1], hipEventDisableTiming) != hipSuccess) k = 1;
+    }
+    if (k > 1 && !h->ev_fork && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) k = 1;
+    const int per = ((N + k - 1) / k + 3) & ~3;                // (whole workgroups of up to four atoms)
+    for (int q = 0; q < k; q++) {
+        const int w0 = std::min(N, q * per), w1 = q == k - 1 ? N : std::min(N, (q + 1) * per);
+        spans[q] = Span{q == 0 ? h->stream : h->side[q - 1], order, w0, w1 - w0};
+    }
+    return k;
+}
+
+int fork_streams(nnpops_ani* h, const Span* spans, int k) {
+    if (k <= 1) return NNPOPS_OK;
+    NNPOPS_HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    for (int q = 1; q < k; q++) NNPOPS_HIP_TRY(hipStreamWaitEvent(spans[q].stream, h->ev_fork, 0));
+    return NNPOPS_OK;
+}
+
+int join_streams(nnpops_ani* h, const Span* spans, int k) {
+    for (int q = 1; q < k; q++) {
+        NNPOPS_HIP_TRY(hipEventRecord(h->ev_join[q - 1], spans[q].stream));
+        NNPOPS_HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[q - 1], 0));
+    }
+    return NNPOPS_OK;
 }
 
 }  // namespace
@@ -366,6 +431,10 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_OCC")) h->fwd_occ = std::atoi(e);
+        if (const char* e = std::getenv("NNPOPS_ANI_STREAMS")) h->nstreams = std::max(1, std::min(4, std::atoi(e)));
+        if (const char* e = std::getenv("NNPOPS_ANI_BWD_APG")) h->bwd_atoms_per_group = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_STORE")) h->store_mode = std::atoi(e) & 3;
         if (const char* e = std::getenv("NNPOPS_ANI_OCC")) h->occ6 = std::atoi(e) >= 6;
         if (const char* e = std::getenv("NNPOPS_ANI_BACKWARD")) h->backward_kernel = std::min(4, std::max(0, std::atoi(e)));
@@ -448,6 +517,11 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
     dev_free(h->d_atom_rank); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
+    for (int q = 0; q < 3; q++) {
+        if (h->side[q]) (void)hipStreamDestroy(h->side[q]);
+        if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
         for (hipEvent_t e : h->ev_start[k]) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ev_stop[k]) (void)hipEventDestroy(e);
@@ -521,7 +595,7 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
     const int lds_bw = (int)((builder_lds_bytes(h->cap, h->hp.S, h->hp.NB) + 15) & ~(size_t)15);
     const int wpg_b = waves_per_group(lds_bw);
     const size_t lds_b = (size_t)lds_bw * wpg_b;
-    const dim3 agrid(div_up(N, wpg_b)), ablock(64 * wpg_b);
+    const dim3 ablock(64 * wpg_b);
     const bool use_cells = !h->d_segment && (h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled));
     h->last_used_cells = use_cells;
     if (use_cells) {
@@ -531,31 +605,44 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
                              h->d_hist, h->d_bins, h->bin_cap};
         launch_cell_build(h->stream, N, positions, box, per, h->hp.rcr, h->d_species, cb);
     }
-    {
-    KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS);
-    if (use_cells) {
-        if (per)
-            hipLaunchKernelGGL(ani_neighbors_cells<true>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
-                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist);
+    // The per-atom kernels, span by span: every span's chain (neighbour build -> angular forward) runs on its own stream.
+    h->can_split = !h->generic && h->forward_kernel == 2 && h->backward_kernel >= 1 &&
+                   pair_backward_fits(h);
+    Span spans[4];
+    const int nspans = make_spans(h, spans);
+    int rc = fork_streams(h, spans, nspans);
+    if (rc != NNPOPS_OK) return rc;
+    for (int q = 0; q < nspans; q++) {
+        const Span& sp = spans[q];
+        const dim3 sgrid(div_up(sp.nw, wpg_b));
+        {
+        KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
+        if (use_cells) {
+            if (per)
+                hipLaunchKernelGGL(ani_neighbors_cells<true>, sgrid, ablock, lds_b, sp.stream, h->d_params, box, h->d_grid,
+                                   h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
+                                   h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist,
+                                   sp.w0, sp.nw);
+            else
+                hipLaunchKernelGGL(ani_neighbors_cells<false>, sgrid, ablock, lds_b, sp.stream, h->d_params, box, h->d_grid,
+                                   h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
+                                   h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist,
+                                   sp.w0, sp.nw);
+        } else if (per)
+            hipLaunchKernelGGL(ani_neighbors_allpairs<true>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
+                               h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
+                               h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
         else
-            hipLaunchKernelGGL(ani_neighbors_cells<false>, agrid, ablock, lds_b, h->stream, h->d_params, box, h->d_grid,
-                               h->d_cell_start, h->d_atom_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                               h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist);
-    } else if (per)
-        hipLaunchKernelGGL(ani_neighbors_allpairs<true>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
-                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw);
-    else
-        hipLaunchKernelGGL(ani_neighbors_allpairs<false>, agrid, ablock, lds_b, h->stream, h->d_params, positions, box,
-                           h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw);
+            hipLaunchKernelGGL(ani_neighbors_allpairs<false>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
+                               h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
+                               h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
+        }
+        NNPOPS_HIP_TRY(hipGetLastError());
+        // (the radial AEV is written by the builder wave itself: radial_forward_from_lds)
+        rc = dispatch_angular(h, true, nullptr, angular, sp);
+        if (rc != NNPOPS_OK) return rc;
     }
-    NNPOPS_HIP_TRY(hipGetLastError());
-
-    // (the radial AEV is written by the builder wave itself: radial_forward_from_lds)
-
-    int rc = dispatch_angular(h, true, nullptr, angular);
+    rc = join_streams(h, spans, nspans);
     if (rc != NNPOPS_OK) return rc;
     h->computed = true;
     return NNPOPS_OK;
@@ -584,17 +671,30 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     const int wpg_r = waves_per_group(lds_rw);
     const size_t lds_r = (size_t)lds_rw * wpg_r;
     if (lds_r > 64 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "radial backward needs %zu bytes of LDS", lds_r);
-    const dim3 agrid(div_up(N, wpg_r)), ablock(64 * wpg_r);
-    // 1. angular backward parks the per-leg forces in leg_force / centre_force (no scatter) ...
-    int rc = dispatch_angular(h, false, angular_deriv, nullptr);
+    const dim3 ablock(64 * wpg_r);
+    // 1. angular backward parks the per-leg forces in leg_force / centre_force (no scatter), span by span on the streams ...
+    Span spans[4];
+    const int nspans = make_spans(h, spans);
+    int rc = fork_streams(h, spans, nspans);
+    if (rc != NNPOPS_OK) return rc;
+    for (int q = 0; q < nspans; q++) {
+        rc = dispatch_angular(h, false, angular_deriv, nullptr, spans[q]);
+        if (rc != NNPOPS_OK) return rc;
+    }
+    rc = join_streams(h, spans, nspans);                       // (every leg force must be there before anybody gathers)
     if (rc != NNPOPS_OK) return rc;
     // 2. ... and the radial backward wave of every atom, the only writer of position_deriv[i], gathers them
-    {
-    KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD);
-    hipLaunchKernelGGL(ani_radial_backward, agrid, ablock, lds_r, h->stream, h->d_params, h->d_species, h->d_nbr, h->cap,
-                       h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
-                       h->last_used_cells ? h->d_sorted_atom : nullptr, position_deriv, lds_rw);
+    rc = fork_streams(h, spans, nspans);
+    if (rc != NNPOPS_OK) return rc;
+    for (int q = 0; q < nspans; q++) {
+        const Span& sp = spans[q];
+        KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD, sp.stream);
+        hipLaunchKernelGGL(ani_radial_backward, dim3(div_up(sp.nw, wpg_r)), ablock, lds_r, sp.stream, h->d_params, h->d_species, h->d_nbr, h->cap,
+                           h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
+                           sp.order, position_deriv, lds_rw, sp.w0, sp.nw);
     }
+    rc = join_streams(h, spans, nspans);
+    if (rc != NNPOPS_OK) return rc;
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }

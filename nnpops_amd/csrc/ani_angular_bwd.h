@@ -107,16 +107,20 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 // GENERIC: the function list does not factor (ani_angular_generic.h): functions evaluated one by one, gradients read from
 // global memory in the caller's order (GLDS must be false, NFRP / NFZP are not used).
 template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false>
-__global__ __launch_bounds__(64 * WPA, OCC) void ani_angular_backward_pair(
+__global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
     const AniParams* __restrict__ P, int cap, int capA, const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
     const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
     const float* __restrict__ angular_grad, int ld_angular, float4* __restrict__ leg_force, float4* __restrict__ centre_force,
-    int vec_ok, int N, int NB) {
+    int vec_ok, int NB, int lds_per_atom, const int* __restrict__ order, int w0, int nw) {     // positions [w0, w0 + nw) of `order`
     constexpr int BLK = NFRP * NFZP;
     constexpr int NT = 64 * WPA;                               // lanes of the workgroup
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = lane_id();
-    const int role = WPA == 2 ? __builtin_amdgcn_readfirstlane(wave_in_group()) : 0;
+    const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());
+    const int role = WPA == 2 ? wig : 0;
+    // one wave per atom: a workgroup holds blockDim / 64 independent atoms (fewer, larger dispatches), each with its own LDS slice
+    const int atoms_per_group = WPA == 2 ? 1 : (int)(blockDim.x >> 6);
+    const int slot_in_group = WPA == 2 ? 0 : wig;
     const int nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
     const int tile = capA, tstride = capA + 1;
     auto sync = [&]() {
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(64 * WPA, OCC) void ani_angular_backward_pair(
         else wave_fence();
     };
 
-    char* cursor = lds_raw;
+    char* cursor = lds_raw + (size_t)slot_in_group * lds_per_atom;
     float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
     float* grow = (float*)cursor;         if (GLDS) cursor += (size_t)NB * BLK * sizeof(float);   // upstream gradient row, canonical [bucket][a][z]
@@ -147,7 +151,10 @@ __global__ __launch_bounds__(64 * WPA, OCC) void ani_angular_backward_pair(
         zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;
     }
 
-    for (int i = blockIdx.x; i < N; i += gridDim.x) {
+    const int stride_atoms = gridDim.x * atoms_per_group;
+    for (int w = blockIdx.x * atoms_per_group + slot_in_group; w < nw; w += stride_atoms) {
+        int i = order ? order[w0 + w] : w0 + w;
+        if ((unsigned)i >= (unsigned)P->N) i = w0 + w;         // (a void grid build leaves no valid order: stay in bounds)
         int n, nro;
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
         if (n < 2) {                                           // no triples (uniform for the workgroup): a lone leg carries no force
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(64 * WPA, OCC) void ani_angular_backward_pair(
             cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
             if (lane == 0) centre_force[i] = make_float4(cx, cy, cz, 0.f);
         }
-        if (i + (int)gridDim.x < N) sync();                    // (another atom follows: the LDS arrays must be free)
+        if (w + stride_atoms < nw) sync();                    // (another atom follows: the LDS arrays must be free)
     }
 }
 

@@ -76,12 +76,13 @@ template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
     const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
-    const int* __restrict__ cnt_ro, float* __restrict__ angular, int ld_angular, int vec_ok, int lds_per_atom) {
+    const int* __restrict__ cnt_ro, float* __restrict__ angular, int ld_angular, int vec_ok, int lds_per_atom,
+    const int* __restrict__ order, int w0, int nw) {      // this launch covers positions [w0, w0 + nw) of `order` (NULL: atom = position)
     constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
     constexpr int NS = 2 / WPA;                                // quad sets run by this wave
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = lane_id();
-    const int N = P->N, NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
+    const int NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
     const int K = P->fwd_split, logK = 31 - __builtin_clz(K);
 
     const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());        // wave-uniform: keeps per-atom addressing scalar
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
 
     const int natoms_group = WPA == 2 ? 1 : (blockDim.x >> 6);
     const int stride_atoms = gridDim.x * natoms_group;
-    for (int i = blockIdx.x * natoms_group + slot_in_group; i < N; i += stride_atoms) {
+    for (int w = blockIdx.x * natoms_group + slot_in_group; w < nw; w += stride_atoms) {
+        int i = order ? order[w0 + w] : w0 + w;
+        if ((unsigned)i >= (unsigned)P->N) i = w0 + w;         // (a void grid build leaves no valid order: stay in bounds)
         int n, nro;
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
         const int T = (n * (n - 1)) / 2;
@@ -250,45 +253,78 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         // ---------------- epilogue: registers -> the atom's output row ----------------
         // register r of lane (quad, nn) of block (zh, rh) is canonical slot (a = nn + 4 rh, z = r + 4 zh) of the quad's bucket
         float* out = angular + (size_t)i * ld_angular;
+        const bool via_lds = vec_ok && (vec_ok & 8) && NB * nA <= CH * REC;
+        if (via_lds) {
+            // The row is assembled in LDS (the staging area is free now) and leaves as whole 1 KB wave stores: a quad holds
+            // 64-byte halves of 128-byte blocks, and stores of that shape reached memory as partial lines (47.9 MB of write
+            // traffic for 35.8 MB of rows, profiles/r02b_hbm_traffic_pmc.txt).
+            float* rowbuf = fac;
+            constexpr int NT = 64 * WPA;
+            const int tid = role * 64 + lane, pieces = (NB * nA) >> 2;
+            const int nabs = P->fwd_nabsent;
+            sync();                                            // every wave is done with the staged factors
+            if (nabs > 0) {                                    // blocks nobody owns are zero
+                for (int q = tid; q < pieces; q += NT) reinterpret_cast<float4*>(rowbuf)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                sync();
+            }
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            if (sbk[s] < 0 || spart[s] != 0) continue;
-            float* ob = out + sbk[s] * nA;
+            for (int s = 0; s < NS; s++) {
+                if (sbk[s] < 0 || spart[s] != 0) continue;
 #pragma unroll
-            for (int zh = 0; zh < NZ4; zh++)
+                for (int zh = 0; zh < NZ4; zh++)
 #pragma unroll
-                for (int rh = 0; rh < NR4; rh++) {
-                    const int c = (nn + 4 * rh) * NFZP + 4 * zh;
-                    const mfma_f4 v = acc[s][zh][rh];
-                    if (vec_ok) {                              // function m sits at canonical slot m: one 16-byte store
-                        store_row16(ob + c, v, vec_ok >> 1);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int m = P->m_of_c[c + r];
-                            if (m >= 0) ob[m] = v[r];
+                    for (int rh = 0; rh < NR4; rh++) {
+                        const mfma_f4 v = acc[s][zh][rh];
+                        *reinterpret_cast<float4*>(rowbuf + sbk[s] * nA + (nn + 4 * rh) * NFZP + 4 * zh) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+            }
+            sync();
+            for (int q = tid; q < pieces; q += NT) {
+                const float4 v = reinterpret_cast<const float4*>(rowbuf)[q];
+                store_row16(out + 4 * q, mfma_f4{v.x, v.y, v.z, v.w}, (vec_ok >> 1) & 3);
+            }
+        } else {
+            float* out = angular + (size_t)i * ld_angular;
+    #pragma unroll
+            for (int s = 0; s < NS; s++) {
+                if (sbk[s] < 0 || spart[s] != 0) continue;
+                float* ob = out + sbk[s] * nA;
+    #pragma unroll
+                for (int zh = 0; zh < NZ4; zh++)
+    #pragma unroll
+                    for (int rh = 0; rh < NR4; rh++) {
+                        const int c = (nn + 4 * rh) * NFZP + 4 * zh;
+                        const mfma_f4 v = acc[s][zh][rh];
+                        if (vec_ok) {                              // function m sits at canonical slot m: one 16-byte store
+                            store_row16(ob + c, v, (vec_ok >> 1) & 3);
+                        } else {
+    #pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int m = P->m_of_c[c + r];
+                                if (m >= 0) ob[m] = v[r];
+                            }
                         }
                     }
-                }
-        }
-        // species pairs that cannot occur in this system have no quad: their blocks are zero
-        const int nabs = P->fwd_nabsent;
-        if (nabs > 0 && role == 0) {
-            if (vec_ok) {                                      // 2^fwd_zero_shift lanes per block, one 16-byte piece each
-                const int sh = P->fwd_zero_shift, piece = lane & ((1 << sh) - 1), per_pass = 64 >> sh;
-                for (int a0 = 0; a0 < nabs; a0 += per_pass) {
-                    const int a = a0 + (lane >> sh);
-                    if (a < nabs && piece * 4 < nA)
-                        *reinterpret_cast<float4*>(out + P->fwd_absent[a] * nA + piece * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            } else {
-                for (int a = 0; a < nabs; a++) {
-                    float* ob = out + P->fwd_absent[a] * nA;
-                    for (int m = lane; m < nA; m += 64) ob[m] = 0.f;
+            }
+            // species pairs that cannot occur in this system have no quad: their blocks are zero
+            const int nabs = P->fwd_nabsent;
+            if (nabs > 0 && role == 0) {
+                if (vec_ok) {                                      // 2^fwd_zero_shift lanes per block, one 16-byte piece each
+                    const int sh = P->fwd_zero_shift, piece = lane & ((1 << sh) - 1), per_pass = 64 >> sh;
+                    for (int a0 = 0; a0 < nabs; a0 += per_pass) {
+                        const int a = a0 + (lane >> sh);
+                        if (a < nabs && piece * 4 < nA)
+                            *reinterpret_cast<float4*>(out + P->fwd_absent[a] * nA + piece * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    for (int a = 0; a < nabs; a++) {
+                        float* ob = out + P->fwd_absent[a] * nA;
+                        for (int m = lane; m < nA; m += 64) ob[m] = 0.f;
+                    }
                 }
             }
         }
-        if (i + stride_atoms < N) sync();                      // (another atom follows: records and staging area must be free)
+        if (w + stride_atoms < nw) sync();                     // (another atom follows: records and staging area must be free)
     }
 }
 

@@ -381,15 +381,15 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
                                                              float4* __restrict__ recB, int* __restrict__ ids,
                                                              int* __restrict__ tri,
                                                              int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
-                                                             float* __restrict__ radial, int ld_radial, int lds_per_wave) {
+                                                             float* __restrict__ radial, int ld_radial, int lds_per_wave, int w0, int nw) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
     const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap + 64 * P->S), P->S, P->NB);
-    const int i = wave_global_id();
+    if (wave_global_id() >= nw) return;
+    const int i = w0 + wave_global_id();                   // this launch covers atoms [w0, w0 + nw)
     const int lane = lane_id();
     const int N = P->N;
-    if (i >= N) return;
     const float rcr2 = P->rcr2, rca2 = P->rca2;
     Box b{};
     if (PERIODIC) b = load_box(box);
@@ -437,15 +437,15 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           int* __restrict__ tri,
                                                           int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
                                                           int* __restrict__ status, float* __restrict__ radial,
-                                                          int ld_radial, int lds_per_wave, int* __restrict__ cell_hist) {
+                                                          int ld_radial, int lds_per_wave, int* __restrict__ cell_hist, int slot0, int nslots) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     float* rscratch = (float*)(stage + cap);
     const AtomGroups G = carve_groups((int*)(rscratch + 3 * cap + 64 * P->S), P->S, P->NB);
     const int lane = lane_id();
-    const int slot_id = wave_global_id();                  // position in cell order
+    const int slot_id = slot0 + wave_global_id();          // position in cell order; this launch covers [slot0, slot0 + nslots)
     clear_cell_histogram(cell_hist);
-    if (slot_id >= P->N) return;
+    if (wave_global_id() >= nslots) return;
     const CellGrid g = *grid;
     if (!g.ok) {                                           // box too small for the stencil: tell the host
         if (lane == 0) {
@@ -515,14 +515,15 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
                                                           const float4* __restrict__ leg_force,
                                                           const float4* __restrict__ centre_force,
                                                           const int* __restrict__ order,     // atoms in cell order, or NULL
-                                                          float* __restrict__ pos_grad, int lds_per_wave) {
+                                                          float* __restrict__ pos_grad, int lds_per_wave, int w0, int nw) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float* lds = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
     const int lane = lane_id();
     // This kernel gathers rows of its atom's NEIGHBOURS (gradient rows, id rows, leg forces).  Atoms are walked in
     // cell order, an XCD-contiguous stretch per XCD, so that those rows are fetched into one L2 instead of eight.
-    const int w = order ? xcd_contiguous_wave_id() : wave_global_id();
-    if (w >= P->N) return;
+    const int wl = order ? xcd_contiguous_wave_id() : wave_global_id();      // this launch covers positions [w0, w0 + nw)
+    if (wl >= nw) return;
+    const int w = w0 + wl;
     int i = order ? order[w] : w;
     if ((unsigned)i >= (unsigned)P->N) i = w;              // (a void grid build leaves no valid order: stay in bounds)
     const int S = P->S, nR = P->nR, width = S * nR;
