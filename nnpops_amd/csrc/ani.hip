@@ -46,6 +46,7 @@ struct nnpops_ani {
     // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
     // the tail of every launch overlap with the steady state of the other spans' launches (two half-size evaluations on two
     // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
+    bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
     int fwd_occ = 7;                // A/B: register budget of the forward kernel (waves per SIMD)
     int nstreams = 1;
@@ -378,6 +379,9 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     hp.rcr = radial_cutoff; hp.rca = angular_cutoff;
     hp.rcr2 = radial_cutoff * radial_cutoff; hp.rca2 = angular_cutoff * angular_cutoff;
     hp.radial_scale = torchani ? 0.25f : 1.0f;
+    hp.inv_rcr = 1.0f / radial_cutoff; hp.inv_rca = 1.0f / angular_cutoff;
+    hp.kp_shift = 0;
+    while ((1 << hp.kp_shift) < num_radial) hp.kp_shift++;
     hp.angle_damp = torchani ? 0.95f : 1.0f;
     for (int k = 0; k < num_radial; k++) {
         hp.rad_eta[k] = radial_eta_rs[2 * k];
@@ -431,6 +435,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_OCC")) h->fwd_occ = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_STREAMS")) h->nstreams = std::max(1, std::min(4, std::atoi(e)));
@@ -602,7 +607,7 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
         KernelTimer timer(h, NNPOPS_ANI_K_CELL_GRID);
         const CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank,
                              h->d_unsorted_atom, h->d_sorted_atom, h->d_sorted_pos, h->max_cells,
-                             h->d_hist, h->d_bins, h->bin_cap};
+                             h->d_hist, h->d_bins, h->bin_cap, h->fine_grid ? 1 : 0};
         launch_cell_build(h->stream, N, positions, box, per, h->hp.rcr, h->d_species, cb);
     }
     // The per-atom kernels, span by span: every span's chain (neighbour build -> angular forward) runs on its own stream.

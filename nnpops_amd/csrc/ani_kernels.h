@@ -52,6 +52,8 @@ struct AniParams {
     int N, S, nR, nA, NB, nFR, nFZ;
     int periodic, torchani;
     float rcr, rca, rcr2, rca2;
+    float inv_rcr, inv_rca;          // 1 / cutoff, rounded once on the host
+    int kp_shift;                    // log2 of KP, the smallest power of two >= nR (lane = (stream, k) layouts)
     float radial_scale;              // 0.25 (TorchANI) or 1          ref :99-103
     float angle_damp;                // 0.95 (TorchANI) or 1          ref :391-392
     float rad_c[kMaxRadialFns];      // -eta_k * log2(e)
@@ -172,14 +174,9 @@ __device__ __forceinline__ int build_bucket_offsets(int NB, const AtomGroups& G)
             const int ga = G.gn[A], gb = G.gn[B];
             c = (A == B) ? (ga * (ga - 1)) / 2 : ga * gb;
         }
-        int incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
-        }
+        const int incl = wave_prefix_sum(c);
         if (bk < NB) G.boff[bk] = carry + incl - c;
-        carry += __shfl(incl, 63, 64);
+        carry += __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) G.boff[NB] = carry;
     wave_fence();
@@ -248,7 +245,7 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
                                                  int* __restrict__ boff_out, const AtomGroups& G) {
     const int lane = lane_id();
     const int S = P->S, NB = P->NB;
-    const float inv_rca = 1.0f / P->rca;
+    const float inv_rca = P->inv_rca;
     for (int bk = lane; bk < NB; bk += 64) { G.ba[bk] = P->bkt_a[bk]; G.bb[bk] = P->bkt_b[bk]; }
     auto emit = [&](const float4& r4, int rank) {
         const float r = fast_sqrt(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);       // ~1 ulp, like everything downstream
@@ -329,9 +326,10 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
     const int S = P->S, nR = P->nR;
     float* nb_r = scratch;                   // [cap]
     float* nb_fc = nb_r + cap;               // [cap]
-    int* nb_sp = (int*)(nb_fc + cap);        // [cap]
+    int* nb_bin = (int*)(nb_fc + cap);       // [cap]  species * KP: where this neighbour's bins start inside a stream
     const int total = na + nro;
-    const float inv_rcr = 1.0f / P->rcr;
+    const float inv_rcr = P->inv_rcr;
+    const int kshift = P->kp_shift, KP = 1 << kshift;
     for (int e = lane; e < total; e += 64) {
         const float4 rec = e < na ? stage[e] : stage[cap - 1 - (e - na)];
         const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
@@ -339,32 +337,38 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
         float sn_unused, cs;
         sincospi_unit(r * inv_rcr, sn_unused, cs);
         nb_fc[e] = 0.5f * cs + 0.5f;
-        nb_sp[e] = __float_as_int(rec.w) >> kTagShift;
+        nb_bin[e] = (__float_as_int(rec.w) >> kTagShift) << kshift;
     }
-    wave_fence();
 
-    // lanes = (stream, k): KP = smallest power of two >= nR.  Every (stream, species, k) has a private LDS bin,
-    // so the scatter by species is one plain read-modify-write per neighbour (LDS operations of a wave execute
-    // in order: back-to-back hits on one bin are safe) instead of a compare/select per species in registers.
-    int KP = 1;
-    while (KP < nR) KP <<= 1;
-    const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
+    // lanes = (stream, k): KP = smallest power of two >= nR.  Every (stream, species, k) has a private LDS bin, so
+    // the scatter by species is one plain read-modify-write per neighbour (LDS operations of a wave execute in
+    // order: back-to-back hits on one bin are safe) instead of a compare/select per species in registers.  The next
+    // neighbour is read before the bin of this one (LDS float atomics would need no read at all, but they run at a
+    // fraction of the rate: 65 us instead of 26 for the kernel).
+    const int k = lane & (KP - 1), stream = lane >> kshift, nstreams = 64 >> kshift;
     const float ck = P->rad_c[min(k, nR - 1)], rs = P->rad_rs[min(k, nR - 1)];
-    float* bins = (float*)(nb_sp + cap);               // [nstreams][S][KP] = 64 * S floats
+    float* bins = (float*)(nb_bin + cap);              // [nstreams][S][KP] = 64 * S floats
     for (int s = 0; s < S; s++) bins[s * 64 + lane] = 0.f;
     wave_fence();
     float* mine = bins + stream * S * KP + k;
-    for (int e = stream; e < total; e += nstreams) {
-        const float sh = nb_r[e] - rs;
-        mine[nb_sp[e] * KP] += nb_fc[e] * fast_exp2(ck * sh * sh);
+    int e = stream;
+    float r = 0.f, fc = 0.f;
+    int bin = 0;
+    if (e < total) { r = nb_r[e]; fc = nb_fc[e]; bin = nb_bin[e]; }
+    while (e < total) {
+        const float sh = r - rs, w = fc;
+        float* dst = mine + bin;
+        e += nstreams;
+        if (e < total) { r = nb_r[e]; fc = nb_fc[e]; bin = nb_bin[e]; }
+        *dst += w * fast_exp2(ck * sh * sh);
     }
     wave_fence();
     const float scale = P->radial_scale;
-    for (int q = lane; q < S * nR; q += 64) {
-        const int sp = q / nR, kk = q - sp * nR;
+    for (int q = lane; q < S * KP; q += 64) {              // q = species * KP + k: the bins of stream 0
+        const int sp = q >> kshift, kk = q & (KP - 1);
         float v = 0.f;
-        for (int st = 0; st < nstreams; st++) v += bins[(st * S + sp) * KP + kk];
-        out[q] = v * scale;
+        for (int st = 0; st < nstreams; st++) v += bins[st * S * KP + q];
+        if (kk < nR) out[sp * nR + kk] = v * scale;
     }
 }
 
@@ -461,32 +465,28 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     const float4 me = sorted_pos[slot_id];
     const int i = __float_as_int(me.w) & kIdMask;
     const int c = atom_cell[i];
-    const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+    // cell coordinates without integer division: (c + 1/2) / n rounds down correctly for every grid that fits (c < 2^20)
+    const int nxy = g.nx * g.ny;
+    const int cz = (int)(((float)c + 0.5f) * fast_rcp((float)nxy));
+    const int rem = c - cz * nxy;
+    const int cy = (int)(((float)rem + 0.5f) * fast_rcp((float)g.nx));
+    const int cx = rem - cy * g.nx;
     float4* row = nbr + (size_t)i * cap;
     int na = 0, nro = 0;
-    const Stencil st = gather_stencil(g, cell_start, cx, cy, cz);
-    // (stencil_slot reads other lanes' registers: every lane calls it, out-of-range lanes with a clamped index)
-    const int last = max(st.total - 1, 0);
-    float4 pj = sorted_pos[stencil_slot(st, min(lane, last))];
+    const WideStencil st = gather_wide_stencil(g, cell_start, cx, cy, cz);
+    int* strip = (int*)rscratch;                           // the radial scratch is idle during the scan
+    int carry = 0;
+    float4 pj = sorted_pos[wide_stencil_slot(st, 0, strip, carry)];
     for (int base = 0; base < st.total; base += 64) {
-        const int k = base + lane;
         const float4 cur = pj;
-        const int next_slot = stencil_slot(st, min(k + 64, last));
-        if (base + 64 < st.total) pj = sorted_pos[next_slot];                                   // next batch in flight
-        bool in_r = false, in_a = false;
-        int word = 0;
-        float dx = 0.f, dy = 0.f, dz = 0.f;
-        if (k < st.total) {
-            word = __float_as_int(cur.w);
-            if ((word & kIdMask) != i) {
-                dx = cur.x - me.x; dy = cur.y - me.y; dz = cur.z - me.z;
-                min_image<PERIODIC>(dx, dy, dz, b);
-                const float r2 = dx * dx + dy * dy + dz * dz;
-                in_r = r2 < rcr2;
-                in_a = in_r && (r2 < rca2);
-            }
-        }
-        append_to_row(cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
+        if (base + 64 < st.total) pj = sorted_pos[wide_stencil_slot(st, base + 64, strip, carry)];   // next batch in flight
+        const int word = __float_as_int(cur.w);
+        float dx = cur.x - me.x, dy = cur.y - me.y, dz = cur.z - me.z;
+        min_image<PERIODIC>(dx, dy, dz, b);
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        const bool in_r = (base + lane < st.total) & ((word & kIdMask) != i) & (r2 < rcr2);
+        const bool in_a = in_r & (r2 < rca2);
+        append_to_row(cap, stage, in_a, in_r & !in_a, dx, dy, dz, word, na, nro);
     }
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     clamp_counts(cnt_a[i], cnt_ro[i], cap, cap_angular, na, nro);
     const int total = na + nro;
     const float4* row = nbr + (size_t)i * cap;
-    const float inv_rcr = 1.0f / P->rcr;
+    const float inv_rcr = P->inv_rcr;
     const int si = species[i];
 
     const float* gi = radial_grad + (size_t)i * ld_radial;
@@ -574,9 +574,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
         for (int q = 0; q < 8; q++) idv[q] = idrow[q];
     }
 
-    int KP = 1;
-    while (KP < nR) KP <<= 1;
-    const int k = lane & (KP - 1), stream = lane / KP, nstreams = 64 / KP;
+    const int KP = 1 << P->kp_shift;
+    const int k = lane & (KP - 1), stream = lane >> P->kp_shift, nstreams = 64 >> P->kp_shift;
     float fx = 0.f, fy = 0.f, fz = 0.f;
     if (k < nR) {
         const float ck = P->rad_c[k], rs = P->rad_rs[k], eta = P->rad_eta[k];

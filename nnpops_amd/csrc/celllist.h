@@ -27,6 +27,7 @@ constexpr int kIdMask = (1 << kTagShift) - 1;
 struct CellGrid {
     int nx, ny, nz, ncells;
     int periodic;
+    int m;                  // stencil half-width in cells: cells are at least cutoff / m wide (1, or 2 for the fine grid)
     int ok;                 // 0: the stencil would be invalid for this box (too few cells), or a bin overflowed
     int bin_overflow;       // 1: ok was cleared because a cell holds more atoms than the bins of the two-kernel build
     // lattice coordinates: sz = (z-oz)*izz; sy = ((y-oy) - sz*cy)*iyy; sx = ((x-ox) - sy*bx - sz*cx)*ixx
@@ -50,11 +51,14 @@ __device__ __forceinline__ void cell_of(const CellGrid& g, float x, float y, flo
 }
 
 // The grid for a box (periodic) or a bounding box lo..hi (non-periodic): the largest dims whose cells are at
-// least `cutoff` wide, capped at max_cells.
+// least `cutoff` wide, capped at max_cells.  `fine`: prefer cells of half the cutoff (a 5x5x5 stencil holds 58 % of
+// the volume of the 3x3x3 one of full-width cells, so a consumer tests 42 % fewer candidates) when such a grid has
+// at most max_cells cells and, in a periodic box, at least 5 cells along every axis; g.m says which it is.
 __device__ inline CellGrid decide_grid(int periodic, const float* __restrict__ box, const float* lo, const float* hi,
-                                       float cutoff, int max_cells) {
+                                       float cutoff, int max_cells, int fine = 0) {
     CellGrid g;
     g.periodic = periodic;
+    g.m = 1;
     g.ok = 1;
     g.bin_overflow = 0;
     float wx, wy, wz;      // perpendicular widths of the cell-able region
@@ -78,6 +82,16 @@ __device__ inline CellGrid decide_grid(int periodic, const float* __restrict__ b
     // largest dims with cell width >= cutoff (a hair of slack for rounding in cell_of)
     const float c = cutoff * 1.0001f;
     int nx = max(1, (int)floorf(wx / c)), ny = max(1, (int)floorf(wy / c)), nz = max(1, (int)floorf(wz / c));
+    if (fine) {
+        const float h = 0.5f * c;
+        const int fx = max(1, (int)floorf(wx / h)), fy = max(1, (int)floorf(wy / h)), fz = max(1, (int)floorf(wz / h));
+        if ((long long)fx * fy * fz <= max_cells && (!periodic || (fx >= 5 && fy >= 5 && fz >= 5))) {
+            g.m = 2;
+            g.nx = fx; g.ny = fy; g.nz = fz;
+            g.ncells = fx * fy * fz;
+            return g;
+        }
+    }
     if (periodic && (nx < 3 || ny < 3 || nz < 3)) g.ok = 0;
     // cap the total cell count (sparse systems): coarser cells are always valid
     while ((long long)nx * ny * nz > max_cells) {
@@ -95,7 +109,7 @@ __device__ inline CellGrid decide_grid(int periodic, const float* __restrict__ b
 // One block of 256 threads.
 static __global__ __launch_bounds__(256) void grid_setup(int N, const float* __restrict__ pos, const float* __restrict__ box,
                                                   int periodic, float cutoff, int max_cells, CellGrid* __restrict__ grid,
-                                                  int* __restrict__ cell_count) {
+                                                  int* __restrict__ cell_count, int fine) {
     __shared__ float red[6][256];
     __shared__ CellGrid g;
     const int tid = threadIdx.x;
@@ -120,7 +134,7 @@ static __global__ __launch_bounds__(256) void grid_setup(int N, const float* __r
     }
     if (tid == 0) {
         float lo3[3] = {red[0][0], red[1][0], red[2][0]}, hi3[3] = {red[3][0], red[4][0], red[5][0]};
-        g = decide_grid(periodic, box, lo3, hi3, cutoff, max_cells);
+        g = decide_grid(periodic, box, lo3, hi3, cutoff, max_cells, fine);
         *grid = g;
     }
     __syncthreads();
@@ -223,10 +237,10 @@ static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const 
                                                                    const float* __restrict__ box, float cutoff, int max_cells,
                                                                    CellGrid* __restrict__ grid, int* __restrict__ hist,
                                                                    int* __restrict__ bins, int bin_cap,
-                                                                   int* __restrict__ atom_cell) {
+                                                                   int* __restrict__ atom_cell, int fine) {
     __shared__ CellGrid g;
     if (threadIdx.x == 0) {
-        g = decide_grid(1, box, nullptr, nullptr, cutoff, min(max_cells, kBinnedCells));
+        g = decide_grid(1, box, nullptr, nullptr, cutoff, min(max_cells, kBinnedCells), fine);
         if (blockIdx.x == 0) *grid = g;
     }
     __syncthreads();
@@ -354,6 +368,75 @@ __device__ __forceinline__ int stencil_slot(const Stencil& S, int k) {
     return k + __builtin_amdgcn_ds_bpermute(r << 2, S.delta);
 }
 
+// The stencil of a grid of either width (g.m = 1: 3x3x3 cells, g.m = 2: 5x5x5 half-width cells) as one flat
+// candidate space.  The ranges (rows of 2m+1 cells, split in two where they cross the periodic seam: at most 50)
+// live one per lane; the range of a candidate is found per batch of 64 candidates by dropping "range r starts
+// here" marks into a 64-int LDS strip and running a prefix maximum over the wave (the marks ascend), which costs
+// the same ~20 instructions for 18 or 50 ranges -- the compare chain of stencil_slot costs 2 per range.
+struct WideStencil {
+    int pre;                      // lane r: first flat index of range r
+    int count;                    // lane r: candidates in range r
+    int delta;                    // lane r: begin_r - pre_r
+    int total;                    // wave-uniform
+};
+
+__device__ __forceinline__ WideStencil gather_wide_stencil(const CellGrid& g, const int* __restrict__ cell_start, int cx, int cy,
+                                                           int cz) {
+    const int lane = lane_id();
+    const int m = g.m, W = 2 * m + 1;
+    int begin = 0, end = 0;
+    if (lane < 2 * W * W) {
+        const int row = lane >> 1, sub = lane & 1;
+        const int rz = (row * (m == 1 ? 86 : 52)) >> 8;                // row / W for W = 3 (row < 9) or 5 (row < 25)
+        int z = cz + rz - m, y = cy + (row - rz * W) - m;
+        bool live = true;
+        if (g.periodic) {                                              // every axis has at least W cells
+            z += z < 0 ? g.nz : 0; z -= z >= g.nz ? g.nz : 0;
+            y += y < 0 ? g.ny : 0; y -= y >= g.ny ? g.ny : 0;
+        } else live = z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+        if (live) {
+            const int rowbase = (z * g.ny + y) * g.nx;
+            const int x0 = cx - m, x1 = cx + m;
+            int a = 0, b = -1;                                         // cells [a, b] of this row
+            if (sub == 0) { a = max(x0, 0); b = min(x1, g.nx - 1); }
+            else if (g.periodic) {
+                if (x0 < 0) { a = x0 + g.nx; b = g.nx - 1; }
+                else if (x1 >= g.nx) { a = 0; b = x1 - g.nx; }
+            }
+            if (b >= a) { begin = cell_start[rowbase + a]; end = cell_start[rowbase + b + 1]; }
+        }
+    }
+    WideStencil S;
+    S.count = end - begin;
+    const int incl = wave_prefix_sum(S.count);
+    S.pre = incl - S.count;
+    S.delta = begin - S.pre;
+    S.total = __builtin_amdgcn_readlane(incl, 63);
+    return S;
+}
+
+// Sorted slot of flat candidate base + lane (clamped to the last candidate).  `strip`: 64 ints of this wave's LDS;
+// `carry`: wave-uniform state, 0 before the first batch; batches must be asked for in ascending order.  ALL lanes call.
+__device__ __forceinline__ int wide_stencil_slot(const WideStencil& S, int base, int* strip, int& carry) {
+    const int lane = lane_id();
+    strip[lane] = 0;
+    const int at = S.pre - base;
+    if (S.count > 0 && at >= 0 && at < 64) strip[at] = lane + 1;       // LDS operations of a wave execute in order
+    wave_fence();
+    int x = strip[lane];
+    wave_fence();
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));     // prefix maximum: row_shr 1, 2, 4, 8 ...
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));     // ... row_bcast:15 -> rows 1, 3
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));     // ... row_bcast:31 -> rows 2, 3
+    x = max(x, carry);
+    carry = __builtin_amdgcn_readlane(x, 63);
+    const int k = min(base + lane, max(S.total - 1, 0));
+    return k + __builtin_amdgcn_ds_bpermute(max(x - 1, 0) << 2, S.delta);
+}
+
 // Half-list variant: a consumer that wants only partners with a SMALLER atom id (getNeighborPairs: col < row)
 // need not look at the others at all.  Inside a cell the sorted arrays ascend in atom id (order_cells /
 // order_binned rank by id), so the partners of `row` in a cell are a PREFIX of that cell's run: 27 lanes
@@ -432,6 +515,7 @@ struct CellBuffers {
     int* hist = nullptr;
     int* bins = nullptr;
     int bin_cap = 0;
+    int fine = 0;                          // 1: prefer half-cutoff cells (decide_grid); only for consumers that read CellGrid::m
 };
 
 static inline bool cell_build_is_binned(int N, bool periodic, const CellBuffers& b) {
@@ -443,12 +527,12 @@ static inline void launch_cell_build(hipStream_t stream, int N, const float* pos
     const int tb = 256, nb = (N + tb - 1) / tb;
     if (cell_build_is_binned(N, periodic, b)) {
         hipLaunchKernelGGL(bin_atoms, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, box, cutoff, b.max_cells, b.grid, b.hist, b.bins,
-                           b.bin_cap, b.atom_cell);
+                           b.bin_cap, b.atom_cell, b.fine);
         hipLaunchKernelGGL(order_binned, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, tag, b.grid, b.hist, b.bins, b.bin_cap,
                            b.atom_cell, b.cell_start, b.sorted_atom, b.sorted_pos);
         return;
     }
-    hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, stream, N, pos, box, (int)periodic, cutoff, b.max_cells, b.grid, b.cell_count);
+    hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, stream, N, pos, box, (int)periodic, cutoff, b.max_cells, b.grid, b.cell_count, b.fine);
     hipLaunchKernelGGL(assign_cells, dim3(nb), dim3(tb), 0, stream, N, pos, b.grid, b.cell_count, b.atom_cell, b.atom_rank);
     hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, stream, b.grid, b.cell_count, b.cell_start);
     hipLaunchKernelGGL(fill_cells, dim3(nb), dim3(tb), 0, stream, N, b.grid, b.cell_start, b.atom_cell, b.atom_rank, b.unsorted_atom);

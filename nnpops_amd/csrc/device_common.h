@@ -31,25 +31,29 @@ __device__ __forceinline__ Box load_box(const float* __restrict__ box) {
     const float b10 = box[3], b11 = box[4], b12 = box[5];
     const float b20 = box[6], b21 = box[7], b22 = box[8];
     b.ax = b00; b.bx = b10; b.by = b11; b.cx = b20; b.cy = b21; b.cz = b22;
-    b.inv_x = 1.0f / b00; b.inv_y = 1.0f / b11; b.inv_z = 1.0f / b22;
+    // (v_rcp_f32, 1 ulp: the scaled coordinate only picks the image, see min_image)
+    b.inv_x = __builtin_amdgcn_rcpf(b00); b.inv_y = __builtin_amdgcn_rcpf(b11); b.inv_z = __builtin_amdgcn_rcpf(b22);
     b.triclinic = (b01 != 0.f) | (b02 != 0.f) | (b10 != 0.f) | (b12 != 0.f) | (b20 != 0.f) | (b21 != 0.f);
     return b;
 }
 
+// The reference rounds half away from zero (round()); rintf (one v_rndne_f32 instead of seven instructions) differs
+// from it only when a scaled component is exactly +-1/2, where both images are equally near and, the box being at
+// least two cutoffs wide, at least a cutoff away: the pair is outside every list either way.
 template <bool PERIODIC>
 __device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const Box& b) {
     if (PERIODIC) {
         if (b.triclinic) {   // wave-uniform branch
-            const float s3 = roundf(dz * b.inv_z);
+            const float s3 = rintf(dz * b.inv_z);
             dx -= s3 * b.cx; dy -= s3 * b.cy; dz -= s3 * b.cz;
-            const float s2 = roundf(dy * b.inv_y);
+            const float s2 = rintf(dy * b.inv_y);
             dx -= s2 * b.bx; dy -= s2 * b.by;
-            const float s1 = roundf(dx * b.inv_x);
+            const float s1 = rintf(dx * b.inv_x);
             dx -= s1 * b.ax;
         } else {
-            dx -= roundf(dx * b.inv_x) * b.ax;
-            dy -= roundf(dy * b.inv_y) * b.by;
-            dz -= roundf(dz * b.inv_z) * b.cz;
+            dx -= rintf(dx * b.inv_x) * b.ax;
+            dy -= rintf(dy * b.inv_y) * b.by;
+            dz -= rintf(dz * b.inv_z) * b.cz;
         }
     }
 }
@@ -104,6 +108,18 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));     // row_bcast:15 -> rows 1, 3
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));     // row_bcast:31 -> rows 2, 3
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Inclusive prefix sum of an int over the wave: the same DPP ladder (6 adds, no LDS round trips; __shfl_up costs a
+// ds_bpermute and its address arithmetic per step).
+__device__ __forceinline__ int wave_prefix_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
 }
 
 // Fast single-instruction transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32 /

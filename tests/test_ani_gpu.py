@@ -278,6 +278,9 @@ def test_handles_release_their_device_memory():
     """200 create / compute / backprop / (capacity growth) / destroy cycles of the ANI and CFConv handles leave the
     device's free memory where it was (the handles own ~20 device buffers each, some reallocated by check())."""
     import gc
+    import os
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("reads the device's free memory: meaningless while other test processes allocate on the same GPU")
     from nnpops_amd.capi import AniSymmetryFunctions, CFConv, CFConvNeighbors
     rf, af = workloads.ani2x_functions()
     pos, species, box = workloads.random_box(1200, density=0.2, seed=41)          # dense: rows and records grow
