@@ -13,6 +13,7 @@
 #include "ani_angular_mfma.h"
 #include "ani_angular_bwd.h"
 #include "ani_angular_generic.h"
+#include "ani_radial_bwd.h"
 #include "host_common.h"
 
 using namespace nnpops;
@@ -46,6 +47,8 @@ struct nnpops_ani {
     // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
     // the tail of every launch overlap with the steady state of the other spans' launches (two half-size evaluations on two
     // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
+    int rbwd_occ = 8;               // waves per SIMD the lane-per-neighbour radial backward is compiled for (8 or 6)
+    bool rbwd_lanes = true;         // radial backward with a lane per neighbour (ani_radial_bwd.h) where rows read as float4
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
     int fwd_occ = 7;                // A/B: register budget of the forward kernel (waves per SIMD)
@@ -435,6 +438,8 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_RBWD_OCC")) h->rbwd_occ = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_OCC")) h->fwd_occ = std::atoi(e);
@@ -694,6 +699,29 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     for (int q = 0; q < nspans; q++) {
         const Span& sp = spans[q];
         KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD, sp.stream);
+        const int nr4 = h->hp.nR / 4;
+        const bool lanes = h->rbwd_lanes && h->hp.nR % 4 == 0 && nr4 >= 1 && nr4 <= 8 && h->ld_radial % 4 == 0 && h->cap_angular == 32 &&
+                           (reinterpret_cast<uintptr_t>(radial_deriv) & 15) == 0;
+        if (lanes) {
+            // a lane per neighbour: only this atom's own gradient row is staged in LDS
+            const int lw = (int)(((size_t)h->hp.S * h->hp.nR * sizeof(float) + 15) & ~(size_t)15);
+            const int wpg = kWavesPerGroup;
+            auto k = ani_radial_backward_lanes<4, 8>;
+            const bool o8 = h->rbwd_occ >= 8;
+            switch (nr4) {
+                case 1: k = o8 ? ani_radial_backward_lanes<1, 8> : ani_radial_backward_lanes<1, 6>; break;
+                case 2: k = o8 ? ani_radial_backward_lanes<2, 8> : ani_radial_backward_lanes<2, 6>; break;
+                case 3: k = o8 ? ani_radial_backward_lanes<3, 8> : ani_radial_backward_lanes<3, 6>; break;
+                case 4: k = o8 ? ani_radial_backward_lanes<4, 8> : ani_radial_backward_lanes<4, 6>; break;
+                case 5: k = o8 ? ani_radial_backward_lanes<5, 8> : ani_radial_backward_lanes<5, 6>; break;
+                case 6: k = o8 ? ani_radial_backward_lanes<6, 8> : ani_radial_backward_lanes<6, 6>; break;
+                case 7: k = o8 ? ani_radial_backward_lanes<7, 8> : ani_radial_backward_lanes<7, 6>; break;
+                default: k = o8 ? ani_radial_backward_lanes<8, 8> : ani_radial_backward_lanes<8, 6>; break;
+            }
+            hipLaunchKernelGGL(k, dim3(div_up(sp.nw, wpg)), dim3(64 * wpg), (size_t)lw * wpg, sp.stream, h->d_params, h->d_species, h->d_nbr,
+                               h->cap, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
+                               sp.order, position_deriv, lw, sp.w0, sp.nw);
+        } else
         hipLaunchKernelGGL(ani_radial_backward, dim3(div_up(sp.nw, wpg_r)), ablock, lds_r, sp.stream, h->d_params, h->d_species, h->d_nbr, h->cap,
                            h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
                            sp.order, position_deriv, lds_rw, sp.w0, sp.nw);

@@ -231,9 +231,11 @@ __device__ __forceinline__ void append_to_row(int cap, float4* stage, bool in_a,
 }
 
 __device__ __forceinline__ void flush_row(float4* __restrict__ row, const float4* stage, int cap, int na, int nro) {
+    // the global row is CONTIGUOUS: angular neighbours first, the radial-only ones behind them (the stage keeps them
+    // at its two ends because the counts are only known after the scan); a consumer can issue row[lane] before it
+    // has the counts
     const int front = min(na, cap), back = min(nro, cap - front);
-    for (int e = lane_id(); e < cap; e += 64)
-        if (e < front || e >= cap - back) row[e] = stage[e];
+    for (int e = lane_id(); e < front + back; e += 64) row[e] = e < front ? stage[e] : stage[cap - 1 - (e - front)];
 }
 
 // After the scan: sort the staged angular neighbours by species (stable), evaluate everything that
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     const float* gi = radial_grad + (size_t)i * ld_radial;
     for (int q = lane; q < width; q += 64) g_own[q] = gi[q];
     for (int e = lane; e < total; e += 64) {
-        const float4 rec = e < na ? row[e] : row[cap - 1 - (e - na)];
+        const float4 rec = row[e];
         const int word = __float_as_int(rec.w);
         const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         const float rinv = fast_rcp(r);

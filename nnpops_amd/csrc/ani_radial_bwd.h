@@ -1,0 +1,120 @@
+// ani_radial_bwd.h -- radial backward + gather of the angular leg forces, lane = neighbour.
+//
+// ani_radial_backward (ani_kernels.h) gives a lane one (neighbour stream, radial function k): 17 dependent steps per
+// atom, each with its own gather of a neighbour's gradient row -- five round trips to memory in a row even when
+// unrolled by four, and nine LDS reads per step.  The kernel is bound by that latency times the number of occupancy
+// rounds, not by arithmetic.  Here a lane owns one NEIGHBOUR: its 16 gradient values arrive as four 16-byte loads
+// issued at once (one round trip), the id row for the reverse lookup of the angular leg force is requested in the
+// same breath, and the sum over k runs in registers with the function parameters as scalar operands:
+//     rows of the atom (1 round trip) -> gradient rows + id rows of its neighbours (1) -> leg forces (1).
+// ~280 vector instructions per atom instead of 680.  Used when rows can be read as float4 (nR % 4 == 0, ld % 4 == 0,
+// 16-byte aligned gradient tensor) and id rows are 32 wide; everything else takes ani_radial_backward.
+//
+// Semantics: reference src/ani/CpuANISymmetryFunctions.cpp:228-263 (radial part), :310-344 (angular legs, here
+// gathered by the owner from leg_force / centre_force written by the angular backward kernel).
+#pragma once
+
+#include "ani_kernels.h"
+
+namespace nnpops {
+
+template <int NR4, int OCC>
+__global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_lanes(
+    const AniParams* __restrict__ P, const int* __restrict__ species, const float4* __restrict__ nbr, int cap,
+    const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro, const float* __restrict__ radial_grad, int ld_radial,
+    const int* __restrict__ ids, const float4* __restrict__ leg_force, const float4* __restrict__ centre_force,
+    const int* __restrict__ order,     // atoms in cell order, or NULL
+    float* __restrict__ pos_grad, int lds_per_wave, int w0, int nw) {
+    constexpr int NR = 4 * NR4, CAPA = 32;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float* g_own = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);      // [S * NR] this atom's gradient row
+    const int lane = lane_id();
+    const int wl = order ? xcd_contiguous_wave_id() : wave_global_id();      // this launch covers positions [w0, w0 + nw)
+    if (wl >= nw) return;
+    const int w = w0 + wl;
+    int i = order ? order[w] : w;
+    if ((unsigned)i >= (unsigned)P->N) i = w;              // (a void grid build leaves no valid order: stay in bounds)
+    const int width = P->S * NR;
+    const float4* row = nbr + (size_t)i * cap;
+    const float4 first = row[min(lane, cap - 1)];          // rows are contiguous (flush_row): requested before the counts are known
+    int na, nro;
+    clamp_counts(cnt_a[i], cnt_ro[i], cap, CAPA, na, nro);
+    const int total = na + nro;
+    const float inv_rcr = P->inv_rcr;
+    const int col = species[i] * NR;                       // where this atom's species sits in a neighbour's row
+
+    const float* gi = radial_grad + (size_t)i * ld_radial;
+    for (int q = lane; q < width; q += 64) g_own[q] = gi[q];
+    wave_fence();
+
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    for (int base = 0; base < total; base += 64) {         // one pass for up to 64 neighbours
+        const int e = base + lane;
+        const bool live = e < total;
+        float4 rec = base == 0 ? first : row[min(e, cap - 1)];
+        if (!live) rec = make_float4(1.f, 0.f, 0.f, __int_as_float(i));
+        const int word = __float_as_int(rec.w), j = word & kIdMask;
+        // everything that depends on the neighbour's id, in flight together
+        const float4* grow = reinterpret_cast<const float4*>(radial_grad + (size_t)j * ld_radial + col);
+        float4 gj[NR4];
+#pragma unroll
+        for (int c = 0; c < NR4; c++) gj[c] = grow[c];
+        const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
+        const float rinv = fast_rcp(r);
+        float sn, cs;
+        sincospi_unit(r * inv_rcr, sn, cs);
+        const float fc2 = -cs - 1.0f, dfc = -(0.5f * kPi * inv_rcr) * sn;       // fc2 = -2 fc
+        const float4* own = reinterpret_cast<const float4*>(g_own + (word >> kTagShift) * NR);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NR4; c++) {
+            const float4 o = own[c];
+            const float d[4] = {o.x + gj[c].x, o.y + gj[c].y, o.z + gj[c].z, o.w + gj[c].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int k = 4 * c + t;                   // compile-time: the parameters are scalar operands
+                const float sh = r - P->rad_rs[k];
+                const float ex = fast_exp2(P->rad_c[k] * sh * sh);
+                s = fmaf(d[t], fmaf(fc2 * sh, P->rad_eta[k], dfc) * ex, s);
+            }
+        }
+        s = live ? s * P->radial_scale * rinv : 0.f;
+        fx -= s * rec.x; fy -= s * rec.y; fz -= s * rec.z;
+        // reverse lookup of the angular legs, all lanes together: lane l scans quarter-row (l & 7) of the id rows of
+        // angular neighbours (l >> 3) + 8 t -- one 16-byte load per lane and t, all of them in flight with the gathers
+        int4 idv[4];
+        int jt[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int et = (lane >> 3) + 8 * t;            // (angular neighbours are the first na of the row: pass 0 only)
+            jt[t] = __shfl(j, et, 64);
+            idv[t] = make_int4(-1, -1, -1, -1);
+            if (base == 0 && et < na) idv[t] = reinterpret_cast<const int4*>(ids + (size_t)jt[t] * CAPA)[lane & 7];
+        }
+        // angular legs: whoever finds this atom in a neighbour's id row (rows are padded with -1) fetches that leg
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int slot = -1;
+            slot = idv[t].x == i ? 0 : slot;
+            slot = idv[t].y == i ? 1 : slot;
+            slot = idv[t].z == i ? 2 : slot;
+            slot = idv[t].w == i ? 3 : slot;
+            if (slot >= 0) {
+                const float4 f = leg_force[(size_t)jt[t] * CAPA + 4 * (lane & 7) + slot];
+                fx += f.x; fy += f.y; fz += f.z;
+            }
+        }
+    }
+    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    if (lane == 0) {
+        if (na >= 2) {
+            const float4 c = centre_force[i];
+            fx += c.x; fy += c.y; fz += c.z;
+        }
+        pos_grad[3 * i] = fx;
+        pos_grad[3 * i + 1] = fy;
+        pos_grad[3 * i + 2] = fz;
+    }
+}
+
+}  // namespace nnpops

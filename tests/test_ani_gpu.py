@@ -311,9 +311,11 @@ def test_handles_release_their_device_memory():
     assert free0 - free1 < 8 << 20, (free0, free1)          # allow allocator granularity, not 200 leaked handles
 
 
-def test_strided_rows_write_one_aev_array():
+@pytest.mark.parametrize("pad", [8, 5])
+def test_strided_rows_write_one_aev_array(pad):
     """nnpops_ani_compute_strided / _backprop_strided: radial and angular parts written into (and their gradients read
-    from) ONE [N, W_r + W_a + padding] array, bit-identical to the dense calls; strides below the row width refused."""
+    from) ONE [N, W_r + W_a + padding] array, bit-identical to the dense calls (rows that stay 16-byte aligned) or equal
+    to rounding (odd strides take the scalar-load kernels); strides below the row width refused."""
     from nnpops_amd.capi import AniSymmetryFunctions, lib, _ptr, _check, NNPOpsHipError
     rf, af = workloads.ani2x_functions()
     pos, species, box = workloads.random_box(1300, seed=61)
@@ -325,7 +327,7 @@ def test_strided_rows_write_one_aev_array():
     g_r = torch.randn(radial.shape, device=dev, generator=gen)
     g_a = torch.randn(angular.shape, device=dev, generator=gen)
     grad = sym.backprop(g_r, g_a).clone()
-    wr, wa, pad = radial.shape[1], angular.shape[1], 5
+    wr, wa = radial.shape[1], angular.shape[1]
     ld = wr + wa + pad
     aev = torch.full((len(pos), ld), float("nan"), device=dev)
     L = lib()
@@ -337,7 +339,10 @@ def test_strided_rows_write_one_aev_array():
     grad2 = torch.empty_like(grad)
     _check(L.nnpops_ani_backprop_strided(sym._h, g.data_ptr(), ld, g.data_ptr() + 4 * wr, ld, _ptr(grad2)))
     torch.cuda.synchronize()
-    assert torch.equal(grad2, grad)
+    if ld % 4 == 0:
+        assert torch.equal(grad2, grad)
+    else:
+        assert float((grad2 - grad).abs().max()) <= 2e-6 * float(grad.abs().max())
     with pytest.raises(NNPOpsHipError, match="row strides"):
         _check(L.nnpops_ani_compute_strided(sym._h, _ptr(tpos), _ptr(tbox), aev.data_ptr(), wr - 1, aev.data_ptr(), ld))
 
