@@ -72,82 +72,80 @@ __device__ __forceinline__ const float* lds_ptr(int byte_address) {
 // WPA = waves per atom.  1: a wave owns an atom (both quad sets).  2: a 128-lane workgroup owns an atom -- the two
 // waves stage alternate batches of phase 1 into ONE shared staging area, meet at a barrier, and each runs the step loop of
 // one quad set: same instructions in total, half the LDS per wave (twice the waves per CU) and half the latency per atom.
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC>
-__global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
-    const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
-    const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
-    const int* __restrict__ cnt_ro, float* __restrict__ angular, int ld_angular, int vec_ok, int lds_per_atom,
-    const int* __restrict__ order, int w0, int nw) {      // this launch covers positions [w0, w0 + nw) of `order` (NULL: atom = position)
-    constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
-    constexpr int NS = 2 / WPA;                                // quad sets run by this wave
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int lane = lane_id();
-    const int NB = P->NB, nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
-    const int K = P->fwd_split, logK = 31 - __builtin_clz(K);
+//
+// The per-atom work is a struct so that two kernels can run it: ani_angular_forward_mfma below (records and triple
+// list read back from global memory) and ani_build_forward (ani_build_forward.h: the neighbour build of the same atom
+// runs first in the same workgroup and leaves them in LDS).
+template <bool TORCHANI, int NFRP, int NFZP, int WPA>
+struct MfmaForward {
+    static constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
+    static constexpr int NS = 2 / WPA;                         // quad sets run by this wave
 
-    const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());        // wave-uniform: keeps per-atom addressing scalar
-    const int role = WPA == 2 ? wig : 0;                        // which half of the work of the atom
-    const int slot_in_group = WPA == 2 ? 0 : wig;               // which atom of the workgroup
-    auto sync = [&]() {
+    const AniParams* P;
+    int capA, CH, vec_ok, ld_angular;
+    float* angular;
+    float4 *recA, *recB;                  // [capA] each, LDS
+    float* fac;                           // [CH + 1][REC], LDS; the last record stays zero
+    int lane, role, quad, nn;
+    int NB, nA, K, logK;
+    int fac_addr, zdelta, zero_addr;      // (LDS addresses of phase 2 are kept as 32-bit byte offsets: one register per quad stream)
+    int sbk[NS], spart[NS];
+    float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];   // constants of the two factor families (wave-uniform)
+
+    __device__ __forceinline__ void sync() const {
         if constexpr (WPA == 2) __syncthreads();
         else wave_fence();
-    };
-    char* cursor = lds_raw + (size_t)slot_in_group * lds_per_atom;
-    float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
-    float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
-    float* fac = (float*)cursor;          // [CH + 1][REC]; the last record stays zero
-    // (LDS addresses of phase 2 are kept as 32-bit byte offsets: one register per quad stream)
-    const int fac_addr = (int)(uintptr_t)fac + (lane & 3) * (NR4 * 4);             // this lane's R pieces in record 0
-    const int zdelta = NFRP * 4 + (lane & 3) * (NZ4 * 4) - (lane & 3) * (NR4 * 4);   // from the R pieces to the Z pieces
-    const int zero_addr = fac_addr + CH * (REC * 4);
-
-    // per-lane view of phase 2: quad = block of the MFMA, nn = column inside the block
-    const int quad = lane >> 2, nn = lane & 3;
-    int sbk[NS], spart[NS];
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        sbk[s] = P->fwd_slot_bucket[(role * NS + s) * 16 + quad];          // -1: unused slot
-        spart[s] = ((role * NS + s) * 16 + quad) & (K - 1);
     }
-    // constants of the two factor families (wave-uniform: scalar registers)
-    float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];
-#pragma unroll
-    for (int a = 0; a < NFRP; a++) { frc[a] = a < nFR ? P->fr_c[a] : 0.f; frs[a] = a < nFR ? P->fr_rs[a] : 0.f; }
-#pragma unroll
-    for (int z = 0; z < NFZP; z++) {
-        zz[z] = z < nFZ ? P->fz_zeta[z] : 1.f;
-        zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
-        zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
-        zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;                 // 1 - zeta: the 2^(1-zeta) of ref :104-109 folded into the exponent
-    }
-    if (role == 0 && lane < REC) fac[CH * REC + lane] = 0.f;
 
-    const int natoms_group = WPA == 2 ? 1 : (blockDim.x >> 6);
-    const int stride_atoms = gridDim.x * natoms_group;
-    for (int w = blockIdx.x * natoms_group + slot_in_group; w < nw; w += stride_atoms) {
-        int i = order ? order[w0 + w] : w0 + w;
-        if ((unsigned)i >= (unsigned)P->N) i = w0 + w;         // (a void grid build leaves no valid order: stay in bounds)
-        int n, nro;
-        clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+    // lds: this atom's area, recA | recB | fac.  role: which half of the work of the atom (0 when WPA == 1).
+    __device__ __forceinline__ void init(const AniParams* P_, int capA_, int CH_, int vec_ok_, float* angular_, int ld_angular_,
+                                         char* lds, int role_) {
+        P = P_; capA = capA_; CH = CH_; vec_ok = vec_ok_; angular = angular_; ld_angular = ld_angular_; role = role_;
+        lane = lane_id();
+        NB = P->NB; nA = P->nA;
+        const int nFR = P->nFR, nFZ = P->nFZ;
+        K = P->fwd_split; logK = 31 - __builtin_clz(K);
+        recA = (float4*)lds;
+        recB = recA + capA;
+        fac = (float*)(recB + capA);
+        fac_addr = (int)(uintptr_t)fac + (lane & 3) * (NR4 * 4);                   // this lane's R pieces in record 0
+        zdelta = NFRP * 4 + (lane & 3) * (NZ4 * 4) - (lane & 3) * (NR4 * 4);       // from the R pieces to the Z pieces
+        zero_addr = fac_addr + CH * (REC * 4);
+        quad = lane >> 2; nn = lane & 3;                       // per-lane view of phase 2: quad = block of the MFMA, nn = column inside the block
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            sbk[s] = P->fwd_slot_bucket[(role * NS + s) * 16 + quad];          // -1: unused slot
+            spart[s] = ((role * NS + s) * 16 + quad) & (K - 1);
+        }
+#pragma unroll
+        for (int a = 0; a < NFRP; a++) { frc[a] = a < nFR ? P->fr_c[a] : 0.f; frs[a] = a < nFR ? P->fr_rs[a] : 0.f; }
+#pragma unroll
+        for (int z = 0; z < NFZP; z++) {
+            zz[z] = z < nFZ ? P->fz_zeta[z] : 1.f;
+            zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
+            zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
+            zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;             // 1 - zeta: the 2^(1-zeta) of ref :104-109 folded into the exponent
+        }
+    }
+    __device__ __forceinline__ void write_zero_record() const {
+        if (role == 0 && lane < REC) fac[CH * REC + lane] = 0.f;
+    }
+
+    // One atom with n angular neighbours.  tri_at(t): word of triple t; boff_at(b): first triple of bucket b;
+    // stage_records(): called once, before the first barrier -- the records of the atom must be in recA / recB after it.
+    template <class TriAt, class BoffAt, class StageRecords>
+    __device__ __forceinline__ void atom(int i, int n, TriAt&& tri_at, BoffAt&& boff_at, StageRecords&& stage_records) {
         const int T = (n * (n - 1)) / 2;
-        const int* tri = tri_g + (size_t)i * triples_capacity(capA);
-        int word = role * 64 + lane < T ? tri[role * 64 + lane] : 0;        // my first batch of triple words, in flight early
-        const int* boff_g = P->bucket_offsets + (size_t)i * (NB + 1);
+        int word = role * 64 + lane < T ? tri_at(role * 64 + lane) : 0;        // my first batch of triple words, in flight early
         int sstart[NS], send[NS];
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const int b = max(sbk[s], 0);
-            const int lo = boff_g[b], hi = boff_g[b + 1];
+            const int lo = boff_at(b), hi = boff_at(b + 1);
             sstart[s] = (sbk[s] >= 0 && T > 0) ? lo : 0;
             send[s] = (sbk[s] >= 0 && T > 0) ? hi : 0;
         }
-        if constexpr (WPA == 2) {                               // one array each
-            const float4* src = (role == 0 ? recA_g : recB_g) + (size_t)i * capA;
-            float4* dst = role == 0 ? recA : recB;
-            for (int e = lane; e < n; e += 64) dst[e] = src[e];
-        } else {
-            load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
-        }
+        stage_records();
 
         mfma_f4 acc[NS][NZ4][NR4];
 #pragma unroll
@@ -162,10 +160,10 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
             const int c1 = min(c0 + CH, T);
             // ---------------- phase 1: lane = triple, records of the chunk to LDS ----------------
             const int first_sub = c0 + role * 64;
-            if (c0 > 0 && (CH & (64 * WPA - 1)) != 0) word = first_sub + lane < T ? tri[first_sub + lane] : 0;   // (ragged chunks)
+            if (c0 > 0 && (CH & (64 * WPA - 1)) != 0) word = first_sub + lane < T ? tri_at(first_sub + lane) : 0;   // (ragged chunks)
             for (int sub = first_sub; sub < c1; sub += 64 * WPA) {
                 const int t = sub + lane;
-                const int next_word = (t + 64 * WPA < T) ? tri[t + 64 * WPA] : 0;
+                const int next_word = (t + 64 * WPA < T) ? tri_at(t + 64 * WPA) : 0;
                 if (t < c1) {
                     const int p = word & 0xff, q = (word >> 8) & 0xff;
                     const float4 A = recA[p], B = recA[q];
@@ -284,21 +282,20 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                 store_row16(out + 4 * q, mfma_f4{v.x, v.y, v.z, v.w}, (vec_ok >> 1) & 3);
             }
         } else {
-            float* out = angular + (size_t)i * ld_angular;
-    #pragma unroll
+#pragma unroll
             for (int s = 0; s < NS; s++) {
                 if (sbk[s] < 0 || spart[s] != 0) continue;
                 float* ob = out + sbk[s] * nA;
-    #pragma unroll
+#pragma unroll
                 for (int zh = 0; zh < NZ4; zh++)
-    #pragma unroll
+#pragma unroll
                     for (int rh = 0; rh < NR4; rh++) {
                         const int c = (nn + 4 * rh) * NFZP + 4 * zh;
                         const mfma_f4 v = acc[s][zh][rh];
                         if (vec_ok) {                              // function m sits at canonical slot m: one 16-byte store
                             store_row16(ob + c, v, (vec_ok >> 1) & 3);
                         } else {
-    #pragma unroll
+#pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 const int m = P->m_of_c[c + r];
                                 if (m >= 0) ob[m] = v[r];
@@ -324,7 +321,43 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                 }
             }
         }
-        if (w + stride_atoms < nw) sync();                     // (another atom follows: records and staging area must be free)
+    }
+};
+
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC>
+__global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
+    const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
+    const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
+    const int* __restrict__ cnt_ro, float* __restrict__ angular, int ld_angular, int vec_ok, int lds_per_atom,
+    const int* __restrict__ order, int w0, int nw) {      // this launch covers positions [w0, w0 + nw) of `order` (NULL: atom = position)
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());        // wave-uniform: keeps per-atom addressing scalar
+    const int slot_in_group = WPA == 2 ? 0 : wig;               // which atom of the workgroup
+    MfmaForward<TORCHANI, NFRP, NFZP, WPA> F;
+    F.init(P, capA, CH, vec_ok, angular, ld_angular, lds_raw + (size_t)slot_in_group * lds_per_atom, WPA == 2 ? wig : 0);
+    F.write_zero_record();
+    const int lane = F.lane, NB = F.NB;
+
+    const int natoms_group = WPA == 2 ? 1 : (blockDim.x >> 6);
+    const int stride_atoms = gridDim.x * natoms_group;
+    for (int w = blockIdx.x * natoms_group + slot_in_group; w < nw; w += stride_atoms) {
+        int i = order ? order[w0 + w] : w0 + w;
+        if ((unsigned)i >= (unsigned)P->N) i = w0 + w;         // (a void grid build leaves no valid order: stay in bounds)
+        int n, nro;
+        clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+        const int* tri = tri_g + (size_t)i * triples_capacity(capA);
+        const int* boff_g = P->bucket_offsets + (size_t)i * (NB + 1);
+        F.atom(i, n, [&](int t) { return tri[t]; }, [&](int b) { return boff_g[b]; },
+               [&]() {
+                   if constexpr (WPA == 2) {                   // one array each
+                       const float4* src = (F.role == 0 ? recA_g : recB_g) + (size_t)i * capA;
+                       float4* dst = F.role == 0 ? F.recA : F.recB;
+                       for (int e = lane; e < n; e += 64) dst[e] = src[e];
+                   } else {
+                       load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, F.recA, F.recB);
+                   }
+               });
+        if (w + stride_atoms < nw) F.sync();                   // (another atom follows: records and staging area must be free)
     }
 }
 

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           const float* __restrict__ box,
                                                           const CellGrid* __restrict__ grid,
                                                           const int* __restrict__ cell_start,
-                                                          const int* __restrict__ atom_cell,
+                                                          const int* __restrict__ sorted_cell,
                                                           const float4* __restrict__ sorted_pos, float4* __restrict__ nbr,
                                                           int cap, int capA, float4* __restrict__ recA,
                                                           float4* __restrict__ recB, int* __restrict__ ids,
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     Box b{};
     if (PERIODIC) b = load_box(box);
     const float4 me = sorted_pos[slot_id];
+    const int c = sorted_cell[slot_id];                    // (written in sorted order by the grid build: no load that waits for the id)
     const int i = __float_as_int(me.w) & kIdMask;
-    const int c = atom_cell[i];
     // cell coordinates without integer division: (c + 1/2) / n rounds down correctly for every grid that fits (c < 2^20)
     const int nxy = g.nx * g.ny;
     const int cz = (int)(((float)c + 0.5f) * fast_rcp((float)nxy));
@@ -478,17 +478,26 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     const WideStencil st = gather_wide_stencil(g, cell_start, cx, cy, cz);
     int* strip = (int*)rscratch;                           // the radial scratch is idle during the scan
     int carry = 0;
-    float4 pj = sorted_pos[wide_stencil_slot(st, 0, strip, carry)];
-    for (int base = 0; base < st.total; base += 64) {
-        const float4 cur = pj;
-        if (base + 64 < st.total) pj = sorted_pos[wide_stencil_slot(st, base + 64, strip, carry)];   // next batch in flight
-        const int word = __float_as_int(cur.w);
-        float dx = cur.x - me.x, dy = cur.y - me.y, dz = cur.z - me.z;
-        min_image<PERIODIC>(dx, dy, dz, b);
-        const float r2 = dx * dx + dy * dy + dz * dz;
-        const bool in_r = (base + lane < st.total) & ((word & kIdMask) != i) & (r2 < rcr2);
-        const bool in_a = in_r & (r2 < rca2);
-        append_to_row(cap, stage, in_a, in_r & !in_a, dx, dy, dz, word, na, nro);
+    // This wave's time is the sum of its dependent round trips to memory (the kernel runs ~1.5 occupancy rounds of it),
+    // so the candidates are requested four batches at a time -- the whole stencil of a half-cutoff grid in one trip.
+    constexpr int GROUP = 4;
+    for (int base = 0; base < st.total; base += 64 * GROUP) {
+        float4 pj[GROUP];
+#pragma unroll
+        for (int b4 = 0; b4 < GROUP; b4++)
+            if (base + 64 * b4 < st.total) pj[b4] = sorted_pos[wide_stencil_slot(st, base + 64 * b4, strip, carry)];
+#pragma unroll
+        for (int b4 = 0; b4 < GROUP; b4++) {
+            if (base + 64 * b4 >= st.total) break;         // wave-uniform
+            const float4 cur = pj[b4];
+            const int word = __float_as_int(cur.w);
+            float dx = cur.x - me.x, dy = cur.y - me.y, dz = cur.z - me.z;
+            min_image<PERIODIC>(dx, dy, dz, b);
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            const bool in_r = (base + 64 * b4 + lane < st.total) & ((word & kIdMask) != i) & (r2 < rcr2);
+            const bool in_a = in_r & (r2 < rca2);
+            append_to_row(cap, stage, in_a, in_r & !in_a, dx, dy, dz, word, na, nro);
+        }
     }
     if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
     int n, nro_c;

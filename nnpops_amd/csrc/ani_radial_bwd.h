@@ -26,6 +26,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_
     const int* __restrict__ order,     // atoms in cell order, or NULL
     float* __restrict__ pos_grad, int lds_per_wave, int w0, int nw) {
     constexpr int NR = 4 * NR4, CAPA = 32;
+    constexpr bool EARLY_IDS = OCC < 8;                    // id rows requested together with the gradient rows (16 more registers)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float* g_own = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);      // [S * NR] this atom's gradient row
     const int lane = lane_id();
@@ -59,6 +60,18 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_
         float4 gj[NR4];
 #pragma unroll
         for (int c = 0; c < NR4; c++) gj[c] = grow[c];
+        int4 idv[4];
+        int jt[4];
+        auto request_ids = [&]() {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int et = (lane >> 3) + 8 * t;        // (angular neighbours are the first na of the row: pass 0 only)
+                jt[t] = __shfl(j, et, 64);
+                idv[t] = make_int4(-1, -1, -1, -1);
+                if (base == 0 && et < na) idv[t] = reinterpret_cast<const int4*>(ids + (size_t)jt[t] * CAPA)[lane & 7];
+            }
+        };
+        if (EARLY_IDS) request_ids();
         const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         const float rinv = fast_rcp(r);
         float sn, cs;
@@ -82,15 +95,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_
         fx -= s * rec.x; fy -= s * rec.y; fz -= s * rec.z;
         // reverse lookup of the angular legs, all lanes together: lane l scans quarter-row (l & 7) of the id rows of
         // angular neighbours (l >> 3) + 8 t -- one 16-byte load per lane and t, all of them in flight with the gathers
-        int4 idv[4];
-        int jt[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int et = (lane >> 3) + 8 * t;            // (angular neighbours are the first na of the row: pass 0 only)
-            jt[t] = __shfl(j, et, 64);
-            idv[t] = make_int4(-1, -1, -1, -1);
-            if (base == 0 && et < na) idv[t] = reinterpret_cast<const int4*>(ids + (size_t)jt[t] * CAPA)[lane & 7];
-        }
+        if (!EARLY_IDS) request_ids();
         // angular legs: whoever finds this atom in a neighbour's id row (rows are padded with -1) fetches that leg
 #pragma unroll
         for (int t = 0; t < 4; t++) {

@@ -200,7 +200,7 @@ static __global__ void fill_cells(int N, const CellGrid* __restrict__ grid, cons
 static __global__ void order_cells(int N, const float* __restrict__ pos, const CellGrid* __restrict__ grid,
                             const int* __restrict__ cell_start, const int* __restrict__ atom_cell,
                             const int* __restrict__ unsorted_atom, const int* __restrict__ tag,
-                            int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos) {
+                            int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos, int* __restrict__ sorted_cell) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N || !grid->ok) return;
     const int c = atom_cell[i];
@@ -208,6 +208,7 @@ static __global__ void order_cells(int N, const float* __restrict__ pos, const C
     int rank = 0;
     for (int a = lo; a < hi; a++) rank += unsorted_atom[a] < i;
     sorted_atom[lo + rank] = i;
+    if (sorted_cell) sorted_cell[lo + rank] = c;
     // .w carries the atom id in its low 24 bits and an optional 8-bit tag (e.g. the species) above them
     const int packed = i | (tag ? (tag[i] << kTagShift) : 0);
     sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
@@ -260,7 +261,8 @@ static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, con
                                                                       const int* __restrict__ hist,
                                                                       const int* __restrict__ bins, int bin_cap,
                                                                       const int* __restrict__ atom_cell, int* __restrict__ cell_start,
-                                                                      int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos) {
+                                                                      int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos,
+                                                                      int* __restrict__ sorted_cell) {
     __shared__ int s_start[kBinnedCells + 1];
     __shared__ int wave_tot[kBinnedThreads / 64];
     constexpr int T = kBinnedThreads;
@@ -308,6 +310,7 @@ static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, con
         rank += (v.x < i) + (k + 1 < n && v.y < i) + (k + 2 < n && v.z < i) + (k + 3 < n && v.w < i);
     }
     sorted_atom[lo + rank] = i;
+    if (sorted_cell) sorted_cell[lo + rank] = c;              // (a consumer that walks the sorted order gets the cell without a dependent load)
     const int packed = i | (tag ? (tag[i] << kTagShift) : 0);
     sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
 }
@@ -516,6 +519,7 @@ struct CellBuffers {
     int* bins = nullptr;
     int bin_cap = 0;
     int fine = 0;                          // 1: prefer half-cutoff cells (decide_grid); only for consumers that read CellGrid::m
+    int* sorted_cell = nullptr;            // [N] optional: cell of the atom in every sorted slot
 };
 
 static inline bool cell_build_is_binned(int N, bool periodic, const CellBuffers& b) {
@@ -529,7 +533,7 @@ static inline void launch_cell_build(hipStream_t stream, int N, const float* pos
         hipLaunchKernelGGL(bin_atoms, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, box, cutoff, b.max_cells, b.grid, b.hist, b.bins,
                            b.bin_cap, b.atom_cell, b.fine);
         hipLaunchKernelGGL(order_binned, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, tag, b.grid, b.hist, b.bins, b.bin_cap,
-                           b.atom_cell, b.cell_start, b.sorted_atom, b.sorted_pos);
+                           b.atom_cell, b.cell_start, b.sorted_atom, b.sorted_pos, b.sorted_cell);
         return;
     }
     hipLaunchKernelGGL(grid_setup, dim3(1), dim3(256), 0, stream, N, pos, box, (int)periodic, cutoff, b.max_cells, b.grid, b.cell_count, b.fine);
@@ -537,7 +541,7 @@ static inline void launch_cell_build(hipStream_t stream, int N, const float* pos
     hipLaunchKernelGGL(scan_cells, dim3(1), dim3(1024), 0, stream, b.grid, b.cell_count, b.cell_start);
     hipLaunchKernelGGL(fill_cells, dim3(nb), dim3(tb), 0, stream, N, b.grid, b.cell_start, b.atom_cell, b.atom_rank, b.unsorted_atom);
     hipLaunchKernelGGL(order_cells, dim3(nb), dim3(tb), 0, stream, N, pos, b.grid, b.cell_start, b.atom_cell, b.unsorted_atom, tag,
-                       b.sorted_atom, b.sorted_pos);
+                       b.sorted_atom, b.sorted_pos, b.sorted_cell);
 }
 
 // Iterate the candidate ranges of the 3x3x3 stencil around cell (cx,cy,cz).  For every (dy,dz)
