@@ -14,6 +14,7 @@
 #include "ani_angular_bwd.h"
 #include "ani_angular_generic.h"
 #include "ani_radial_bwd.h"
+#include "ani_build_forward.h"
 #include "host_common.h"
 
 using namespace nnpops;
@@ -47,6 +48,8 @@ struct nnpops_ani {
     // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
     // the tail of every launch overlap with the steady state of the other spans' launches (two half-size evaluations on two
     // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
+    bool fuse_forward = false;      // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h): measured
+                                    // EQUAL to the two launches (47.5 vs 23.4 + 19.9 + 2.3 us of boundary at 10k atoms), so off; $NNPOPS_ANI_FUSE=1
     int rbwd_occ = 8;               // waves per SIMD the lane-per-neighbour radial backward is compiled for (8 or 6)
     bool rbwd_lanes = true;         // radial backward with a lane per neighbour (ani_radial_bwd.h) where rows read as float4
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
@@ -308,6 +311,26 @@ int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out, co
     return h->hp.torchani ? dispatch_factors<true>(h, forward, g, out, sp) : dispatch_factors<false>(h, forward, g, out, sp);
 }
 
+// The fused neighbour build + angular forward (ani_build_forward.h): the ANI-1x / ANI-2x factor shape, two waves per atom.
+bool build_forward_fused(const nnpops_ani* h, const float* angular) {
+    return h->fuse_forward && !h->generic && h->forward_kernel == 2 && h->fwd_waves_per_atom == 2 && h->nfrp == 8 && h->nfzp == 4 &&
+           h->nstreams == 1 && h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)angular & 15) == 0 &&
+           build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk) <= 160 * 1024;
+}
+
+template <bool TA>
+int launch_build_forward(nnpops_ani* h, const BuildInputs& in, const BuildOutputs& out, float* angular, const Span& sp) {
+    int tri_offset = 0;
+    const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk, &tri_offset) + 15) & ~(size_t)15;
+    const int vec_ok = 1 | (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);
+    auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6> : ani_build_forward<TA, 8, 4, 7>;
+    if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, h->fwd_chunk, angular,
+                       h->ld_angular, vec_ok, tri_offset, sp.w0, sp.nw);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
 bool pair_backward_fits(const nnpops_ani* h) {
     const size_t m = (size_t)h->cap_angular * (h->cap_angular + 1) + (size_t)h->cap_angular * (h->cap_angular - 1) / 2;
     return (size_t)h->cap_angular * 32 + (size_t)h->hp.NB * h->nfrp * h->nfzp * 4 + m * 4 <= 160 * 1024;
@@ -439,6 +462,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD_OCC")) h->rbwd_occ = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
@@ -627,6 +651,15 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
     for (int q = 0; q < nspans; q++) {
         const Span& sp = spans[q];
         const dim3 sgrid(div_up(sp.nw, wpg_b));
+        if (build_forward_fused(h, angular)) {                 // one launch: build + radial + angular forward (timed as the build)
+            KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
+            const BuildInputs in{box, h->d_grid, h->d_cell_start, h->d_sorted_cell, h->d_sorted_pos, h->d_hist, positions, h->d_species,
+                                 h->d_segment, use_cells ? 1 : 0, per ? 1 : 0};
+            const BuildOutputs out{h->d_nbr, h->d_recA, h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial};
+            rc = h->hp.torchani ? launch_build_forward<true>(h, in, out, angular, sp) : launch_build_forward<false>(h, in, out, angular, sp);
+            if (rc != NNPOPS_OK) return rc;
+            continue;
+        }
         {
         KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
         if (use_cells) {

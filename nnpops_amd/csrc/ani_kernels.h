@@ -244,7 +244,9 @@ __device__ __forceinline__ void flush_row(float4* __restrict__ row, const float4
 __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P, const float4* stage, int n,
                                                  float4* __restrict__ recA, float4* __restrict__ recB,
                                                  int* __restrict__ ids, int capA, int* __restrict__ tri,
-                                                 int* __restrict__ boff_out, const AtomGroups& G) {
+                                                 int* __restrict__ boff_out, const AtomGroups& G,
+                                                 float4* recA_l = nullptr, float4* recB_l = nullptr, int* tri_l = nullptr) {
+    // (recA_l / recB_l / tri_l: LDS copies for a forward pass that follows in the same workgroup, ani_build_forward.h)
     const int lane = lane_id();
     const int S = P->S, NB = P->NB;
     const float inv_rca = P->inv_rca;
@@ -253,8 +255,11 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
         const float r = fast_sqrt(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);       // ~1 ulp, like everything downstream
         float sn, cs;
         sincospi_unit(r * inv_rca, sn, cs);                // fc = (cos(pi r/Rc)+1)/2, ref :381-387
-        recA[rank] = make_float4(r4.x, r4.y, r4.z, r);
-        recB[rank] = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi * inv_rca) * sn, fast_rcp(r), r4.w);
+        const float4 a = make_float4(r4.x, r4.y, r4.z, r);
+        const float4 b2 = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi * inv_rca) * sn, fast_rcp(r), r4.w);
+        recA[rank] = a;
+        recB[rank] = b2;
+        if (recA_l) { recA_l[rank] = a; recB_l[rank] = b2; }
         ids[rank] = __float_as_int(r4.w) & kIdMask;        // compact copy for the backward gather's reverse lookup
     };
     if (n <= 64) {
@@ -308,7 +313,9 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     for (int t = lane; t < T; t += 64) {
         int p, q, bucket;
         decode_triple(NB, G, t, steps, p, q, bucket);
-        tri[t] = p | (q << 8) | (bucket << 16);
+        const int word = p | (q << 8) | (bucket << 16);
+        tri[t] = word;
+        if (tri_l) tri_l[t] = word;
     }
 }
 

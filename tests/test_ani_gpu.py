@@ -217,6 +217,29 @@ def test_both_angular_forward_kernels(monkeypatch, kernel, kind):
     _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
 
 
+@pytest.mark.parametrize("kind", ["water", "seven_species", "dense", "vacuum", "triclinic", "tiny_box"])
+def test_fused_build_and_forward(monkeypatch, kind):
+    """$NNPOPS_ANI_FUSE=1: neighbour build, radial and angular AEV of an atom in one workgroup (ani_build_forward.h, not
+    the default: it measured equal to the two launches).  Same answers on every kind of system, including the all-pairs
+    search (vacuum) and a box too small for the cell stencil (the handle falls back and recomputes)."""
+    monkeypatch.setenv("NNPOPS_ANI_FUSE", "1")
+    rf, af = workloads.ani2x_functions()
+    box = None
+    if kind == "water":
+        pos, species, box = workloads.water_box(350, seed=31)
+    elif kind == "seven_species":
+        pos, species, box = workloads.random_box(1100, seed=32)
+    elif kind == "dense":
+        pos, species, box = workloads.random_box(900, density=0.2, seed=33)       # > 32 angular neighbours: records grow
+    elif kind == "vacuum":
+        pos, species = workloads.conformer(120, seed=34)
+    elif kind == "triclinic":
+        pos, species, box = workloads.triclinic_box(1200, seed=35)
+    else:
+        pos, species, box = workloads.random_box(1100, density=0.35, seed=12, min_dist=0.5)
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
+
+
 def test_single_atom_and_isolated_atoms():
     rf, af = workloads.ani2x_functions()
     pos = np.array([[0, 0, 0], [30, 0, 0], [0, 30, 0]], dtype=np.float32)
