@@ -74,6 +74,7 @@ struct nnpops_ani {
     int* d_atom_cell = nullptr;     // [N]
     int* d_atom_rank = nullptr;     // [N]
     int* d_sorted_cell = nullptr;   // [N] cell of the atom in every sorted slot
+    int* d_tile_total = nullptr;    // [max_cells / 8192 + 1] partial sums of the parallel cell scan
     int* d_unsorted_atom = nullptr; // [N] cell segments in arrival order
     int* d_sorted_atom = nullptr;   // [N]
     float4* d_sorted_pos = nullptr; // [N]
@@ -503,6 +504,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_atom_cell, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_atom_rank, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_cell, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_tile_total, (size_t)h->max_cells / kScanTile + 2))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_unsorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
@@ -552,7 +554,7 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     dev_free(h->d_ids); dev_free(h->d_leg_force); dev_free(h->d_centre_force); dev_free(h->d_bucket_offsets);
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
-    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
+    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_tile_total); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
     for (int q = 0; q < 3; q++) {
         if (h->side[q]) (void)hipStreamDestroy(h->side[q]);
         if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
@@ -638,7 +640,7 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
         KernelTimer timer(h, NNPOPS_ANI_K_CELL_GRID);
         const CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank,
                              h->d_unsorted_atom, h->d_sorted_atom, h->d_sorted_pos, h->max_cells,
-                             h->d_hist, h->d_bins, h->bin_cap, h->fine_grid ? 1 : 0, h->d_sorted_cell};
+                             h->d_hist, h->d_bins, h->bin_cap, h->fine_grid ? 1 : 0, h->d_sorted_cell, h->d_tile_total};
         launch_cell_build(h->stream, N, positions, box, per, h->hp.rcr, h->d_species, cb);
     }
     // The per-atom kernels, span by span: every span's chain (neighbour build -> angular forward) runs on its own stream.
