@@ -239,8 +239,9 @@ def run_aev(args, R):
 
     sym.compute(tpos, tbox, radial, angular, check=True)     # calibrates neighbour capacity (blocks)
     # Warm-up, with events around EVERY kernel: the per-kernel breakdown (diagnostic) and the choice of the
-    # dominant kernel.  An event pair costs ~3 us of stream time, so inside the timed region only the dominant
-    # kernel -- the one the roofline line is about -- is bracketed.
+    # dominant kernel.  An event costs ~4.5 us of stream time (profiles/r02d_timeline.txt: the two gaps of a step sit
+    # exactly around the bracketed kernel), so inside the timed region only the dominant kernel -- the one the roofline
+    # line is about -- is bracketed, and only on every 8th step.
     sym.enable_timing(True)
     for _ in range(args.warmup):
         step()
@@ -252,7 +253,7 @@ def run_aev(args, R):
     dominant = max(ROOFLINE_KERNELS, key=lambda k: kern_all.get(k, 0.0))
     R.barrier()
     event_overhead = sym.timing_overhead()                   # seconds reported for an EMPTY event bracket on this stream
-    sym.enable_timing(True, only=[dominant])
+    sym.enable_timing(True, only=[dominant], every=8)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

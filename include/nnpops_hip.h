@@ -122,6 +122,9 @@ enum {
     NNPOPS_ANI_NUM_KERNELS = 6
 };
 int nnpops_ani_enable_timing(nnpops_ani_t h, int enable);
+/* Bracket only every `every`-th launch of each selected kernel (default 1 = every launch): a benchmark that must
+ * measure its kernel inside the timed region pays the ~3 us per event that way on a sample of the steps only. */
+int nnpops_ani_set_timing_stride(nnpops_ani_t h, int every);
 int nnpops_ani_get_timing(nnpops_ani_t h, double* total_ms, int* launches);
 /* What an event pair reports for an EMPTY bracket on the handle's stream (median of 21, milliseconds; blocks):
  * subtract it from a per-launch average to compare with a profiler's kernel durations. */

@@ -39,6 +39,7 @@ SIGNATURES = {
     "nnpops_ani_set_neighbor_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_ani_set_molecules": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "nnpops_ani_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "nnpops_ani_set_timing_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nnpops_ani_timing_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
@@ -212,12 +213,14 @@ class AniSymmetryFunctions:
 
     KERNELS = ("neighbors", "radial_forward", "angular_forward", "radial_backward", "angular_backward", "cell_grid")
 
-    def enable_timing(self, enable=True, only=None):
-        """HIP-event timing of the kernels: all of them, or just the names in ``only`` (each event pair costs
-        a few microseconds of stream time, so benchmarks time one kernel inside their timed region)."""
+    def enable_timing(self, enable=True, only=None, every=1):
+        """HIP-event timing of the kernels: all of them, or just the names in ``only``, on every ``every``-th launch
+        (each event costs a few microseconds of stream time, so benchmarks time one kernel on a sample of the steps
+        inside their timed region)."""
         mask = int(bool(enable))
         if enable and only:
             mask = sum(1 << (self.KERNELS.index(k) + 1) for k in only)
+        _check(self._lib.nnpops_ani_set_timing_stride(self._h, int(every)))
         _check(self._lib.nnpops_ani_enable_timing(self._h, mask))
 
     def get_timing(self):

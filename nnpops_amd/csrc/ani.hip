@@ -92,6 +92,8 @@ struct nnpops_ani {
     int ld_radial = 0, ld_angular = 0;   // row strides (floats) of the AEV / gradient arrays of the call in progress
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
+    int timing_every = 1;           // ... on every timing_every-th launch
+    unsigned timing_seen[NNPOPS_ANI_NUM_KERNELS] = {};
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
     size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {};
 };
@@ -105,6 +107,8 @@ struct KernelTimer {
     hipStream_t stream;
     KernelTimer(nnpops_ani* h_, int id_, hipStream_t s_ = nullptr) : h(h_), id(id_), stream(s_ ? s_ : h_->stream) {
         if (!(h->timing_mask >> id & 1)) return;
+        if (h->timing_seen[id]++ % (unsigned)h->timing_every != 0) return;
+        active = true;
         if (h->ev_used[id] == h->ev_start[id].size()) {
             hipEvent_t a, b;
             // timing-only events: no system-scope fence (and L2 write-back) when they complete
@@ -117,8 +121,9 @@ struct KernelTimer {
         (void)hipEventRecord(h->ev_start[id][slot], stream);
     }
     size_t slot = 0;
+    bool active = false;
     ~KernelTimer() {
-        if (!(h->timing_mask >> id & 1)) return;
+        if (!active) return;
         (void)hipEventRecord(h->ev_stop[id][slot], stream);
     }
 };
@@ -826,7 +831,14 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
 int nnpops_ani_enable_timing(nnpops_ani_t h, int enable) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
     h->timing_mask = enable == 1 ? ~0u : (unsigned)enable >> 1;      // 1: all kernels; else bit (id + 1) selects kernel id
-    for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) h->ev_used[k] = 0;
+    for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) { h->ev_used[k] = 0; h->timing_seen[k] = 0; }
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_set_timing_stride(nnpops_ani_t h, int every) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    NNPOPS_REQUIRE(every >= 1, "timing stride must be at least 1 (got %d)", every);
+    h->timing_every = every;
     return NNPOPS_OK;
 }
 

@@ -235,7 +235,7 @@ __device__ __forceinline__ void flush_row(float4* __restrict__ row, const float4
     // at its two ends because the counts are only known after the scan); a consumer can issue row[lane] before it
     // has the counts
     const int front = min(na, cap), back = min(nro, cap - front);
-    for (int e = lane_id(); e < front + back; e += 64) row[e] = e < front ? stage[e] : stage[cap - 1 - (e - front)];
+    for (int e = lane_id(); e < front + back; e += 64) store_wt(row + e, e < front ? stage[e] : stage[cap - 1 - (e - front)]);
 }
 
 // After the scan: sort the staged angular neighbours by species (stable), evaluate everything that
@@ -257,10 +257,10 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
         sincospi_unit(r * inv_rca, sn, cs);                // fc = (cos(pi r/Rc)+1)/2, ref :381-387
         const float4 a = make_float4(r4.x, r4.y, r4.z, r);
         const float4 b2 = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi * inv_rca) * sn, fast_rcp(r), r4.w);
-        recA[rank] = a;
-        recB[rank] = b2;
+        store_wt(recA + rank, a);
+        store_wt(recB + rank, b2);
         if (recA_l) { recA_l[rank] = a; recB_l[rank] = b2; }
-        ids[rank] = __float_as_int(r4.w) & kIdMask;        // compact copy for the backward gather's reverse lookup
+        store_wt(ids + rank, __float_as_int(r4.w) & kIdMask);        // compact copy for the backward gather's reverse lookup
     };
     if (n <= 64) {
         // one neighbour per lane: the stable species sort is S ballots, no LDS traffic, no fences
@@ -305,16 +305,16 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
             if (valid) emit(r4, rank);
         }
     }
-    for (int e = n + lane; e < capA; e += 64) ids[e] = -1;    // the gather scans whole rows: no stale ids behind the list
+    for (int e = n + lane; e < capA; e += 64) store_wt(ids + e, -1);    // the gather scans whole rows: no stale ids behind the list
     const int T = build_bucket_offsets(NB, G);
-    for (int bk = lane; bk <= NB; bk += 64) boff_out[bk] = G.boff[bk];       // for the forward kernel's chunked view
+    for (int bk = lane; bk <= NB; bk += 64) store_wt(boff_out + bk, G.boff[bk]);       // for the forward kernel's chunked view
     int steps = 0;
     while ((1 << steps) < NB) steps++;
     for (int t = lane; t < T; t += 64) {
         int p, q, bucket;
         decode_triple(NB, G, t, steps, p, q, bucket);
         const int word = p | (q << 8) | (bucket << 16);
-        tri[t] = word;
+        store_wt(tri + t, word);
         if (tri_l) tri_l[t] = word;
     }
 }
@@ -377,7 +377,7 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
         const int sp = q >> kshift, kk = q & (KP - 1);
         float v = 0.f;
         for (int st = 0; st < nstreams; st++) v += bins[st * S * KP + q];
-        if (kk < nR) out[sp * nR + kk] = v * scale;
+        if (kk < nR) store_wt(out + sp * nR + kk, v * scale);
     }
 }
 

@@ -110,6 +110,18 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Write-through stores (sc1): the line stays valid in this XCD's L2 for the kernel that reads it next and is written to
+// memory right away, so it is not part of the dirty-line write-back every kernel ends with.  A kernel that leaves tens
+// of MB dirty (the neighbour build: 27 MB of rows and records) otherwise delays the start of the next one by ~5 us
+// (profiles/r02d_timeline.txt); `nt` stores would also avoid that but evict the lines the next kernel wants.
+typedef float f4_vec __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt(float4* p, const float4& v) {
+    const f4_vec t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void store_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_wt(int* p, int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
 // Inclusive prefix sum of an int over the wave: the same DPP ladder (6 adds, no LDS round trips; __shfl_up costs a
 // ds_bpermute and its address arithmetic per step).
 __device__ __forceinline__ int wave_prefix_sum(int v) {

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Print the kernel timeline of the LAST `n` dispatches of a rocprofv3 rocpd database: start offset,
+"""Print the kernel timeline of `n` dispatches from the MIDDLE of a rocprofv3 rocpd database (the steady state of a
+timed loop; pass a third argument "last" for the last n): start offset,
 duration and the idle gap before each kernel (microseconds).  Shows how much of a step is spent between
 kernels (launch latency, dependencies) rather than in them.
 
@@ -16,7 +17,11 @@ def main():
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     s, e = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
-    rows = c.execute(f"select name, {s}, {e} from kernels order by {s} desc limit {n}").fetchall()[::-1]
+    if len(sys.argv) > 3 and sys.argv[3] == "last":
+        rows = c.execute(f"select name, {s}, {e} from kernels order by {s} desc limit {n}").fetchall()[::-1]
+    else:
+        total = c.execute("select count(*) from kernels").fetchone()[0]
+        rows = c.execute(f"select name, {s}, {e} from kernels order by {s} limit {n} offset {max(0, total // 2 - n // 2)}").fetchall()
     t0 = rows[0][1]
     prev_end = None
     busy = 0
