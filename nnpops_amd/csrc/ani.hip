@@ -84,6 +84,7 @@ struct nnpops_ani {
     int bin_cap = 64;
     bool cells_disabled = false;    // set when a box turned out too small for the 27-cell stencil
     int cap = 0;                    // row capacity (angular + radial-only neighbours)
+    bool cap_fitted = false;        // the first clean check() shrinks `cap` to the system
     int cap_angular = 0;            // LDS capacity of the angular kernels
     int tile = 32;                  // pair-matrix edge of the angular backward kernel (<= 32, sized in check())
     bool compact_bwd = false;       // check() saw no atom with more than `tile` angular neighbours: compact LDS layout
@@ -485,6 +486,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     h->device = device;
     h->cap = 128;
     h->cap_angular = 32;
+    if (const char* e = std::getenv("NNPOPS_ANI_CAP")) h->cap = std::max(16, std::atoi(e) & ~15);      // (initial row capacity; grows on demand)
 
     DeviceGuard guard(device);
     if (!guard.ok) { delete h; return fail(NNPOPS_ERR_HIP, "cannot select device %d", device); }
@@ -824,6 +826,22 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         return fail(NNPOPS_ERR_CAPACITY,
                     "neighbour rows overflowed (max row %d > %d or max angular %d > %d); capacities grown to %d / %d, "
                     "call compute() again", st[kStatMaxRow], old_cap, st[kStatMaxAngular], old_ca, h->cap, h->cap_angular);
+    }
+    if (!h->cap_fitted) {
+        // First clean check: fit the row capacity to the system (12 % + 8 entries of slack, multiple of 16).  The builder's
+        // LDS per wave is proportional to it -- at the initial 128 a CU holds 27 builder waves, at 96 all 32 (-1 us per
+        // launch at 10 000 atoms) -- and every row-indexed array shrinks with it.  Growth stays on demand, as before.
+        h->cap_fitted = true;
+        const int fit = std::max(32, (st[kStatMaxRow] + st[kStatMaxRow] / 8 + 8 + 15) & ~15);
+        if (fit < h->cap && !std::getenv("NNPOPS_ANI_CAP")) {
+            const int old_cap = h->cap;
+            h->cap = fit;
+            int rc = alloc_rows(h);
+            if (rc != NNPOPS_OK) return rc;
+            h->computed = false;
+            return fail(NNPOPS_ERR_CAPACITY, "row capacity fitted to the system (longest row %d: %d -> %d), call compute() again",
+                        st[kStatMaxRow], old_cap, h->cap);
+        }
     }
     return NNPOPS_OK;
 }
