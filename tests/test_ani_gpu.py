@@ -240,6 +240,17 @@ def test_fused_build_and_forward(monkeypatch, kind):
     _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
 
 
+@pytest.mark.parametrize("fine", ["0", "1"])
+def test_large_cluster_in_vacuum_uses_the_cell_grid(monkeypatch, fine):
+    """A non-periodic system of more than 1024 atoms takes the five-kernel grid build over its bounding box (no wrap, cells
+    at the faces have fewer stencil ranges), with half-cutoff or full-width cells ($NNPOPS_ANI_FINE_GRID)."""
+    monkeypatch.setenv("NNPOPS_ANI_FINE_GRID", fine)
+    rf, af = workloads.ani2x_functions()
+    pos, species, _ = workloads.random_box(2600, seed=57)      # the same lattice gas, without its box
+    pos = pos - np.float32(13.0)                               # (negative coordinates: the grid origin is the bounding box's corner)
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, None, algorithm=2)
+
+
 def test_single_atom_and_isolated_atoms():
     rf, af = workloads.ani2x_functions()
     pos = np.array([[0, 0, 0], [30, 0, 0], [0, 30, 0]], dtype=np.float32)
