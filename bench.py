@@ -40,7 +40,7 @@ F16_DENSE_PEAK = 2500.0    # TFLOP/s, dense fp16/bf16 MFMA (same guide)
 
 ROOFLINE_KERNELS = ("neighbors", "angular_forward", "angular_backward", "radial_backward")
 ROCPROF_NAME = {"neighbors": "ani_neighbors_cells (neighbour rows + radial AEV)", "angular_forward": "ani_angular_forward_mfma",
-                "angular_backward": "ani_angular_backward_pair", "radial_backward": "ani_radial_backward (+ force gather)"}
+                "angular_backward": "ani_angular_backward_pair", "radial_backward": "ani_radial_backward_lanes (+ force gather)"}
 
 
 # =============================================================================================
@@ -239,7 +239,7 @@ def run_aev(args, R):
 
     sym.compute(tpos, tbox, radial, angular, check=True)     # calibrates neighbour capacity (blocks)
     # Warm-up, with events around EVERY kernel: the per-kernel breakdown (diagnostic) and the choice of the
-    # dominant kernel.  An event costs ~4.5 us of stream time (profiles/r02d_timeline.txt: the two gaps of a step sit
+    # dominant kernel.  An event costs ~4.5 us of stream time (profiles/r02e_timeline.txt: the two gaps of a step sit
     # exactly around the bracketed kernel), so inside the timed region only the dominant kernel -- the one the roofline
     # line is about -- is bracketed, and only on every 8th step.
     sym.enable_timing(True)
@@ -310,8 +310,9 @@ def run_aev(args, R):
         "event_pair_overhead_us": round(1e6 * event_overhead, 2),
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                     "limiter": "not HBM: every per-atom kernel of this path is bound by latency x occupancy and vector-instruction "
-                                "issue (DESIGN.md s6: ~10 KB of LDS per atom in flight, ~1000 VALU instructions per atom per kernel)",
+                     "limiter": "not HBM: the per-atom kernels are bound by vector-instruction issue while the chip is full and by "
+                                "latency in the last occupancy round (DESIGN.md s3/s6: 390-1160 VALU instructions per atom per "
+                                "kernel, 1.2-2.8 rounds of resident waves at 10 000 atoms)",
                      "angular": {"forward": roof("angular_forward"), "backward": roof("angular_backward")},
                      "per_kernel": {k: roof(k) for k in ROOFLINE_KERNELS},
                      "step": {"algorithmic_bytes": step_bytes, "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2),
