@@ -66,7 +66,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
     float* rscratch = (float*)(stage + cap);
     int* groups = (int*)(rscratch + 3 * cap + 64 * P->S);
     const AtomGroups G = carve_groups(groups, P->S, P->NB);
-    int* shared = groups + ((group_ints(P->S, P->NB) + 3) & ~(size_t)3);       // [0] angular count, [1] radial-only count
+    int* shared = groups + ((group_ints(P->S, P->NB, cap) + 3) & ~(size_t)3);       // [0] angular count, [1] radial-only count
     int* tri_l = (int*)(lds_raw + tri_offset);
     clear_cell_histogram(in.use_cells ? in.cell_hist : nullptr);
 

@@ -151,13 +151,15 @@ struct AtomGroups {
     int* boff;    // [NB + 1] exclusive offsets of the species-pair buckets in bucket-major triple order
     int* ba;      // [NB] first species of bucket b   (LDS copy of AniParams::bkt_a)
     int* bb;      // [NB] second species of bucket b
+    unsigned char* ssp;   // [cap] species of the neighbour in every sorted slot
 };
-__host__ __device__ inline size_t group_ints(int S, int NB) { return (size_t)3 * S + 3 * NB + 1; }
+__host__ __device__ inline size_t group_ints(int S, int NB, int cap) { return (size_t)3 * S + 3 * NB + 1 + (cap + 3) / 4; }
 
 __device__ __forceinline__ AtomGroups carve_groups(int* base, int S, int NB) {
     AtomGroups G;
     G.gs = base; G.gn = G.gs + S; G.run = G.gn + S; G.boff = G.run + S;
     G.ba = G.boff + NB + 1; G.bb = G.ba + NB;
+    G.ssp = (unsigned char*)(G.bb + NB);
     return G;
 }
 
@@ -181,31 +183,6 @@ __device__ __forceinline__ int build_bucket_offsets(int NB, const AtomGroups& G)
     if (lane == 0) G.boff[NB] = carry;
     wave_fence();
     return carry;
-}
-
-// t-th triple in bucket-major order -> sorted slots (p < q) and its bucket.
-__device__ __forceinline__ void decode_triple(int NB, const AtomGroups& G, int t, int steps, int& p, int& q, int& bucket) {
-    int lo = 0, hi = NB;
-    for (int it = 0; it < steps; it++) {                  // uniform trip count = ceil(log2(NB))
-        const int mid = (lo + hi) >> 1;
-        const bool ge = G.boff[mid] <= t;
-        lo = ge ? mid : lo;
-        hi = ge ? hi : mid;
-    }
-    bucket = lo;
-    const int A = G.ba[lo], B = G.bb[lo];
-    const int local = t - G.boff[lo];
-    if (A == B) {
-        int ia, ib;
-        decode_pair(local, G.gn[A], ia, ib);
-        p = G.gs[A] + ia;
-        q = G.gs[A] + ib;
-    } else {
-        const int nb = G.gn[B];
-        const int ia = (int)(((float)local + 0.5f) * fast_rcp((float)nb));
-        p = G.gs[A] + ia;
-        q = G.gs[B] + (local - ia * nb);
-    }
 }
 
 // =============================================================================================
@@ -257,6 +234,7 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
         sincospi_unit(r * inv_rca, sn, cs);                // fc = (cos(pi r/Rc)+1)/2, ref :381-387
         const float4 a = make_float4(r4.x, r4.y, r4.z, r);
         const float4 b2 = make_float4(0.5f * cs + 0.5f, -(0.5f * kPi * inv_rca) * sn, fast_rcp(r), r4.w);
+        G.ssp[rank] = (unsigned char)(__float_as_int(r4.w) >> kTagShift);
         store_wt(recA + rank, a);
         store_wt(recB + rank, b2);
         if (recA_l) { recA_l[rank] = a; recB_l[rank] = b2; }
@@ -308,21 +286,30 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     for (int e = n + lane; e < capA; e += 64) store_wt(ids + e, -1);    // the gather scans whole rows: no stale ids behind the list
     const int T = build_bucket_offsets(NB, G);
     for (int bk = lane; bk <= NB; bk += 64) store_wt(boff_out + bk, G.boff[bk]);       // for the forward kernel's chunked view
-    int steps = 0;
-    while ((1 << steps) < NB) steps++;
+    // The triple list, bucket-major (bucket b = (A <= B) holds its pairs in row-major (ia, ib) order), written by lanes that
+    // walk the PAIRS (p < q) of the sorted slots in row-major order and compute where each one goes: the bucket is the
+    // species pair of the two slots and the place inside it a multiply-add, where finding the pair of a given place costs a
+    // binary search over the bucket offsets and a division or a square root per lane (~100 vector instructions per batch
+    // of 64 against ~45).  Same list, scattered 4-byte stores inside the atom's own few cache lines.
+    wave_fence();                                              // (G.ssp, G.boff)
     for (int t = lane; t < T; t += 64) {
-        int p, q, bucket;
-        decode_triple(NB, G, t, steps, p, q, bucket);
+        int p, q;
+        decode_pair(t, n, p, q);
+        const int A = G.ssp[p], B = G.ssp[q];                  // A <= B: the slots are sorted by species
+        const int bucket = A * S - (A * (A - 1)) / 2 + (B - A);        // upper-triangular row-major, as AniParams::bkt_a / bkt_b
+        const int ia = p - G.gs[A], ib = q - G.gs[B], gb = G.gn[B];
+        const int local = A == B ? (ia * (2 * gb - ia - 1)) / 2 + (ib - ia - 1) : ia * gb + ib;
+        const int at = G.boff[bucket] + local;
         const int word = p | (q << 8) | (bucket << 16);
-        store_wt(tri + t, word);
-        if (tri_l) tri_l[t] = word;
+        store_wt(tri + at, word);
+        if (tri_l) tri_l[at] = word;
     }
 }
 
 // LDS of one builder wave: the row mirror [cap] float4 | radial scratch r, fc, species [3][cap] | radial bins
 // [64 * S] | species groups
 __host__ __device__ inline size_t builder_lds_bytes(int cap, int S, int NB) {
-    return (size_t)cap * (sizeof(float4) + 3 * sizeof(float)) + (size_t)64 * S * sizeof(float) + group_ints(S, NB) * sizeof(int);
+    return (size_t)cap * (sizeof(float4) + 3 * sizeof(float)) + (size_t)64 * S * sizeof(float) + group_ints(S, NB, cap) * sizeof(int);
 }
 
 // =============================================================================================
