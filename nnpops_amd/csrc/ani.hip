@@ -48,6 +48,7 @@ struct nnpops_ani {
     // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
     // the tail of every launch overlap with the steady state of the other spans' launches (two half-size evaluations on two
     // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
+    bool fwd_uniform = false;       // every radial factor shares its eta, every angular factor its zeta (set at create; $NNPOPS_ANI_FWD_UNI=0)
     bool fuse_forward = false;      // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h): measured
                                     // EQUAL to the two launches (47.5 vs 23.4 + 19.9 + 2.3 us of boundary at 10k atoms), so off; $NNPOPS_ANI_FUSE=1
     int rbwd_occ = 8;               // waves per SIMD the lane-per-neighbour radial backward is compiled for (8 or 6)
@@ -227,7 +228,9 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (h->fwd_waves_per_atom == 2) {                      // a 128-lane workgroup per atom
             int groups = N;
             if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
-            auto k = h->fwd_occ == 6 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 6> : h->fwd_occ == 8 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 8> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
+            const bool uni = h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP;      // one eta, one zeta, no padded factor slots
+            auto k = h->fwd_occ == 6 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 6> : h->fwd_occ == 8 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 8>
+                   : uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
             hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
                                h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.order, sp.w0, sp.nw);
@@ -256,7 +259,9 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, glds) + 15) & ~(size_t)15;
         void (*k)(const AniParams*, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
                   float4*, float4*, int, int, int, const int*, int, int) =
-            mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false> : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
+            mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
+                         : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, true>
+                                                                                       : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
           : mode == 2 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, true>
           : mode == 3 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false>
                       : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, true>;
@@ -440,6 +445,10 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if (const char* e = std::getenv("NNPOPS_ANI_GENERIC")) h->generic = h->generic || std::atoi(e) != 0;      // tests: force
     h->nfrp = pad_pow2(hp.nFR, 4);
     h->nfzp = pad_pow2(hp.nFZ, 4);
+    h->fwd_uniform = !h->generic;
+    for (int a = 1; a < hp.nFR; a++) h->fwd_uniform = h->fwd_uniform && hp.fr_c[a] == hp.fr_c[0];
+    for (int z = 1; z < hp.nFZ; z++) h->fwd_uniform = h->fwd_uniform && hp.fz_zeta[z] == hp.fz_zeta[0];
+    if (const char* e = std::getenv("NNPOPS_ANI_FWD_UNI")) h->fwd_uniform = h->fwd_uniform && std::atoi(e) != 0;
     // Matrix-core forward kernel: quads are handed the species pairs that can occur among this system's atoms.
     {
         std::vector<char> present(num_species, 0);

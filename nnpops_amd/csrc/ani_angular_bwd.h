@@ -106,7 +106,9 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 
 // GENERIC: the function list does not factor (ani_angular_generic.h): functions evaluated one by one, gradients read from
 // global memory in the caller's order (GLDS must be false, NFRP / NFZP are not used).
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false>
+// UNI: one eta for every radial factor, one zeta for every angular factor, no padded factor slots (ani_angular_mfma.h):
+// 20 fewer wave-uniform constants in scalar registers.
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, bool UNI = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
     const AniParams* __restrict__ P, int cap, int capA, const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
     const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
@@ -139,16 +141,16 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     float frc[NFRP], frs[NFRP], fren[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];
 #pragma unroll
     for (int a = 0; a < NFRP; a++) {
-        frc[a] = a < nFR ? P->fr_c[a] : 0.f;
+        frc[a] = UNI ? P->fr_c[0] : (a < nFR ? P->fr_c[a] : 0.f);
         frs[a] = a < nFR ? P->fr_rs[a] : 0.f;
-        fren[a] = a < nFR ? -P->fr_eta[a] : 0.f;
+        fren[a] = UNI ? -P->fr_eta[0] : (a < nFR ? -P->fr_eta[a] : 0.f);
     }
 #pragma unroll
     for (int z = 0; z < NFZP; z++) {
-        zz[z] = z < nFZ ? P->fz_zeta[z] : 1.f;
+        zz[z] = UNI ? P->fz_zeta[0] : (z < nFZ ? P->fz_zeta[z] : 1.f);
         zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
         zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
-        zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;
+        zb[z] = UNI ? P->fz_bias[0] : (z < nFZ ? P->fz_bias[z] : 0.f);
     }
 
     const int stride_atoms = gridDim.x * atoms_per_group;

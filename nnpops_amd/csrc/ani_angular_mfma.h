@@ -76,7 +76,10 @@ __device__ __forceinline__ const float* lds_ptr(int byte_address) {
 // The per-atom work is a struct so that two kernels can run it: ani_angular_forward_mfma below (records and triple
 // list read back from global memory) and ani_build_forward (ani_build_forward.h: the neighbour build of the same atom
 // runs first in the same workgroup and leaves them in LDS).
-template <bool TORCHANI, int NFRP, int NFZP, int WPA>
+// UNI: every radial factor has the same eta and every angular factor the same zeta (ANI-1x / 1ccx / 2x: one EtaA, one Zeta)
+// and no factor slot is padding: 13 fewer wave-uniform constants to hold in scalar registers through phase 1 -- the kernel
+// parks scalars in vector lanes when they run out (one vector instruction to park, one to fetch back).
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, bool UNI = false>
 struct MfmaForward {
     static constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
     static constexpr int NS = 2 / WPA;                         // quad sets run by this wave
@@ -91,6 +94,7 @@ struct MfmaForward {
     int fac_addr, zdelta, zero_addr;      // (LDS addresses of phase 2 are kept as 32-bit byte offsets: one register per quad stream)
     int sbk[NS], spart[NS];
     float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];   // constants of the two factor families (wave-uniform)
+    float frc0, zz0, zb0;                                                 // UNI: the shared eta / zeta / bias
 
     __device__ __forceinline__ void sync() const {
         if constexpr (WPA == 2) __syncthreads();
@@ -126,6 +130,7 @@ struct MfmaForward {
             zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
             zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;             // 1 - zeta: the 2^(1-zeta) of ref :104-109 folded into the exponent
         }
+        frc0 = P->fr_c[0]; zz0 = P->fz_zeta[0]; zb0 = P->fz_bias[0];
     }
     __device__ __forceinline__ void write_zero_record() const {
         if (role == 0 && lane < REC) fac[CH * REC + lane] = 0.f;
@@ -173,12 +178,12 @@ struct MfmaForward {
 #pragma unroll
                     for (int a = 0; a < NFRP; a++) {           // stored so that column nn finds its NR4 values together
                         const float sh = g.rbar - frs[a];
-                        vr[(a & 3) * NR4 + (a >> 2)] = fast_exp2(frc[a] * sh * sh);
+                        vr[(a & 3) * NR4 + (a >> 2)] = fast_exp2((UNI ? frc0 : frc[a]) * sh * sh);
                     }
 #pragma unroll
                     for (int z = 0; z < NFZP; z++) {
                         const float x = fmaxf(1.0f + (g.c * zc[z] + g.s * zs[z]), 1e-30f);   // 1 + cos(theta - ths)
-                        vz[(z & 3) * NZ4 + (z >> 2)] = g.fcfc * fast_exp2(fmaf(zz[z], fast_log2(x), zb[z]));
+                        vz[(z & 3) * NZ4 + (z >> 2)] = g.fcfc * fast_exp2(fmaf(UNI ? zz0 : zz[z], fast_log2(x), UNI ? zb0 : zb[z]));
                     }
                     float* dst = fac + (t - c0) * REC;
 #pragma unroll
@@ -324,7 +329,7 @@ struct MfmaForward {
     }
 };
 
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC>
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC, bool UNI = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
     const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());        // wave-uniform: keeps per-atom addressing scalar
     const int slot_in_group = WPA == 2 ? 0 : wig;               // which atom of the workgroup
-    MfmaForward<TORCHANI, NFRP, NFZP, WPA> F;
+    MfmaForward<TORCHANI, NFRP, NFZP, WPA, UNI> F;
     F.init(P, capA, CH, vec_ok, angular, ld_angular, lds_raw + (size_t)slot_in_group * lds_per_atom, WPA == 2 ? wig : 0);
     F.write_zero_record();
     const int lane = F.lane, NB = F.NB;
