@@ -252,8 +252,8 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                     cx -= fx; cy -= fy; cz -= fz;
                 }
             }
-            cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
-            if (lane == 0) centre_force[i] = make_float4(cx, cy, cz, 0.f);
+            cx = wave_sum_lane63(cx); cy = wave_sum_lane63(cy); cz = wave_sum_lane63(cz);
+            if (lane == 63) centre_force[i] = make_float4(cx, cy, cz, 0.f);
         }
         if (w + stride_atoms < nw) sync();                    // (another atom follows: the LDS arrays must be free)
     }

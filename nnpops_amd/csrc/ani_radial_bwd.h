@@ -110,8 +110,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_
             }
         }
     }
-    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-    if (lane == 0) {
+    fx = wave_sum_lane63(fx); fy = wave_sum_lane63(fy); fz = wave_sum_lane63(fz);
+    if (lane == 63) {
         if (na >= 2) {
             const float4 c = centre_force[i];
             fx += c.x; fy += c.y; fz += c.z;

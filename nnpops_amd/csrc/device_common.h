@@ -98,6 +98,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum over the wave, valid in LANE 63 ONLY: the same DPP ladder as wave_max_nonneg (6 vector instructions; wave_sum above
+// costs six ds_bpermute with their address arithmetic and gives every lane the result, which a "lane 0 stores it" does
+// not need).
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));     // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));     // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));     // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));     // row_shr:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));     // row_bcast:15 -> rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Largest value of a NON-NEGATIVE int over the wave, as a wave-uniform (scalar) value: a DPP scan inside each row
 // of 16 lanes, two row broadcasts, the result read from lane 63 (no LDS traffic, 13 instructions).
 __device__ __forceinline__ int wave_max_nonneg(int v) {
