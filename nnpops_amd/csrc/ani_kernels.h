@@ -137,10 +137,10 @@ __device__ __forceinline__ void decode_pair(int t, int n, int& p, int& q) {
     int pp = (int)((w - fast_sqrt(fmaxf(w * w - 8.0f * (float)t, 0.f))) * 0.5f);
     pp = max(0, min(pp, n - 2));
     // offset(p) = p*(2n-p-1)/2 ; one fix-up step each way covers the rounding of the fast sqrt
-    if (((pp + 1) * (2 * n - pp - 2)) / 2 <= t) pp++;
-    if ((pp * (2 * n - pp - 1)) / 2 > t) pp--;
+    if (__mul24(pp + 1, 2 * n - pp - 2) / 2 <= t) pp++;
+    if (__mul24(pp, 2 * n - pp - 1) / 2 > t) pp--;
     p = pp;
-    q = t - (pp * (2 * n - pp - 1)) / 2 + pp + 1;
+    q = t - __mul24(pp, 2 * n - pp - 1) / 2 + pp + 1;
 }
 
 // Per-atom species bookkeeping in LDS (ints), sized by the actual species / bucket counts.
@@ -174,7 +174,7 @@ __device__ __forceinline__ int build_bucket_offsets(int NB, const AtomGroups& G)
         if (bk < NB) {
             const int A = G.ba[bk], B = G.bb[bk];
             const int ga = G.gn[A], gb = G.gn[B];
-            c = (A == B) ? (ga * (ga - 1)) / 2 : ga * gb;
+            c = (A == B) ? __mul24(ga, ga - 1) / 2 : __mul24(ga, gb);          // (24-bit multiplies run at full rate, v_mul_lo_u32 at a quarter)
         }
         const int incl = wave_prefix_sum(c);
         if (bk < NB) G.boff[bk] = carry + incl - c;
@@ -296,9 +296,9 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
         int p, q;
         decode_pair(t, n, p, q);
         const int A = G.ssp[p], B = G.ssp[q];                  // A <= B: the slots are sorted by species
-        const int bucket = A * S - (A * (A - 1)) / 2 + (B - A);        // upper-triangular row-major, as AniParams::bkt_a / bkt_b
+        const int bucket = __mul24(A, S) - __mul24(A, A - 1) / 2 + (B - A);        // upper-triangular row-major, as AniParams::bkt_a / bkt_b
         const int ia = p - G.gs[A], ib = q - G.gs[B], gb = G.gn[B];
-        const int local = A == B ? (ia * (2 * gb - ia - 1)) / 2 + (ib - ia - 1) : ia * gb + ib;
+        const int local = A == B ? __mul24(ia, 2 * gb - ia - 1) / 2 + (ib - ia - 1) : __mul24(ia, gb) + ib;
         const int at = G.boff[bucket] + local;
         const int word = p | (q << 8) | (bucket << 16);
         store_wt(tri + at, word);

@@ -432,7 +432,7 @@ __device__ __forceinline__ WideStencil gather_wide_stencil(const CellGrid& g, co
             y += y < 0 ? g.ny : 0; y -= y >= g.ny ? g.ny : 0;
         } else live = z >= 0 && z < g.nz && y >= 0 && y < g.ny;
         if (live) {
-            const int rowbase = (z * g.ny + y) * g.nx;
+            const int rowbase = __mul24(__mul24(z, g.ny) + y, g.nx);      // (cells < 2^24)
             const int x0 = cx - m, x1 = cx + m;
             int a = 0, b = -1;                                         // cells [a, b] of this row
             if (sub == 0) { a = max(x0, 0); b = min(x1, g.nx - 1); }
