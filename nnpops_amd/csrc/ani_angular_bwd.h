@@ -204,9 +204,9 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                     triple_forces_pk<TORCHANI, NFRP, NFZP>(recA[p], recB[p], recA[q], recB[q], Gb, frc, frs, fren,
                                                            zz, zc, zs, zb, ap, aq, bt);
                 }
-                Ma[p * tstride + q] = ap;
-                Ma[q * tstride + p] = aq;
-                Mb[p * (2 * tile - p - 1) / 2 + (q - p - 1)] = bt;            // p < q: once per unordered pair
+                Ma[__mul24(p, tstride) + q] = ap;                          // (24-bit multiplies: full rate)
+                Ma[__mul24(q, tstride) + p] = aq;
+                Mb[__mul24(p, 2 * tile - p - 1) / 2 + (q - p - 1)] = bt;     // p < q: once per unordered pair
             }
             word = next_word;
         }
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                 float fx = 0.f, fy = 0.f, fz = 0.f, as = 0.f;
                 if (e < n) {
                     const int x0 = half * hc, x1 = min(n, x0 + hc);
-                    const float* ma = Ma + e * tstride;
+                    const float* ma = Ma + __mul24(e, tstride);
                     // index of beta{e,x} in the triangle: x < e: x(2T-x-1)/2 + e-x-1 (grows by T-x-2 per step), x > e: base_e + x-e-1
-                    int below = x0 * (2 * tile - x0 - 1) / 2 + (e - x0 - 1);
-                    const int above0 = e * (2 * tile - e - 1) / 2 - e - 1;
+                    int below = __mul24(x0, 2 * tile - x0 - 1) / 2 + (e - x0 - 1);
+                    const int above0 = __mul24(e, 2 * tile - e - 1) / 2 - e - 1;
 #pragma unroll 4
                     for (int x = x0; x < x1; x++) {
                         const bool use = x != e;

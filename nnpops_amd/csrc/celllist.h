@@ -267,41 +267,33 @@ constexpr int kBinnedAtoms = 65536;
 constexpr int kBinnedCells = 8192;
 constexpr int kBinnedThreads = 256;
 
-// hist: [kBinnedCells + 1] ints, the last one is the overflow flag of that build
-static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const float* __restrict__ pos,
-                                                                   const float* __restrict__ box, float cutoff, int max_cells,
-                                                                   CellGrid* __restrict__ grid, int* __restrict__ hist,
-                                                                   int* __restrict__ bins, int bin_cap,
-                                                                   int* __restrict__ atom_cell, int fine) {
-    __shared__ CellGrid g;
-    if (threadIdx.x == 0) {
-        g = decide_grid(1, box, nullptr, nullptr, cutoff, min(max_cells, kBinnedCells), fine);
-        if (blockIdx.x == 0) *grid = g;
-    }
-    __syncthreads();
-    const int i = blockIdx.x * kBinnedThreads + threadIdx.x;
-    if (i >= N || !g.ok) return;
+// hist: [kHistWords] ints: the cell histogram, then the overflow flag of that build.
+// (Both phases in ONE launch, the blocks meeting at a device-wide arrival counter between them -- release fence, one
+//  atomic per block, spin, acquire fence -- was tried: 10.9 us against 8.6 us for the two launches.  A device-scope fence
+//  pair across eight XCDs costs more than the ~2.5 us of dispatch a launch adds.)
+constexpr int kHistWords = kBinnedCells + 1;
+
+// phase 1 of the binned build for atom i (any i; returns its cell, or -1)
+__device__ __forceinline__ int bin_one_atom(int i, int N, const CellGrid& g, const float* __restrict__ pos, int* __restrict__ hist,
+                                            int* __restrict__ bins, int bin_cap) {
+    if (i >= N || !g.ok) return -1;
     int cx, cy, cz;
     cell_of(g, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], cx, cy, cz);
     const int c = (cz * g.ny + cy) * g.nx + cx;
-    atom_cell[i] = c;
     const int r = atomicAdd(&hist[c], 1);
     if (r < bin_cap) bins[(size_t)c * bin_cap + r] = i;
     else hist[kBinnedCells] = 1;                              // benign race: everyone writes the same value
+    return c;
 }
 
-static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, const float* __restrict__ pos,
-                                                                      const int* __restrict__ tag, CellGrid* __restrict__ grid,
-                                                                      const int* __restrict__ hist,
-                                                                      const int* __restrict__ bins, int bin_cap,
-                                                                      const int* __restrict__ atom_cell, int* __restrict__ cell_start,
-                                                                      int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos,
-                                                                      int* __restrict__ sorted_cell) {
-    __shared__ int s_start[kBinnedCells + 1];
-    __shared__ int wave_tot[kBinnedThreads / 64];
-    constexpr int T = kBinnedThreads;
+// phase 2 (whole block): scan of the histogram in LDS, then atom i (cell c) is ranked inside its bin and published
+template <int T>
+__device__ __forceinline__ void order_block(int i, int c, int N, const CellGrid& g, CellGrid* __restrict__ grid,
+                                            const float* __restrict__ pos, const int* __restrict__ tag, const int* __restrict__ hist,
+                                            const int* __restrict__ bins, int bin_cap, int* __restrict__ cell_start,
+                                            int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos,
+                                            int* __restrict__ sorted_cell, int* s_start, int* wave_tot) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const CellGrid g = *grid;
     if (!g.ok) return;
     if (hist[kBinnedCells] != 0) {                            // a bin overflowed: this grid is unusable
         if (blockIdx.x == 0 && tid == 0) { grid->ok = 0; grid->bin_overflow = 1; }
@@ -310,31 +302,24 @@ static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, con
     const int ncells = g.ncells;
     // exclusive scan of the histogram, redundantly in every block: coalesced into LDS, then thread t owns a
     // contiguous run of cells
-    for (int c = tid; c < ncells; c += T) s_start[c] = hist[c];
+    for (int q = tid; q < ncells; q += T) s_start[q] = hist[q];
     __syncthreads();
     const int per = (ncells + T - 1) / T;
     const int c0 = min(tid * per, ncells), c1 = min(c0 + per, ncells);
     int sum = 0;
-    for (int c = c0; c < c1; c++) sum += s_start[c];
-    int incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
+    for (int q = c0; q < c1; q++) sum += s_start[q];
+    const int incl = wave_prefix_sum(sum);
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     int run = incl - sum;
     for (int w = 0; w < wave; w++) run += wave_tot[w];
-    for (int c = c0; c < c1; c++) { const int v = s_start[c]; s_start[c] = run; run += v; }
+    for (int q = c0; q < c1; q++) { const int v = s_start[q]; s_start[q] = run; run += v; }
     if (tid == T - 1) s_start[ncells] = run;
     __syncthreads();
     // the global copy of the offsets, a slice per block
-    for (int c = blockIdx.x * T + tid; c <= ncells; c += gridDim.x * T) cell_start[c] = s_start[c];
+    for (int q = blockIdx.x * T + tid; q <= ncells; q += gridDim.x * T) cell_start[q] = s_start[q];
 
-    const int i = blockIdx.x * T + tid;
     if (i >= N) return;
-    const int c = atom_cell[i];
     const int lo = s_start[c], n = s_start[c + 1] - lo;
     const int* bin = bins + (size_t)c * bin_cap;
     int rank = 0;                                             // deterministic order inside the cell
@@ -347,6 +332,38 @@ static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, con
     if (sorted_cell) sorted_cell[lo + rank] = c;              // (a consumer that walks the sorted order gets the cell without a dependent load)
     const int packed = i | (tag ? (tag[i] << kTagShift) : 0);
     sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
+}
+
+static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const float* __restrict__ pos,
+                                                                   const float* __restrict__ box, float cutoff, int max_cells,
+                                                                   CellGrid* __restrict__ grid, int* __restrict__ hist,
+                                                                   int* __restrict__ bins, int bin_cap,
+                                                                   int* __restrict__ atom_cell, int fine) {
+    __shared__ CellGrid g;
+    if (threadIdx.x == 0) {
+        g = decide_grid(1, box, nullptr, nullptr, cutoff, min(max_cells, kBinnedCells), fine);
+        if (blockIdx.x == 0) *grid = g;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * kBinnedThreads + threadIdx.x;
+    const int c = bin_one_atom(i, N, g, pos, hist, bins, bin_cap);
+    if (c >= 0) atom_cell[i] = c;
+}
+
+static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, const float* __restrict__ pos,
+                                                                      const int* __restrict__ tag, CellGrid* __restrict__ grid,
+                                                                      const int* __restrict__ hist,
+                                                                      const int* __restrict__ bins, int bin_cap,
+                                                                      const int* __restrict__ atom_cell, int* __restrict__ cell_start,
+                                                                      int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos,
+                                                                      int* __restrict__ sorted_cell) {
+    __shared__ int s_start[kBinnedCells + 1];
+    __shared__ int wave_tot[kBinnedThreads / 64];
+    const CellGrid g = *grid;
+    const int i = blockIdx.x * kBinnedThreads + threadIdx.x;
+    const int c = (i < N && g.ok) ? atom_cell[i] : 0;
+    order_block<kBinnedThreads>(i, c, N, g, grid, pos, tag, hist, bins, bin_cap, cell_start, sorted_atom, sorted_pos, sorted_cell,
+                                s_start, wave_tot);
 }
 
 // The same stencil as ONE flat candidate index space: lane r < 18 looks up range r, a wave scan gives
@@ -536,7 +553,7 @@ __device__ __forceinline__ int stencil_slot(const PrefixStencil& S, int k) {
 __device__ __forceinline__ void clear_cell_histogram(int* __restrict__ hist) {
     if (hist == nullptr) return;
     const int stride = gridDim.x * blockDim.x;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= kBinnedCells; c += stride) hist[c] = 0;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < kHistWords; c += stride) hist[c] = 0;
 }
 
 // Host side: the buffers of one grid and the launch sequence.
@@ -547,7 +564,7 @@ struct CellBuffers {
     int *unsorted_atom, *sorted_atom;      // [N]
     float4* sorted_pos;                    // [N]
     int max_cells;
-    // two-kernel path (optional): a zero-initialised histogram of kBinnedCells + 1 ints that the consumer kernel
+    // two-kernel path (optional): a zero-initialised histogram of kHistWords ints that the consumer kernel
     // clears again after every build, and bins of kBinnedCells * bin_cap ints
     int* hist = nullptr;
     int* bins = nullptr;

@@ -1635,9 +1635,9 @@ int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t* out, int num_atoms
     if ((rc = dev_alloc(&h->d_cell_start, (size_t)h->max_cells + 1))) return cleanup(rc);
     if (const char* e = std::getenv("NNPOPS_CELL_BIN_CAP")) h->bin_cap = std::max(4, std::atoi(e) & ~3);   // tests: force growth
     if (periodic && num_atoms <= kBinnedAtoms) {
-        if ((rc = dev_alloc(&h->d_hist, (size_t)kBinnedCells + 1))) return cleanup(rc);
+        if ((rc = dev_alloc(&h->d_hist, (size_t)kHistWords))) return cleanup(rc);
         if ((rc = dev_alloc(&h->d_bins, (size_t)kBinnedCells * h->bin_cap))) return cleanup(rc);
-        if (hipMemset(h->d_hist, 0, sizeof(int) * (kBinnedCells + 1)) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
+        if (hipMemset(h->d_hist, 0, sizeof(int) * kHistWords) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
     }
     if ((rc = dev_alloc(&h->d_lo_cnt, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_half_off, (size_t)num_atoms + 1))) return cleanup(rc);
