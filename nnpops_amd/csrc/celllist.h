@@ -540,6 +540,43 @@ __device__ __forceinline__ PrefixStencil gather_prefix_stencil(const CellGrid& g
     return S;
 }
 
+// The same prefixes in the per-lane form of WideStencil: the range of a candidate is then found with wide_stencil_slot
+// (LDS marks + prefix maximum, ~20 instructions) instead of the 26-step compare chain below, and nothing is read back
+// lane by lane.  The wrap of the cell coordinates is a compare and an add, not three modulo operations by run-time values.
+__device__ __forceinline__ WideStencil gather_prefix_stencil_wide(const CellGrid& g, const int* __restrict__ cell_start,
+                                                                 const int* __restrict__ sorted_atom, int cx, int cy, int cz, int row) {
+    const int lane = lane_id();
+    int begin = 0, count = 0;
+    if (lane < kStencilCells) {
+        const int lz = lane / 9, ly = (lane / 3) % 3, lx = lane % 3;            // (constant divisors)
+        int z = cz + lz - 1, y = cy + ly - 1, x = cx + lx - 1;
+        bool live = true;
+        if (g.periodic) {                                                      // every axis has at least 3 cells
+            z += z < 0 ? g.nz : 0; z -= z >= g.nz ? g.nz : 0;
+            y += y < 0 ? g.ny : 0; y -= y >= g.ny ? g.ny : 0;
+            x += x < 0 ? g.nx : 0; x -= x >= g.nx ? g.nx : 0;
+        } else live = z >= 0 && z < g.nz && y >= 0 && y < g.ny && x >= 0 && x < g.nx;
+        if (live) {
+            const int c = __mul24(__mul24(z, g.ny) + y, g.nx) + x;
+            begin = cell_start[c];
+            int lo = begin, hi = cell_start[c + 1];               // first slot in [lo, hi) whose id is >= row
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sorted_atom[mid] < row) lo = mid + 1;
+                else hi = mid;
+            }
+            count = lo - begin;
+        }
+    }
+    WideStencil S;
+    S.count = count;
+    const int incl = wave_prefix_sum(count);
+    S.pre = incl - count;
+    S.delta = begin - S.pre;
+    S.total = __builtin_amdgcn_readlane(incl, 63);
+    return S;
+}
+
 // (all lanes must call, like stencil_slot)
 __device__ __forceinline__ int stencil_slot(const PrefixStencil& S, int k) {
     int r = 0;

@@ -177,11 +177,20 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
         return found;
     }
     const int c = atom_cell[row];
+    // cell coordinates without integer division: (c + 1/2) / n rounds down correctly for every grid that fits
+    const int nxy = g.nx * g.ny;
+    const int cz = (int)(((float)c + 0.5f) * __builtin_amdgcn_rcpf((float)nxy));
+    const int rem = c - cz * nxy;
+    const int cy = (int)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)g.nx));
+    const int cx = rem - cy * g.nx;
     // only partners with a smaller id: the prefix of every stencil cell (celllist.h), half the candidates of the full walk
-    const PrefixStencil st = gather_prefix_stencil(g, cell_start, sorted_atom, c % g.nx, (c / g.nx) % g.ny, c / (g.nx * g.ny), row);
+    const WideStencil st = gather_prefix_stencil_wide(g, cell_start, sorted_atom, cx, cy, cz, row);
+    __shared__ int strips[4][64];                                          // (256-thread blocks: one strip per wave)
+    int* strip = strips[threadIdx.x >> 6];
+    int carry = 0;
     for (int base = 0; base < st.total; base += 64) {
         const int k = base + lane;
-        const int slot = stencil_slot(st, min(k, st.total - 1));          // all lanes (ds_bpermute inside)
+        const int slot = wide_stencil_slot(st, base, strip, carry);       // all lanes
         const bool have = k < st.total;
         if (sizeof(T) == 4) {
             // fp32: the grid's cell-ordered copy {x, y, z, id} is the same numbers, read coalesced
