@@ -51,7 +51,6 @@ struct nnpops_ani {
     bool fwd_uniform = false;       // every radial factor shares its eta, every angular factor its zeta (set at create; $NNPOPS_ANI_FWD_UNI=0)
     bool fuse_forward = false;      // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h): measured
                                     // EQUAL to the two launches (47.5 vs 23.4 + 19.9 + 2.3 us of boundary at 10k atoms), so off; $NNPOPS_ANI_FUSE=1
-    int rbwd_occ = 8;               // waves per SIMD the lane-per-neighbour radial backward is compiled for (8 or 6)
     bool rbwd_lanes = true;         // radial backward with a lane per neighbour (ani_radial_bwd.h) where rows read as float4
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
@@ -480,7 +479,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
         if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
-        if (const char* e = std::getenv("NNPOPS_ANI_RBWD_OCC")) h->rbwd_occ = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_OCC")) h->fwd_occ = std::atoi(e);
@@ -753,23 +751,23 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
         const Span& sp = spans[q];
         KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD, sp.stream);
         const int nr4 = h->hp.nR / 4;
-        const bool lanes = h->rbwd_lanes && h->hp.nR % 4 == 0 && nr4 >= 1 && nr4 <= 8 && h->ld_radial % 4 == 0 && h->cap_angular == 32 &&
-                           (reinterpret_cast<uintptr_t>(radial_deriv) & 15) == 0;
+        const bool lanes = h->rbwd_lanes && h->hp.nR % 4 == 0 && nr4 >= 1 && nr4 <= 8 && h->ld_radial % 4 == 0 &&
+                           (h->cap_angular == 32 || h->cap_angular == 64) && (reinterpret_cast<uintptr_t>(radial_deriv) & 15) == 0;
         if (lanes) {
             // a lane per neighbour: only this atom's own gradient row is staged in LDS
             const int lw = (int)(((size_t)h->hp.S * h->hp.nR * sizeof(float) + 15) & ~(size_t)15);
             const int wpg = kWavesPerGroup;
-            auto k = ani_radial_backward_lanes<4, 8>;
-            const bool o8 = h->rbwd_occ >= 8;
+            const bool wide = h->cap_angular == 64;
+            auto k = ani_radial_backward_lanes<4, 32>;
             switch (nr4) {
-                case 1: k = o8 ? ani_radial_backward_lanes<1, 8> : ani_radial_backward_lanes<1, 6>; break;
-                case 2: k = o8 ? ani_radial_backward_lanes<2, 8> : ani_radial_backward_lanes<2, 6>; break;
-                case 3: k = o8 ? ani_radial_backward_lanes<3, 8> : ani_radial_backward_lanes<3, 6>; break;
-                case 4: k = o8 ? ani_radial_backward_lanes<4, 8> : ani_radial_backward_lanes<4, 6>; break;
-                case 5: k = o8 ? ani_radial_backward_lanes<5, 8> : ani_radial_backward_lanes<5, 6>; break;
-                case 6: k = o8 ? ani_radial_backward_lanes<6, 8> : ani_radial_backward_lanes<6, 6>; break;
-                case 7: k = o8 ? ani_radial_backward_lanes<7, 8> : ani_radial_backward_lanes<7, 6>; break;
-                default: k = o8 ? ani_radial_backward_lanes<8, 8> : ani_radial_backward_lanes<8, 6>; break;
+                case 1: k = wide ? ani_radial_backward_lanes<1, 64> : ani_radial_backward_lanes<1, 32>; break;
+                case 2: k = wide ? ani_radial_backward_lanes<2, 64> : ani_radial_backward_lanes<2, 32>; break;
+                case 3: k = wide ? ani_radial_backward_lanes<3, 64> : ani_radial_backward_lanes<3, 32>; break;
+                case 4: k = wide ? ani_radial_backward_lanes<4, 64> : ani_radial_backward_lanes<4, 32>; break;
+                case 5: k = wide ? ani_radial_backward_lanes<5, 64> : ani_radial_backward_lanes<5, 32>; break;
+                case 6: k = wide ? ani_radial_backward_lanes<6, 64> : ani_radial_backward_lanes<6, 32>; break;
+                case 7: k = wide ? ani_radial_backward_lanes<7, 64> : ani_radial_backward_lanes<7, 32>; break;
+                default: k = wide ? ani_radial_backward_lanes<8, 64> : ani_radial_backward_lanes<8, 32>; break;
             }
             hipLaunchKernelGGL(k, dim3(div_up(sp.nw, wpg)), dim3(64 * wpg), (size_t)lw * wpg, sp.stream, h->d_params, h->d_species, h->d_nbr,
                                h->cap, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,

@@ -18,15 +18,15 @@
 
 namespace nnpops {
 
-template <int NR4, int OCC>
-__global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_lanes(
+template <int NR4, int CAPA>
+__global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_lanes(
     const AniParams* __restrict__ P, const int* __restrict__ species, const float4* __restrict__ nbr, int cap,
     const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro, const float* __restrict__ radial_grad, int ld_radial,
     const int* __restrict__ ids, const float4* __restrict__ leg_force, const float4* __restrict__ centre_force,
     const int* __restrict__ order,     // atoms in cell order, or NULL
     float* __restrict__ pos_grad, int lds_per_wave, int w0, int nw) {
-    constexpr int NR = 4 * NR4, CAPA = 32;
-    constexpr bool EARLY_IDS = OCC < 8;                    // id rows requested together with the gradient rows (16 more registers)
+    constexpr int NR = 4 * NR4;
+    constexpr int QL = CAPA / 4, RPP = 64 / QL, NT = CAPA / RPP;      // id row = QL 16-byte pieces; RPP rows per pass of the wave; NT passes cover a row's worth of neighbours
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float* g_own = (float*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);      // [S * NR] this atom's gradient row
     const int lane = lane_id();
@@ -60,18 +60,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_
         float4 gj[NR4];
 #pragma unroll
         for (int c = 0; c < NR4; c++) gj[c] = grow[c];
-        int4 idv[4];
-        int jt[4];
-        auto request_ids = [&]() {
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int et = (lane >> 3) + 8 * t;        // (angular neighbours are the first na of the row: pass 0 only)
-                jt[t] = __shfl(j, et, 64);
-                idv[t] = make_int4(-1, -1, -1, -1);
-                if (base == 0 && et < na) idv[t] = reinterpret_cast<const int4*>(ids + (size_t)jt[t] * CAPA)[lane & 7];
-            }
-        };
-        if (EARLY_IDS) request_ids();
         const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         const float rinv = fast_rcp(r);
         float sn, cs;
@@ -93,20 +81,33 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, OCC) void ani_radial_backward_
         }
         s = live ? s * P->radial_scale * rinv : 0.f;
         fx -= s * rec.x; fy -= s * rec.y; fz -= s * rec.z;
-        // reverse lookup of the angular legs, all lanes together: lane l scans quarter-row (l & 7) of the id rows of
-        // angular neighbours (l >> 3) + 8 t -- one 16-byte load per lane and t, all of them in flight with the gathers
-        if (!EARLY_IDS) request_ids();
-        // angular legs: whoever finds this atom in a neighbour's id row (rows are padded with -1) fetches that leg
+        // Reverse lookup of the angular legs, all lanes together: lane l scans piece (l % QL) of the id rows of angular
+        // neighbours l / QL + RPP t -- one 16-byte load per lane and t, four t in flight; whoever finds this atom in a
+        // neighbour's id row (rows are padded with -1) fetches that leg (the partial forces meet in the wave sum).
+        // (Requesting the id rows together with the gradient rows costs 16 more registers and measured the same.)
+        if (base == 0) {                                       // angular neighbours are the first na <= CAPA <= 64 of the row
+            for (int t0 = 0; t0 < NT && t0 * RPP < na; t0 += 4) {
+                int4 idv[4];
+                int jt[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            int slot = -1;
-            slot = idv[t].x == i ? 0 : slot;
-            slot = idv[t].y == i ? 1 : slot;
-            slot = idv[t].z == i ? 2 : slot;
-            slot = idv[t].w == i ? 3 : slot;
-            if (slot >= 0) {
-                const float4 f = leg_force[(size_t)jt[t] * CAPA + 4 * (lane & 7) + slot];
-                fx += f.x; fy += f.y; fz += f.z;
+                for (int t = 0; t < 4; t++) {
+                    const int et = lane / QL + RPP * (t0 + t);
+                    jt[t] = __shfl(j, et & 63, 64);
+                    idv[t] = make_int4(-1, -1, -1, -1);
+                    if (et < na) idv[t] = reinterpret_cast<const int4*>(ids + (size_t)jt[t] * CAPA)[lane % QL];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    int slot = -1;
+                    slot = idv[t].x == i ? 0 : slot;
+                    slot = idv[t].y == i ? 1 : slot;
+                    slot = idv[t].z == i ? 2 : slot;
+                    slot = idv[t].w == i ? 3 : slot;
+                    if (slot >= 0) {
+                        const float4 f = leg_force[(size_t)jt[t] * CAPA + 4 * (lane % QL) + slot];
+                        fx += f.x; fy += f.y; fz += f.z;
+                    }
+                }
             }
         }
     }
