@@ -239,7 +239,7 @@ def run_aev(args, R):
 
     sym.compute(tpos, tbox, radial, angular, check=True)     # calibrates neighbour capacity (blocks)
     # Warm-up, with events around EVERY kernel: the per-kernel breakdown (diagnostic) and the choice of the
-    # dominant kernel.  An event costs ~4.5 us of stream time (profiles/r02e_timeline.txt: the two gaps of a step sit
+    # dominant kernel.  An event costs ~4.5 us of stream time (profiles/r02f_timeline.txt: the two gaps of a step sit
     # exactly around the bracketed kernel), so inside the timed region only the dominant kernel -- the one the roofline
     # line is about -- is bracketed, and only on every 8th step.
     sym.enable_timing(True)

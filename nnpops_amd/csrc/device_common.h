@@ -126,7 +126,7 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
 // Write-through stores (sc1): the line stays valid in this XCD's L2 for the kernel that reads it next and is written to
 // memory right away, so it is not part of the dirty-line write-back every kernel ends with.  A kernel that leaves tens
 // of MB dirty (the neighbour build: 27 MB of rows and records) otherwise delays the start of the next one by ~5 us
-// (profiles/r02e_timeline.txt); `nt` stores would also avoid that but evict the lines the next kernel wants.
+// (profiles/r02f_timeline.txt); `nt` stores would also avoid that but evict the lines the next kernel wants.
 typedef float f4_vec __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_wt(float4* p, const float4& v) {
     const f4_vec t = {v.x, v.y, v.z, v.w};
