@@ -228,14 +228,31 @@ def run_aev(args, R):
     gen = torch.Generator(device=dev).manual_seed(7)
     g_rad = torch.randn(radial.shape, device=dev, generator=gen)
     g_ang = torch.randn(angular.shape, device=dev, generator=gen)
-    grad = torch.empty((n, 3), device=dev)
-    all_forces = torch.empty((world * n, 3), device=dev) if dist else None
+    # Two sets of force buffers: the all_gather of step s runs on RCCL's stream while the kernels of step s + 1 run on
+    # ours, and a buffer is written again only after the gather that read it (two steps back) has been waited for -- a
+    # stream-level wait, never the host.  Synchronously the ~20 us latency of a small all_gather over xGMI would be added to
+    # every 90 us step.  With one rank nothing of this exists and `grad` is one buffer.
+    grads = [torch.empty((n, 3), device=dev) for _ in range(2 if dist else 1)]
+    gathered = [torch.empty((world * n, 3), device=dev) for _ in range(2)] if dist else None
+    pending = [None, None]
+    counter = [0]
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def step():
+        b = counter[0] & 1 if dist else 0
+        counter[0] += 1
+        if dist and pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
         sym.compute(tpos, tbox, radial, angular, check=False)
-        sym.backprop(g_rad, g_ang, grad)
+        sym.backprop(g_rad, g_ang, grads[b])
         if dist:                                              # the path's only exchange: per-atom forces of every frame
-            dist.all_gather_into_tensor(all_forces, grad)
+            pending[b] = dist.all_gather_into_tensor(gathered[b], grads[b], async_op=True)
 
     sym.compute(tpos, tbox, radial, angular, check=True)     # calibrates neighbour capacity (blocks)
     # Warm-up, with events around EVERY kernel: the per-kernel breakdown (diagnostic) and the choice of the
@@ -257,15 +274,18 @@ def run_aev(args, R):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                                   # every gather of the timed steps has completed on our stream
     R.barrier()
     elapsed = time.perf_counter() - t0
     timing = sym.get_timing()
     sym.enable_timing(False)
     max_row, max_ang = sym.neighbor_stats()
     assert lib().nnpops_ani_check(sym._h, None, None) == OK, "neighbour buffers overflowed inside the timed region"
+    last = (counter[0] - 1) & 1 if dist else 0
+    grad = grads[last]
     assert bool(torch.isfinite(grad).all())
     if dist:
-        assert bool(torch.equal(all_forces[rank * n:(rank + 1) * n], grad))
+        assert bool(torch.equal(gathered[last][rank * n:(rank + 1) * n], grad))
     elapsed = R.max_over_ranks(elapsed)
     if rank != 0:
         return None
