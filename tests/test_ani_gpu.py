@@ -251,6 +251,37 @@ def test_large_cluster_in_vacuum_uses_the_cell_grid(monkeypatch, fine):
     _run_case(7, 5.1, 3.5, species, rf, af, pos, None, algorithm=2)
 
 
+def test_kernel_timing_brackets_and_stride():
+    """nnpops_ani_enable_timing / _set_timing_stride / _get_timing: HIP events around the kernels a benchmark selects, on
+    every k-th launch; counters reset by get_timing; results unchanged by the brackets."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1500, seed=71)
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+    radial, angular = sym.compute(tpos, tbox)
+    ref = sym.backprop(torch.ones_like(radial), torch.ones_like(angular)).clone()
+    sym.enable_timing(True)
+    for _ in range(6):
+        sym.compute(tpos, tbox, radial, angular, check=False)
+        grad = sym.backprop(torch.ones_like(radial), torch.ones_like(angular))
+    t = sym.get_timing()
+    assert t["radial_forward"][1] == 0                         # the radial AEV is written by the neighbour kernel
+    for k in ("neighbors", "angular_forward", "radial_backward", "angular_backward", "cell_grid"):
+        ms, launches = t[k]
+        assert launches == 6 and 0.0 < ms / launches < 5.0, (k, t[k])
+    assert torch.equal(grad, ref)
+    assert all(c == 0 for _, c in sym.get_timing().values())  # reset by the previous call
+    sym.enable_timing(True, only=["angular_forward"], every=4)
+    for _ in range(8):
+        sym.compute(tpos, tbox, radial, angular, check=False)
+    t = sym.get_timing()
+    assert t["angular_forward"][1] == 2 and t["neighbors"][1] == 0, t
+    assert sym.timing_overhead() >= 0.0
+    sym.enable_timing(False)
+
+
 def test_single_atom_and_isolated_atoms():
     rf, af = workloads.ani2x_functions()
     pos = np.array([[0, 0, 0], [30, 0, 0], [0, 30, 0]], dtype=np.float32)
