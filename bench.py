@@ -176,13 +176,21 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a HIP device (there is no CPU fallback in the product path)")
+        # ($NNPOPS_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a box with ONE device -- the ranks share it,
+        #  the collectives go through the host; numbers from such a run mean nothing)
+        backend = os.environ.get("NNPOPS_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            self.local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # "nccl" is RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)   # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
             self.dist = dist
 
     def barrier(self):

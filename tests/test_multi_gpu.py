@@ -62,3 +62,24 @@ def test_two_ranks_gather_exactly_the_single_gpu_forces(tmp_path):
     single = _forces(0, sizes, 0, len(sizes)).cpu()
     for rank in range(2):
         assert torch.equal(torch.load(tmp_path / f"full_{rank}.pt"), single)
+
+
+def test_two_rank_bench_rehearsal_on_one_device():
+    """bench.py's multi-rank headline (own frame per rank, asynchronous all_gather of the forces with two buffer sets,
+    bitwise self-check of the gathered block, one JSON line from rank 0) rehearsed with TWO ranks sharing ONE device over
+    gloo ($NNPOPS_BENCH_BACKEND): the code path the driver's 8-GPU run takes, minus RCCL.  The numbers mean nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NNPOPS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--atoms", "2000", "--no-side", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 12 and line["scaling"] == "weak" and line["value"] > 0
+    assert "roofline" in line and line["config"]["atoms"] == 2000
