@@ -120,6 +120,7 @@ constexpr int kCellThreshold = 8192;        // below this the N^2/2 scan is chea
 enum { kStage = 0, kEmit = 1 };
 
 template <typename T> struct Staged { T dx, dy, dz, dist; };
+template <typename T> __device__ constexpr T kTieTol() { return sizeof(T) == 4 ? T(1e-6) : T(1e-14); }
 
 template <typename T, int MODE>
 __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, const T* __restrict__ box, int periodic, T cutoff2,
@@ -130,18 +131,40 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
                                         int32_t* __restrict__ neighbors, T* __restrict__ deltas, T* __restrict__ distances) {
     const int lane = lane_id();
     int found = 0;
+    const T inv_x = periodic ? T(1) / box[0] : T(0), inv_y = periodic ? T(1) / box[4] : T(0), inv_z = periodic ? T(1) / box[8] : T(0);
     auto visit = [&](bool have, int col, Vec3<T> d) {
         bool keep = false;
         T d2 = 0;
-        if (have && col < row) {
-            if (periodic) {
-                const T s3 = round(d.z / box[8]);
-                d.x -= s3 * box[6]; d.y -= s3 * box[7]; d.z -= s3 * box[8];
-                const T s2 = round(d.y / box[4]);
-                d.x -= s2 * box[3]; d.y -= s2 * box[4];
-                const T s1 = round(d.x / box[0]);
-                d.x -= s1 * box[0];
+        const bool active = have && col < row;
+        if (periodic) {
+            // round(v / b) of the reference (CUDA.cu:54-63), bit for bit, at the price of a multiply and v_rndne: the quotient
+            // by reciprocal is within 2e-7 |q| (fp32) of the divided one, so unless it lies that close to a half-integer both
+            // round to the same integer; a wave that sees such a candidate redoes the batch with the division (rare: uniform
+            // branch).  Three IEEE divisions and three round() were 51 of the ~150 instructions per batch.
+            const Vec3<T> d0 = d;
+            bool near = false;
+            auto rq = [&](T v, T inv) {
+                const T q = v * inv, s = rint(q);
+                near = near || (fabs(q - s) > T(0.5) - kTieTol<T>() * (fabs(q) + T(1)));
+                return s;
+            };
+            const T s3 = rq(d.z, inv_z);
+            d.x -= s3 * box[6]; d.y -= s3 * box[7]; d.z -= s3 * box[8];
+            const T s2 = rq(d.y, inv_y);
+            d.x -= s2 * box[3]; d.y -= s2 * box[4];
+            const T s1 = rq(d.x, inv_x);
+            d.x -= s1 * box[0];
+            if ((periodic & 2) || __any(active && near)) {           // (bit 1: $NNPOPS_PAIRS_DIVIDE=1, the division for every candidate)
+                d = d0;
+                const T e3 = round(d.z / box[8]);
+                d.x -= e3 * box[6]; d.y -= e3 * box[7]; d.z -= e3 * box[8];
+                const T e2 = round(d.y / box[4]);
+                d.x -= e2 * box[3]; d.y -= e2 * box[4];
+                const T e1 = round(d.x / box[0]);
+                d.x -= e1 * box[0];
             }
+        }
+        if (active) {
             d2 = d.x * d.x + d.y * d.y + d.z * d.z;
             keep = !(d2 > cutoff2);
         }
@@ -450,11 +473,12 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
         launch_cell_build(stream, N, fpos, fbox, periodic != 0, (float)cutoff, nullptr, cb);
         const dim3 rgrid(div_up(N, 4)), rblock(256);       // one wave per row
         Staged<T>* st_rec = (Staged<T>*)w.st_rec;
-        hipLaunchKernelGGL(pairs_cells_stage<T>, rgrid, rblock, 0, stream, N, pos, box, periodic, cutoff2, w.grid, w.cell_start,
+        const int periodic_flags = periodic | ((periodic && std::getenv("NNPOPS_PAIRS_DIVIDE") && std::atoi(std::getenv("NNPOPS_PAIRS_DIVIDE"))) ? 2 : 0);
+        hipLaunchKernelGGL(pairs_cells_stage<T>, rgrid, rblock, 0, stream, N, pos, box, periodic_flags, cutoff2, w.grid, w.cell_start,
                            w.atom_cell, w.sorted_atom, w.sorted_pos, w.st_col, st_rec, w.row_count, ticket);
         hipLaunchKernelGGL(scan_rows, dim3(nscan), dim3(kScanBlock), 0, stream, N, w.row_count, w.row_offset, w.block_prefix, ticket,
                            num_pairs);
-        hipLaunchKernelGGL(pairs_cells_emit<T>, rgrid, rblock, 0, stream, N, pos, box, periodic, cutoff2, num_slots, w.grid,
+        hipLaunchKernelGGL(pairs_cells_emit<T>, rgrid, rblock, 0, stream, N, pos, box, periodic_flags, cutoff2, num_slots, w.grid,
                            w.cell_start, w.atom_cell, w.sorted_atom, w.sorted_pos, w.st_col, st_rec, w.row_count, w.row_offset,
                            w.block_prefix, neighbors, deltas, distances);
     } else {

@@ -153,3 +153,51 @@ def test_large_system_cell_grid_float64_matches_float32_pairs():
     d -= np.round(d / L) * L
     np.testing.assert_allclose(dl64[:n64], d, rtol=0, atol=1e-12)
     np.testing.assert_allclose(ds64[:n64], np.sqrt((d * d).sum(1)), rtol=1e-14)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_minimum_image_ties_take_the_division(monkeypatch, dtype):
+    """The cell-grid path rounds the scaled displacement by reciprocal multiply + round-to-nearest-even and redoes a batch
+    with the reference's round(d / L) when a candidate sits at a half-integer (neighbor_pairs.hip).  A lattice whose
+    spacing divides half the box, with the cutoff exactly half the box, is made of such candidates -- and keeps them
+    (d2 <= cutoff2): the deltas, signs included, must equal those of the all-division build bit for bit, and the oracle's."""
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    m, a = 22, 2.0                                             # 22^3 = 10 648 atoms (above the all-pairs threshold), L = 44
+    g = np.arange(m, dtype=npdt) * npdt(a)
+    pos = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(npdt)
+    rng = np.random.default_rng(9)
+    pos[rng.choice(len(pos), 3000, replace=False)] += rng.normal(0, 0.05, (3000, 3)).astype(npdt)   # and ordinary candidates
+    box = np.diag([m * a] * 3).astype(npdt)
+    cutoff = 4.0
+    fast = _run(pos, cutoff, 2000000, box, dtype)
+    monkeypatch.setenv("NNPOPS_PAIRS_DIVIDE", "1")
+    exact = _run(pos, cutoff, 2000000, box, dtype)
+    assert fast[3] == exact[3] and fast[3] > 100000
+    for x, y in zip(fast[:3], exact[:3]):
+        assert np.array_equal(x, y, equal_nan=True)
+    # ties that are KEPT: the cutoff is exactly half the box along x, and columns of four atoms share their (y, z): the pairs
+    # half a box apart have d2 == cutoff2 exactly, and the sign of their delta is the reference's round-half-away
+    monkeypatch.delenv("NNPOPS_PAIRS_DIVIDE")
+    rc = npdt(5.0)
+    yz = rng.uniform(0, 40, (2048, 2)).astype(npdt)
+    cols = np.concatenate([np.concatenate([np.full((2048, 1), x, npdt), yz], 1) for x in (0.0, 2.5, 5.0, 7.5)]).astype(npdt)
+    cols = cols[rng.permutation(len(cols))]
+    cbox = np.diag([10.0, 40.0, 40.0]).astype(npdt)
+    f2 = _run(cols, float(rc), 3000000, cbox, dtype)
+    monkeypatch.setenv("NNPOPS_PAIRS_DIVIDE", "1")
+    e2 = _run(cols, float(rc), 3000000, cbox, dtype)
+    assert f2[3] == e2[3]
+    for x, y in zip(f2[:3], e2[:3]):
+        assert np.array_equal(x, y, equal_nan=True)
+    n = f2[3]
+    assert int(np.count_nonzero(np.abs(f2[1][:n, 0]) == 5.0)) >= 4096          # the two tie pairs of every column were kept
+    ref = neighbor_pairs_oracle(cols, float(rc), -1, cbox)
+    got = _sorted(f2[0][:, :n], f2[1][:n], f2[2][:n])
+    ok = ref[0][0] >= 0
+    want = _sorted(ref[0][:, ok], ref[1][ok], ref[2][ok])
+    assert n == int(ok.sum()) and np.array_equal(got[0], want[0])
+    # (the numpy oracle rounds half to even like the reference's CPU op, the device code half away from zero like its CUDA
+    #  kernel, oracle/neighbors_oracle.py: at the exact ties the two pick opposite images -- same length, opposite sign)
+    tie = np.abs(want[1][:, 0]) == 5.0
+    assert np.array_equal(got[1][~tie], want[1][~tie]) and np.array_equal(np.abs(got[1][tie]), np.abs(want[1][tie]))
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-6 if dtype == torch.float32 else 1e-14)
