@@ -115,7 +115,7 @@ int nnpops_ani_set_molecules(nnpops_ani_t h, int num_molecules, const int32_t* m
 enum {
     NNPOPS_ANI_K_NEIGHBORS = 0,       /* neighbour rows + records + triple lists + radial AEV (one launch) */
     NNPOPS_ANI_K_RADIAL_FWD = 1,      /* always 0 launches: the radial AEV is written by the neighbour kernel */
-    NNPOPS_ANI_K_ANGULAR_FWD = 2,
+    NNPOPS_ANI_K_ANGULAR_FWD = 2,     /* 0 launches for small systems: build + radial + angular forward are one kernel there, timed as NEIGHBORS */
     NNPOPS_ANI_K_RADIAL_BWD = 3,
     NNPOPS_ANI_K_ANGULAR_BWD = 4,
     NNPOPS_ANI_K_CELL_GRID = 5,       /* the grid build in front of the neighbour kernel (2 or 5 launches; 0 for all-pairs) */

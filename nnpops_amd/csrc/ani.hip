@@ -49,8 +49,10 @@ struct nnpops_ani {
     // the tail of every launch overlap with the steady state of the other spans' launches (two half-size evaluations on two
     // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
     bool fwd_uniform = false;       // every radial factor shares its eta, every angular factor its zeta (set at create; $NNPOPS_ANI_FWD_UNI=0)
-    bool fuse_forward = false;      // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h): measured
-                                    // EQUAL to the two launches (47.5 vs 23.4 + 19.9 + 2.3 us of boundary at 10k atoms), so off; $NNPOPS_ANI_FUSE=1
+    int fuse_forward = -1;          // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h).  -1: for
+                                    // systems of up to kFuseAtoms atoms, where a launch less is worth 6-13 % of a step (600 atoms:
+                                    // 33.7 -> 29.6 us, 3 000: 49.5 -> 46.3) -- at 5 000 it breaks even and at 10 000 its lower
+                                    // occupancy makes it equal to the two launches; $NNPOPS_ANI_FUSE=0 / 1 forces
     bool rbwd_lanes = true;         // radial backward with a lane per neighbour (ani_radial_bwd.h) where rows read as float4
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
@@ -324,7 +326,9 @@ int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out, co
 
 // The fused neighbour build + angular forward (ani_build_forward.h): the ANI-1x / ANI-2x factor shape, two waves per atom.
 bool build_forward_fused(const nnpops_ani* h, const float* angular) {
-    return h->fuse_forward && !h->generic && h->forward_kernel == 2 && h->fwd_waves_per_atom == 2 && h->nfrp == 8 && h->nfzp == 4 &&
+    constexpr int kFuseAtoms = 4096;
+    const bool want = h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0;
+    return want && !h->generic && h->forward_kernel == 2 && h->fwd_waves_per_atom == 2 && h->nfrp == 8 && h->nfzp == 4 &&
            h->nstreams == 1 && h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)angular & 15) == 0 &&
            build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk) <= 160 * 1024;
 }
@@ -334,7 +338,8 @@ int launch_build_forward(nnpops_ani* h, const BuildInputs& in, const BuildOutput
     int tri_offset = 0;
     const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk, &tri_offset) + 15) & ~(size_t)15;
     const int vec_ok = 1 | (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);
-    auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6> : ani_build_forward<TA, 8, 4, 7>;
+    const bool uni = h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4;
+    auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6> : uni ? ani_build_forward<TA, 8, 4, 7, true> : ani_build_forward<TA, 8, 4, 7>;
     if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, h->fwd_chunk, angular,
                        h->ld_angular, vec_ok, tri_offset, sp.w0, sp.nw);
@@ -477,7 +482,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
-        if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;

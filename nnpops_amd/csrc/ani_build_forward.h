@@ -52,7 +52,7 @@ struct BuildOutputs {
     int ld_radial;
 };
 
-template <bool TORCHANI, int NFRP, int NFZP, int OCC>
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, bool UNI = false>
 __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* __restrict__ P, BuildInputs in, BuildOutputs out, int cap,
                                                               int capA, int CH, float* __restrict__ angular, int ld_angular,
                                                               int vec_ok, int tri_offset, int w0, int nw) {
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
         __syncthreads();
         // (the forward's constants are set up here, not before the build: they would be live across it -- 32 scalars the
         //  build has no room for)
-        MfmaForward<TORCHANI, NFRP, NFZP, 2> F;
+        MfmaForward<TORCHANI, NFRP, NFZP, 2, UNI> F;
         F.init(P, capA, CH, vec_ok, angular, ld_angular, lds_raw, role);
         F.atom(i, n, [&](int t) { return tri_l[t]; }, [&](int bk) { return G.boff[bk]; }, [&]() { F.write_zero_record(); });
     }

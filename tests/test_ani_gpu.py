@@ -207,6 +207,7 @@ def test_both_angular_forward_kernels(monkeypatch, kernel, kind):
     list for few well-filled species pairs, run merging for many equally likely species); $NNPOPS_ANI_FORWARD forces
     either, and both must pass on every kind of system."""
     monkeypatch.setenv("NNPOPS_ANI_FORWARD", kernel)
+    monkeypatch.setenv("NNPOPS_ANI_FUSE", "0")                 # (the stand-alone kernels; test_fused_build_and_forward covers the fused one)
     rf, af = workloads.ani2x_functions()
     if kind == "water":
         pos, species, box = workloads.water_box(350, seed=31)
@@ -219,9 +220,10 @@ def test_both_angular_forward_kernels(monkeypatch, kernel, kind):
 
 @pytest.mark.parametrize("kind", ["water", "seven_species", "dense", "vacuum", "triclinic", "tiny_box"])
 def test_fused_build_and_forward(monkeypatch, kind):
-    """$NNPOPS_ANI_FUSE=1: neighbour build, radial and angular AEV of an atom in one workgroup (ani_build_forward.h, not
-    the default: it measured equal to the two launches).  Same answers on every kind of system, including the all-pairs
-    search (vacuum) and a box too small for the cell stencil (the handle falls back and recomputes)."""
+    """$NNPOPS_ANI_FUSE=1: neighbour build, radial and angular AEV of an atom in one workgroup (ani_build_forward.h; the
+    default for systems of up to 4096 atoms, where a launch less is worth 6-13 % of a step).  Same answers on every kind
+    of system, including the all-pairs search (vacuum) and a box too small for the cell stencil (the handle falls back
+    and recomputes)."""
     monkeypatch.setenv("NNPOPS_ANI_FUSE", "1")
     rf, af = workloads.ani2x_functions()
     box = None
@@ -251,10 +253,12 @@ def test_large_cluster_in_vacuum_uses_the_cell_grid(monkeypatch, fine):
     _run_case(7, 5.1, 3.5, species, rf, af, pos, None, algorithm=2)
 
 
-def test_kernel_timing_brackets_and_stride():
+def test_kernel_timing_brackets_and_stride(monkeypatch):
     """nnpops_ani_enable_timing / _set_timing_stride / _get_timing: HIP events around the kernels a benchmark selects, on
-    every k-th launch; counters reset by get_timing; results unchanged by the brackets."""
+    every k-th launch; counters reset by get_timing; results unchanged by the brackets.  (Two launches for build and
+    angular forward: a system this small would otherwise take the fused kernel, which is timed as the build.)"""
     from nnpops_amd.capi import AniSymmetryFunctions
+    monkeypatch.setenv("NNPOPS_ANI_FUSE", "0")
     rf, af = workloads.ani2x_functions()
     pos, species, box = workloads.random_box(1500, seed=71)
     dev = torch.device("cuda:0")

@@ -40,8 +40,10 @@ def _random_geometry(rng, n, kind, density):
 
 
 @pytest.mark.parametrize("seed", list(range(52)) + list(range(100, 100 + 52 * (SCALE - 1))))        # seeds 40..51 (and 1 in 4 of the soak seeds): dense systems (row / record capacities grow, >32 angular neighbours)
-def test_ani_random_configuration(seed):
+def test_ani_random_configuration(seed, monkeypatch):
     from nnpops_amd.capi import AniSymmetryFunctions
+    # systems this small take the fused build + forward kernel by default: every other seed keeps the two-launch path covered
+    monkeypatch.setenv("NNPOPS_ANI_FUSE", str(seed % 2))
     rng = np.random.default_rng(1000 + seed)
     S = int(rng.integers(1, 9))
     n_eta_r, n_shf_r = int(rng.integers(1, 3)), int(rng.integers(1, 13))
