@@ -401,7 +401,7 @@ def run_latency(args, R):
            "unit": "us/eval", "higher_is_better": False, "eager_us": round(eager_us, 2), "hip_graph_us": round(graph_us, 2),
            "algorithmic_bytes": 50 * (16 + 2 * 1008 * 4 + 12),
            "config": {"workload": "BASELINE config 1: 50-atom conformer (seed 0), non-periodic, all-pairs neighbour search, "
-                                  "5 launches per evaluation; latency-bound (0.4 MB of algorithmic traffic)"}}
+                                  "3 launches per evaluation (fused build + forward, two backward kernels); latency-bound (0.4 MB of algorithmic traffic)"}}
     if not args.no_cpu_baseline:
         kind, cls = _cpu_classes()
         dt = _ani_eval_seconds(cls, pos, species, None, rf, af, repeats=20)
