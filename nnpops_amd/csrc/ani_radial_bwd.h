@@ -4,11 +4,13 @@
 // atom, each with its own gather of a neighbour's gradient row -- five round trips to memory in a row even when
 // unrolled by four, and nine LDS reads per step.  The kernel is bound by that latency times the number of occupancy
 // rounds, not by arithmetic.  Here a lane owns one NEIGHBOUR: its 16 gradient values arrive as four 16-byte loads
-// issued at once (one round trip), the id row for the reverse lookup of the angular leg force is requested in the
-// same breath, and the sum over k runs in registers with the function parameters as scalar operands:
-//     rows of the atom (1 round trip) -> gradient rows + id rows of its neighbours (1) -> leg forces (1).
-// ~280 vector instructions per atom instead of 680.  Used when rows can be read as float4 (nR % 4 == 0, ld % 4 == 0,
-// 16-byte aligned gradient tensor) and id rows are 32 wide; everything else takes ani_radial_backward.
+// issued at once (one round trip), the sum over k runs in registers with the function parameters as scalar operands,
+// and the reverse lookup of the angular leg forces is done by all 64 lanes together:
+//     row of the atom (requested before its counts are known) -> gradient rows of its neighbours -> their id rows
+//     -> leg forces.
+// ~400 vector instructions per atom instead of 680, 64 registers (8 waves per SIMD).  Used when rows can be read as
+// float4 (nR % 4 == 0, ld % 4 == 0, 16-byte aligned gradient tensor) and id rows are 32 or 64 wide; everything else takes
+// ani_radial_backward.
 //
 // Semantics: reference src/ani/CpuANISymmetryFunctions.cpp:228-263 (radial part), :310-344 (angular legs, here
 // gathered by the owner from leg_force / centre_force written by the angular backward kernel).
