@@ -48,6 +48,7 @@ struct nnpops_ani {
     // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
     // the tail of every launch overlap with the steady state of the other spans' launches (two half-size evaluations on two
     // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
+    bool backward_forced = false;   // $NNPOPS_ANI_BACKWARD given: no automatic choice of the two-wave kernel for dense systems
     bool fwd_uniform = false;       // every radial factor shares its eta, every angular factor its zeta (set at create; $NNPOPS_ANI_FWD_UNI=0)
     int fuse_forward = -1;          // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h).  -1: for
                                     // systems of up to kFuseAtoms atoms, where a launch less is worth 6-13 % of a step (600 atoms:
@@ -255,6 +256,10 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         // layout); 2 = one wave, gradient row staged in LDS; 3 / 4 = the same two with two waves per atom (A/B only)
         const int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)grad_or_null & 15) == 0;
         int mode = h->backward_kernel;
+        // Dense systems (64 or more record slots): the pair matrix is 27 KB per atom and only 6 atoms fit a CU -- six waves
+        // where twenty could run.  Two waves per atom double the waves on the same LDS (1 024 conformers: 1.03 -> 0.97 ms per
+        // batch); with the usual 32 slots one wave per atom wins (section 3.5 of DESIGN.md).
+        if (mode == 1 && !h->backward_forced && ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, false) > 16 * 1024) mode = 3;
         if (!vec_ok && (mode == 1 || mode == 3)) mode++;
         const bool glds = mode == 2 || mode == 4;
         const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, glds) + 15) & ~(size_t)15;
@@ -264,7 +269,8 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
                          : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, true>
                                                                                        : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
           : mode == 2 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, true>
-          : mode == 3 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false>
+          : mode == 3 ? ((h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false, false, true>
+                                                                                       : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false>)
                       : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, true>;
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
@@ -491,7 +497,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_BWD_APG")) h->bwd_atoms_per_group = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_STORE")) h->store_mode = std::atoi(e) & 3;
         if (const char* e = std::getenv("NNPOPS_ANI_OCC")) h->occ6 = std::atoi(e) >= 6;
-        if (const char* e = std::getenv("NNPOPS_ANI_BACKWARD")) h->backward_kernel = std::min(4, std::max(0, std::atoi(e)));
+        if (const char* e = std::getenv("NNPOPS_ANI_BACKWARD")) { h->backward_kernel = std::min(4, std::max(0, std::atoi(e))); h->backward_forced = true; }
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_WPA")) h->fwd_waves_per_atom = std::atoi(e) == 1 ? 1 : 2;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_APG")) h->fwd_atoms_per_group = std::max(1, std::atoi(e));
     }
