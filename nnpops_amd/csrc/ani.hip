@@ -703,11 +703,11 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
         } else if (per)
             hipLaunchKernelGGL(ani_neighbors_allpairs<true>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
                                h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                               h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
+                               h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
         else
             hipLaunchKernelGGL(ani_neighbors_allpairs<false>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
                                h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                               h->d_cnt_a, h->d_cnt_ro, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
+                               h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
         }
         NNPOPS_HIP_TRY(hipGetLastError());
         // (the radial AEV is written by the builder wave itself: radial_forward_from_lds)
@@ -799,6 +799,15 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
     int st[kStatWords] = {0, 0, 0, 0};
+    // The builders flag their own overflow (and a void grid): when nobody asks for the statistics and nothing was flagged,
+    // this is one 4-byte copy and a synchronisation -- no pass over the counts, no memset.  (The torch op checks after
+    // every forward.)
+    const bool want_stats = max_radial_neighbors || max_angular_neighbors || !h->cap_fitted || h->backward_kernel == 0;
+    if (!want_stats) {
+        NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+        if (st[kStatOverflow] == 0) return NNPOPS_OK;
+    }
     hipLaunchKernelGGL(ani_row_stats, dim3(std::min(64, div_up(h->hp.N, 256))), dim3(256), 0, h->stream, h->hp.N, h->d_cnt_a,
                        h->d_cnt_ro, h->cap, h->cap_angular, h->d_status);
     NNPOPS_HIP_TRY(hipGetLastError());

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
             if (lane == 0) {
                 out.cnt_a[i] = na; out.cnt_ro[i] = nro;
                 shared[0] = na; shared[1] = nro;
+                if (na > capA || na + nro > cap) atomicOr(&out.status[kStatOverflow], 1);      // (ani_kernels.h: builders flag their own overflow)
             }
         }
         __syncthreads();

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
                                                              int cap, int capA, float4* __restrict__ recA,
                                                              float4* __restrict__ recB, int* __restrict__ ids,
                                                              int* __restrict__ tri,
-                                                             int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
+                                                             int* __restrict__ cnt_a, int* __restrict__ cnt_ro, int* __restrict__ status,
                                                              float* __restrict__ radial, int ld_radial, int lds_per_wave, int w0, int nw) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
@@ -413,7 +413,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
         }
         append_to_row(cap, stage, in_a, in_r && !in_a, dx, dy, dz, word, na, nro);
     }
-    if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
+    if (lane == 0) {
+        cnt_a[i] = na; cnt_ro[i] = nro;
+        // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
+        //  know that nothing overflowed; an atomic only in that rare case)
+        if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
+    }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
@@ -493,7 +498,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
             append_to_row(cap, stage, in_a, in_r & !in_a, dx, dy, dz, word, na, nro);
         }
     }
-    if (lane == 0) { cnt_a[i] = na; cnt_ro[i] = nro; }
+    if (lane == 0) {
+        cnt_a[i] = na; cnt_ro[i] = nro;
+        // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
+        //  know that nothing overflowed; an atomic only in that rare case)
+        if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
+    }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
     wave_fence();
