@@ -86,3 +86,80 @@ def test_full_size_properties_100k_atoms():
     e2, pd2, cd2 = capi.pme_direct(tpos, q, nb[:, :k][:, idx].contiguous(), dl[:k][idx].contiguous(), ds[:k][idx].contiguous(), excl, 0.6, 332.063713)
     assert abs(float(e2) - float(e)) <= 1e-6 * abs(float(e)) + 1e-3
     assert float((pd2 - pd).abs().max()) <= 1e-4 * fmax and float((cd2 - cd).abs().max()) <= 1e-4 * float(cd.abs().max())
+
+
+def _nine_charges():
+    rng = np.random.default_rng(11)
+    pos = torch.tensor((3 * rng.random((9, 3)) - 1).astype(np.float32), device=DEV)
+    charges = torch.tensor([(i - 4) * 0.1 for i in range(9)], dtype=torch.float32, device=DEV)
+    box = torch.tensor([[1, 0, 0], [0, 1.1, 0], [0, 0, 1.2]], dtype=torch.float32, device=DEV)
+    return pos, charges, box
+
+
+def test_double_derivative_raises():
+    """Second derivatives are not implemented and must say so (reference pme/TestPme.py:297-318, direct-space half)."""
+    from NNPOps.pme import PME
+    pos, charges, box = _nine_charges()
+    pos.requires_grad_(); charges.requires_grad_()
+    pme = PME(14, 16, 15, 5, 5.0, 138.935, torch.zeros(9, 0, dtype=torch.int32))
+    edir = pme.compute_direct(pos, charges, 0.5, box)
+    ddir = torch.autograd.grad(edir, pos, retain_graph=True, create_graph=True)
+    with pytest.raises(Exception):
+        torch.autograd.grad(ddir[0].sum(), pos, retain_graph=True)
+    with pytest.raises(Exception):
+        torch.autograd.grad(ddir[0].sum(), charges, retain_graph=True)
+    with pytest.raises(RuntimeError, match="reciprocal"):
+        pme.compute_reciprocal(pos, charges, box)
+
+
+def test_scripted_module_calls_the_direct_space_op():
+    """torch.jit.script of a module around getNeighborPairs + torch.ops.pme.pme_direct (reference pme/TestPme.py test_jit,
+    direct-space half): same energy and forces as the Python class."""
+    from NNPOps.pme import PME
+    from NNPOps.neighbors import getNeighborPairs
+    pos, charges, box = _nine_charges()
+    excl = torch.sort(torch.tensor([[1], [0], [-1], [-1], [-1], [-1], [-1], [-1], [-1]], dtype=torch.int32), descending=True)[0].to(DEV)
+
+    class Direct(torch.nn.Module):
+        def __init__(self, exclusions: torch.Tensor, alpha: float, coulomb: float):
+            super().__init__()
+            self.exclusions, self.alpha, self.coulomb = exclusions, alpha, coulomb
+
+        def forward(self, positions: torch.Tensor, charges: torch.Tensor, box_vectors: torch.Tensor) -> torch.Tensor:
+            neighbors, deltas, distances, _ = getNeighborPairs(positions, 0.5, -1, box_vectors)
+            return torch.ops.pme.pme_direct(positions, charges, neighbors, deltas, distances, self.exclusions, self.alpha, self.coulomb)
+
+    scripted = torch.jit.script(Direct(excl, 5.0, 138.935))
+    p1 = pos.clone().requires_grad_(); p2 = pos.clone().requires_grad_()
+    e1 = scripted(p1, charges, box); e1.backward()
+    e2 = PME(14, 16, 15, 5, 5.0, 138.935, excl.cpu()).compute_direct(p2, charges, 0.5, box); e2.backward()
+    assert torch.equal(e1, e2) and torch.allclose(p1.grad, p2.grad, rtol=1e-6, atol=1e-6)
+
+
+def test_direct_space_replays_as_a_hip_graph():
+    """compute_direct + backward captured into one HIP graph and replayed on moved atoms (reference test_cuda_graph)."""
+    from NNPOps.pme import PME
+    pos, charges, box = _nine_charges()
+    pme = PME(14, 16, 15, 5, 5.0, 138.935, torch.zeros(9, 0, dtype=torch.int32))
+    static_pos = pos.clone().requires_grad_()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                                 # warm-up outside the capture
+        for _ in range(2):
+            e = pme.compute_direct(static_pos, charges, 0.5, box, max_num_pairs=64)
+            e.backward()
+            static_pos.grad = None
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        e = pme.compute_direct(static_pos, charges, 0.5, box, max_num_pairs=64)
+        e.backward()
+    moved = pos + 0.05
+    with torch.no_grad():
+        static_pos.copy_(moved)
+    graph.replay()
+    torch.cuda.synchronize()
+    ref_pos = moved.clone().requires_grad_()
+    e_ref = pme.compute_direct(ref_pos, charges, 0.5, box, max_num_pairs=64)
+    e_ref.backward()
+    assert torch.allclose(e, e_ref, rtol=1e-6, atol=1e-6) and torch.allclose(static_pos.grad, ref_pos.grad, rtol=1e-5, atol=1e-5)
