@@ -263,17 +263,16 @@ def run_aev(args, R):
             pending[b] = dist.all_gather_into_tensor(gathered[b], grads[b], async_op=True)
 
     sym.compute(tpos, tbox, radial, angular, check=True)     # calibrates neighbour capacity (blocks)
-    # A quarter of a second of the same work before anything is counted: the W warm-up steps below are ~5 ms, too short for
+    # About a quarter of a second of the same work before anything is counted: the W warm-up steps below are ~5 ms, too short for
     # the clocks of a device that has just been handed to this process to settle (one run in ten of this benchmark on a
     # fresh box came out 15 % low without it).  Garbage collection pauses are kept out of the loop for the same reason.
     import gc
     gc.collect()
     gc.disable()
-    t_settle = time.perf_counter() + 0.25
-    while time.perf_counter() < t_settle:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(2500 if n <= 20000 else 250):              # (a COUNT, the same on every rank: every step holds a collective)
+        step()
+    drain()
+    torch.cuda.synchronize()
     # Warm-up, with events around EVERY kernel: the per-kernel breakdown (diagnostic) and the choice of the
     # dominant kernel.  An event costs ~4.5 us of stream time (profiles/r02f_timeline.txt: the two gaps of a step sit
     # exactly around the bracketed kernel), so inside the timed region only the dominant kernel -- the one the roofline

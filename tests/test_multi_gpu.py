@@ -76,7 +76,7 @@ def test_two_rank_bench_rehearsal_on_one_device():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
            "--atoms", "2000", "--no-side", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
