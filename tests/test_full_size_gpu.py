@@ -243,3 +243,68 @@ def test_neighbor_pairs_one_million_atoms():
         d -= np.round(d / L) * L
         want = np.nonzero(np.sqrt((d * d).sum(1)) <= np.float32(cutoff))[0]
         assert np.array_equal(want, np.sort(cols_h[starts[row]:starts[row + 1]])), row
+
+
+def _torchani_reference(model, species, aev_ref):
+    """Energy and dE/dAEV of a TorchANI-shaped ensemble in float64 on the host: the per-species Sequential networks
+    applied to the given AEV rows, summed over atoms, averaged over the members (reference BatchedNN.py:100-111 is the
+    same function in another layout)."""
+    import copy
+    syms = list(workloads.ANI2X_WIDTHS)
+    aev = torch.tensor(aev_ref, dtype=torch.float64, requires_grad=True)
+    sp = torch.tensor(species, dtype=torch.long)
+    total = torch.zeros((), dtype=torch.float64)
+    members = list(model.neural_networks)
+    for member in members:
+        for s in sorted(set(species.tolist())):
+            net = copy.deepcopy(member[syms[s]]).double()
+            total = total + net(aev[sp == s]).sum()
+    energy = total / len(members)
+    energy.backward()
+    return float(energy.detach()), aev.grad.numpy().astype(np.float32)
+
+
+@pytest.mark.parametrize("layout", ["fused", "grouped", "reference"])
+def test_config2_optimized_torchani_against_the_oracle_at_full_size(layout):
+    """BASELINE config 2 in its own shape -- OptimizedTorchANI (species converter + HIP AEV + BatchedNN + shifter) on the
+    2 001-atom periodic water box with an 8-member ANI-2x-shaped ensemble -- against the oracle pipeline: the CPU oracle's
+    AEV (O(N^2), 0.4 s) pushed through the same networks in float64 on the host, forces by the oracle's backward of the
+    float64 dE/dAEV.  north_star's bars: energy 1e-5 relative, forces 1e-4 of the largest component, for every layout of
+    the networks (split-fp16 GEMMs / library GEMMs / the reference's per-atom weights through BatchedLinear)."""
+    from NNPOps import OptimizedTorchANI
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    from oracle import AniOracle
+    from test_torch_surface_gpu import _numbers
+    dev = torch.device("cuda:0")
+    model = workloads.torchani_like_model(n_models=8, seed=2, self_energies=[-0.5, -38.0, -54.7, -75.2, -398.1, -99.8, -460.1])
+    pos, species, box = workloads.water_box(667, seed=1)
+    assert len(species) == 2001
+    numbers = _numbers(species)
+    opt = OptimizedTorchANI(model, numbers.cpu())
+    if layout != "fused":
+        if layout == "reference":             # 21.6 GB of per-atom weights: assemble them on the device
+            torch.set_default_device(dev)
+        try:
+            opt.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=layout)
+        finally:
+            torch.set_default_device("cpu")
+    opt = opt.to(dev)
+    tpos = torch.tensor(pos, device=dev).unsqueeze(0).requires_grad_(True)
+    cell, pbc = torch.tensor(box, device=dev), torch.tensor([True, True, True], device=dev)
+    energy = opt((numbers, tpos), cell, pbc).energies
+    energy.sum().backward()
+    forces = tpos.grad[0].cpu().numpy()
+
+    rf, af = workloads.ani2x_functions()
+    oracle = AniOracle(7, 5.1, 3.5, species, rf, af, periodic=True)
+    r_ref, a_ref = oracle.forward(pos, box)
+    e_nn, g_aev = _torchani_reference(model, species, np.concatenate([r_ref, a_ref], axis=1))
+    sae = np.array([-0.5, -38.0, -54.7, -75.2, -398.1, -99.8, -460.1])
+    e_shift = float(sae[species].sum())
+    f_ref = oracle.backward(np.ascontiguousarray(g_aev[:, :112]), np.ascontiguousarray(g_aev[:, 112:]))
+    # the shifter adds a constant five orders of magnitude larger than the network part: gate the NETWORK energy
+    e_net = float(energy.double().item()) - e_shift
+    assert abs(e_net - e_nn) <= 1e-5 * abs(e_nn), (layout, e_net, e_nn)
+    assert abs(float(energy.double().item()) - (e_nn + e_shift)) <= 1e-5 * abs(e_nn + e_shift)
+    err = np.abs(forces - f_ref).max() / np.abs(f_ref).max()
+    assert err <= 1e-4, (layout, err)

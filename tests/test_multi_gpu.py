@@ -83,3 +83,91 @@ def test_two_rank_bench_rehearsal_on_one_device():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 12 and line["scaling"] == "weak" and line["value"] > 0
     assert "roofline" in line and line["config"]["atoms"] == 2000
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_config4_full_batch_against_the_oracle_and_shard_invariance():
+    """BASELINE config 4 in its own shape: the benchmark's 1 024 conformers (61 199 atoms) through ONE batched handle.
+    (i) 64 sampled molecules against the per-molecule oracle (AEV element-wise, energy 1e-5, forces 1e-4 of the largest
+    component); (ii) what the 8-GPU split relies on: blocks of shard_molecules(sizes, 8) evaluated by their OWN handle give
+    BITWISE the forces the same molecules get inside the full batch (no result depends on what else is in the batch)."""
+    from nnpops_amd import workloads
+    from nnpops_amd.capi import AniSymmetryFunctions
+    from nnpops_amd.parallel import shard_molecules
+    from oracle import AniOracle
+    bench = _bench_module()
+    sizes = bench.conformer_sizes()
+    assert len(sizes) == 1024
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    dev = torch.device("cuda:0")
+
+    def upstream(first, rows, width_r, width_a):
+        idx = torch.arange(first, first + rows, device=dev, dtype=torch.float32).unsqueeze(1)
+        g_r = torch.sin(idx * 0.37 + torch.arange(width_r, device=dev) * 0.11)
+        g_a = torch.cos(idx * 0.23 + torch.arange(width_a, device=dev) * 0.07)
+        return g_r.contiguous(), g_a.contiguous()
+
+    def evaluate(lo, hi):
+        sh = bench.ConformerShard(sizes, lo, hi, 0)
+        g_r, g_a = upstream(int(offsets[lo]), sh.n, sh.sym.radial_width, sh.sym.angular_width)
+        radial, angular = sh.sym.compute(sh.tpos, None)
+        grad = sh.sym.backprop(g_r, g_a)
+        torch.cuda.synchronize()
+        return sh, radial.clone(), angular.clone(), grad.clone(), g_r, g_a
+
+    full, radial, angular, grad, g_r, g_a = evaluate(0, 1024)
+    assert full.n == int(offsets[-1])
+    assert bool(torch.isfinite(grad).all())
+    r, a, g = radial.cpu().numpy(), angular.cpu().numpy(), grad.cpu().numpy()
+    wr, wa = g_r.cpu().numpy(), g_a.cpu().numpy()
+    rf, af = workloads.ani2x_functions()
+    for m in np.random.default_rng(0).choice(1024, 64, replace=False):
+        lo, hi = int(offsets[m]), int(offsets[m + 1])
+        pos, species = full.mols[m]
+        o = AniOracle(7, 5.1, 3.5, species, rf, af)
+        r_ref, a_ref = o.forward(pos)
+        np.testing.assert_allclose(r[lo:hi], r_ref, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(a[lo:hi], a_ref, rtol=2e-5, atol=2e-6)
+        e_ref = float(r_ref.astype(np.float64).sum() + a_ref.astype(np.float64).sum())
+        e = float(r[lo:hi].astype(np.float64).sum() + a[lo:hi].astype(np.float64).sum())
+        assert abs(e - e_ref) <= 1e-5 * abs(e_ref)
+        g_ref = o.backward(np.ascontiguousarray(wr[lo:hi]), np.ascontiguousarray(wa[lo:hi]))
+        assert np.abs(g[lo:hi] - g_ref).max() <= 1e-4 * np.abs(g_ref).max(), m
+    del full
+    blocks = shard_molecules(sizes, 8)
+    for rank in (0, 3, 7):
+        lo, hi = blocks[rank]
+        _, r_s, a_s, g_s, _, _ = evaluate(lo, hi)
+        first, last = int(offsets[lo]), int(offsets[hi])
+        assert torch.equal(g_s, grad[first:last]), rank
+        assert torch.equal(r_s, radial[first:last]) and torch.equal(a_s, angular[first:last]), rank
+
+
+def test_eight_rank_conformer_rehearsal_on_one_device():
+    """`bench.py --workload conformers` as the driver's 8-GPU run launches it -- eight ranks under torch.distributed.run, each
+    with its block of the 1 024 conformers and its own batched handle, the forces assembled by asynchronous padded
+    all_gathers with two buffer sets -- rehearsed with the eight ranks sharing ONE device over gloo ($NNPOPS_BENCH_BACKEND).
+    Checks inside the bench: every rank's own block comes back bitwise, every block finite.  The numbers mean nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NNPOPS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "conformers",
+           "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["conformers"] == 1024 and 7000 < line["config"]["atoms_this_rank"] < 8400

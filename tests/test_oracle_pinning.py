@@ -143,3 +143,29 @@ def test_neighbor_backward_oracle_matches_autograd():
     d = tp[torch.tensor(nb[0], dtype=torch.long)] - tp[torch.tensor(nb[1], dtype=torch.long)]
     ((d * torch.tensor(gd)).sum() + (d.norm(dim=1) * torch.tensor(gs)).sum()).backward()
     np.testing.assert_allclose(neighbor_pairs_backward_oracle(12, nb, dl, ds, gd, gs), tp.grad.numpy(), rtol=1e-10, atol=1e-12)
+
+
+# ---------------------------------------------------------------- the reference's own test molecules
+MOLECULES = ["1hvj", "1hvk", "2iuz", "3hkw", "3hky", "3lka", "3o99", "water"]
+
+
+def molecule_weights(shape, k):
+    """The upstream gradients of tests/golden/make_golden_molecules.py::weights (a formula, not stored)."""
+    i, j = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+    return (np.round(np.cos(0.37 * i + 1.3 * j + 0.5 + k) * 64) / 64).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", MOLECULES)
+def test_ani_oracle_on_the_reference_test_molecules(golden_dir, name):
+    """src/pytorch/TestSymmetryFunctions.py:37-105: the seven ligands and the 306-atom water box the reference tests
+    itself on; expected values = the reference CPU implementation compiled in place (make_golden_molecules.py).
+    The restatement is the same arithmetic in the same order: bit for bit."""
+    g = np.load(f"{golden_dir}/molecules_ref.npz")
+    k = MOLECULES.index(name)
+    cell = g[f"{name}_cell"] if f"{name}_cell" in g else None
+    rf, af = workloads.ani2x_functions()
+    o = AniOracle(7, 5.1, 3.5, g[f"{name}_species"], rf, af, periodic=cell is not None)
+    r, a = o.forward(g[f"{name}_positions"], cell)
+    assert np.array_equal(r, g[f"{name}_radial"]) and np.array_equal(a, g[f"{name}_angular"])
+    grad = o.backward(molecule_weights(r.shape, k), molecule_weights(a.shape, k + 100))
+    assert np.array_equal(grad, g[f"{name}_grad"])

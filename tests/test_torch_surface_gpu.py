@@ -280,7 +280,7 @@ def test_batched_nn_and_optimized_torchani():
     g_aev = aev.grad.float().numpy()
     f_ref = oracle.backward(np.ascontiguousarray(g_aev[:, :112]), np.ascontiguousarray(g_aev[:, 112:]))
     f = tpos.grad[0].cpu().numpy()
-    assert np.abs(f - f_ref).max() <= 2e-4 * np.abs(f_ref).max()
+    assert np.abs(f - f_ref).max() <= 1e-4 * np.abs(f_ref).max()          # north_star: 1e-4 on forces
     # buffers keep the reference's names
     names = {k for k, _ in opt.neural_networks.named_buffers()}
     assert {"0.layer0_weights", "0.layer6_biases"} <= names
