@@ -92,7 +92,11 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
 /* Blocks on the handle's stream and reports whether the last compute() overflowed a neighbour
  * buffer (NNPOPS_ERR_CAPACITY; the handle has then already grown its buffers, so simply call
  * compute() again).  max_radial_neighbors / max_angular_neighbors (host, may be NULL) receive the
- * largest per-atom counts seen.  Not graph-capturable. */
+ * largest per-atom counts seen.  Not graph-capturable.
+ * The first clean check() fits the row capacity to the system (longest row + 25 % + 8, NNPOPS_ERR_CAPACITY once: call
+ * compute() again).  A caller that then stops checking -- a captured graph replayed for many steps -- relies on that
+ * slack: a row that outgrows it is clamped (the builders raise a device-side flag that only check() reads), so call
+ * check() every few hundred replays, or after anything that can change the density. */
 int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors);
 /* Neighbour search used by compute(): 0 = automatic, 1 = all-pairs scan (the reference's
  * algorithm, O(N^2)), 2 = cell list (O(N); periodic boxes must be at least 3 cells wide per axis). */

@@ -855,11 +855,13 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
                     "call compute() again", st[kStatMaxRow], old_cap, st[kStatMaxAngular], old_ca, h->cap, h->cap_angular);
     }
     if (!h->cap_fitted) {
-        // First clean check: fit the row capacity to the system (12 % + 8 entries of slack, multiple of 16).  The builder's
+        // First clean check: fit the row capacity to the system (25 % + 8 entries of slack, multiple of 16: callers that
+        // stop checking afterwards -- graph replays, a check interval of 0 -- keep that much room for density fluctuations;
+        // include/nnpops_hip.h tells them to call check() from time to time).  The builder's
         // LDS per wave is proportional to it -- at the initial 128 a CU holds 27 builder waves, at 96 all 32 (-1 us per
         // launch at 10 000 atoms) -- and every row-indexed array shrinks with it.  Growth stays on demand, as before.
         h->cap_fitted = true;
-        const int fit = std::max(32, (st[kStatMaxRow] + st[kStatMaxRow] / 8 + 8 + 15) & ~15);
+        const int fit = std::max(32, (st[kStatMaxRow] + st[kStatMaxRow] / 4 + 8 + 15) & ~15);
         if (fit < h->cap && !std::getenv("NNPOPS_ANI_CAP")) {
             const int old_cap = h->cap;
             h->cap = fit;

@@ -94,11 +94,8 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
                 if (lane == 0 && slot_id == 0) atomicOr(&out.status[kStatOverflow], g.bin_overflow ? 6 : 2);   // 4: grow the cell bins
             } else if (in.use_cells) {
                 const int c = in.sorted_cell[slot_id];
-                const int nxy = g.nx * g.ny;
-                const int cz = (int)(((float)c + 0.5f) * fast_rcp((float)nxy));
-                const int rem = c - cz * nxy;
-                const int cy = (int)(((float)rem + 0.5f) * fast_rcp((float)g.nx));
-                const int cx = rem - cy * g.nx;
+                int cx, cy, cz;
+                split_cell(g, c, cx, cy, cz);
                 const WideStencil st = gather_wide_stencil(g, in.cell_start, cx, cy, cz);
                 int* strip = (int*)rscratch;                   // the radial scratch is idle during the scan
                 int carry = 0;

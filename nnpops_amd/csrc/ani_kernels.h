@@ -466,12 +466,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     const float4 me = sorted_pos[slot_id];
     const int c = sorted_cell[slot_id];                    // (written in sorted order by the grid build: no load that waits for the id)
     const int i = __float_as_int(me.w) & kIdMask;
-    // cell coordinates without integer division: (c + 1/2) / n rounds down correctly for every grid that fits (c < 2^20)
-    const int nxy = g.nx * g.ny;
-    const int cz = (int)(((float)c + 0.5f) * fast_rcp((float)nxy));
-    const int rem = c - cz * nxy;
-    const int cy = (int)(((float)rem + 0.5f) * fast_rcp((float)g.nx));
-    const int cx = rem - cy * g.nx;
+    int cx, cy, cz;
+    split_cell(g, c, cx, cy, cz);                          // (no integer division; exact: celllist.h)
     float4* row = nbr + (size_t)i * cap;
     int na = 0, nro = 0;
     const WideStencil st = gather_wide_stencil(g, cell_start, cx, cy, cz);

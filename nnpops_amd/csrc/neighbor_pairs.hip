@@ -200,12 +200,8 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
         return found;
     }
     const int c = atom_cell[row];
-    // cell coordinates without integer division: (c + 1/2) / n rounds down correctly for every grid that fits
-    const int nxy = g.nx * g.ny;
-    const int cz = (int)(((float)c + 0.5f) * __builtin_amdgcn_rcpf((float)nxy));
-    const int rem = c - cz * nxy;
-    const int cy = (int)(((float)rem + 0.5f) * __builtin_amdgcn_rcpf((float)g.nx));
-    const int cx = rem - cy * g.nx;
+    int cx, cy, cz;
+    split_cell(g, c, cx, cy, cz);                          // (no integer division; exact: celllist.h)
     // only partners with a smaller id: the prefix of every stencil cell (celllist.h), half the candidates of the full walk
     const WideStencil st = gather_prefix_stencil_wide(g, cell_start, sorted_atom, cx, cy, cz, row);
     __shared__ int strips[4][64];                                          // (256-thread blocks: one strip per wave)

@@ -652,13 +652,15 @@ TORCH_LIBRARY(neighbors, m) {
           "(Tensor neighbors, Tensor deltas, Tensor distances, Tensor num_pairs)");
 }
 
-TORCH_LIBRARY_IMPL(neighbors, AutogradCUDA, m) {
-    m.impl("getNeighborPairs", [](const Tensor& positions, const torch::Scalar& cutoff, const torch::Scalar& max_num_pairs,
-                                  const Tensor& box_vectors, bool checkErrors) {
-        const tensor_list r = NeighborPairsFunction::apply(positions, cutoff, max_num_pairs, box_vectors, checkErrors);
-        return std::make_tuple(r[0], r[1], r[2], r[3]);
-    });
+std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_pairs_device_entry(const Tensor& positions, const torch::Scalar& cutoff,
+                                                                       const torch::Scalar& max_num_pairs, const Tensor& box_vectors,
+                                                                       bool checkErrors) {
+    const tensor_list r = NeighborPairsFunction::apply(positions, cutoff, max_num_pairs, box_vectors, checkErrors);
+    return std::make_tuple(r[0], r[1], r[2], r[3]);
 }
+TORCH_LIBRARY_IMPL(neighbors, AutogradCUDA, m) { m.impl("getNeighborPairs", neighbor_pairs_device_entry); }
+// (the backend key itself: what runs below autograd -- torch.inference_mode(), AutoDispatchBelowAutograd)
+TORCH_LIBRARY_IMPL(neighbors, CUDA, m) { m.impl("getNeighborPairs", neighbor_pairs_device_entry); }
 
 // ---------------------------------------------------------------------------------------------
 // Host tensors.  The reference registers a CPU kernel of this op next to the device one (reference
@@ -822,13 +824,15 @@ public:
     }
 };
 
-TORCH_LIBRARY_IMPL(neighbors, AutogradCPU, m) {
-    m.impl("getNeighborPairs", [](const Tensor& positions, const torch::Scalar& cutoff, const torch::Scalar& max_num_pairs,
-                                  const Tensor& box_vectors, bool checkErrors) {
-        const tensor_list r = NeighborPairsHostFunction::apply(positions, cutoff, max_num_pairs, box_vectors, checkErrors);
-        return std::make_tuple(r[0], r[1], r[2], r[3]);
-    });
+std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_pairs_host_entry(const Tensor& positions, const torch::Scalar& cutoff,
+                                                                     const torch::Scalar& max_num_pairs, const Tensor& box_vectors,
+                                                                     bool checkErrors) {
+    const tensor_list r = NeighborPairsHostFunction::apply(positions, cutoff, max_num_pairs, box_vectors, checkErrors);
+    return std::make_tuple(r[0], r[1], r[2], r[3]);
 }
+TORCH_LIBRARY_IMPL(neighbors, AutogradCPU, m) { m.impl("getNeighborPairs", neighbor_pairs_host_entry); }
+// the reference registers under the CPU key (getNeighborPairsCPU.cpp:102-108): reachable below autograd too
+TORCH_LIBRARY_IMPL(neighbors, CPU, m) { m.impl("getNeighborPairs", neighbor_pairs_host_entry); }
 
 // =============================================================================================
 // PME, direct-space part (reference src/pytorch/pme/pme.cpp:4, pmeCUDA.cu:30-100,236-290, pmeCPU.cpp:75-175): same op
@@ -847,6 +851,13 @@ public:
         TORCH_CHECK(positions.scalar_type() == torch::kFloat32 && charges.scalar_type() == torch::kFloat32 &&
                     deltas.scalar_type() == torch::kFloat32 && distances.scalar_type() == torch::kFloat32, "pme_direct computes in float32");
         const int64_t n = positions.size(0), pairs = neighbors.size(1), max_excl = exclusions.size(1);
+        TORCH_CHECK(deltas.dim() == 2 && deltas.size(0) == pairs && deltas.size(1) == 3, "deltas must have shape (pairs, 3)");
+        TORCH_CHECK(distances.dim() == 1 && distances.size(0) == pairs, "distances must have shape (pairs)");
+        TORCH_CHECK(at::isIntegralType(neighbors.scalar_type(), false) && at::isIntegralType(exclusions.scalar_type(), false),
+                    "neighbors and exclusions must hold integer indices");
+        for (const Tensor* t : {&charges, &neighbors, &deltas, &distances, &exclusions})
+            TORCH_CHECK(t->device() == positions.device(), "pme_direct: every tensor must be on the device of positions (",
+                        positions.device(), "), got ", t->device());
         const Tensor pos = positions.contiguous(), q = charges.contiguous(), nb = neighbors.to(torch::kInt32).contiguous(),
                      dl = deltas.contiguous(), ds = distances.contiguous(), ex = exclusions.to(torch::kInt32).contiguous();
         const auto opts = positions.options();
@@ -872,6 +883,7 @@ public:
             double e = 0.0;
             for (int64_t i = 0; i < pairs; i++) {
                 const int a1 = N0[i], a2 = N1[i];
+                TORCH_CHECK(a1 < n && a2 < n && (a1 < 0 || a2 >= 0), "pme_direct: neighbor index out of range at pair ", i);
                 bool include = a1 > -1;
                 for (int64_t j = 0; include && j < max_excl && E[a1 * max_excl + j] >= a2; j++)
                     if (E[a1 * max_excl + j] == a2) include = false;
@@ -886,6 +898,7 @@ public:
             for (int64_t a1 = 0; a1 < n; a1++)
                 for (int64_t j = 0; j < max_excl && E[a1 * max_excl + j] > a1; j++) {
                     const int a2 = E[a1 * max_excl + j];
+                    TORCH_CHECK(a2 < n, "pme_direct: exclusion index out of range for atom ", a1);
                     float d[3];
                     for (int c = 0; c < 3; c++) d[c] = P[3 * a1 + c] - P[3 * a2 + c];
                     const float r = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), inv_r = 1 / r, ar = a * r, pre = k * inv_r, er = std::erf(ar);
@@ -902,6 +915,10 @@ public:
     }
 
     static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
+        // The derivatives were computed (and detached) in the forward pass: a backward pass that is itself being recorded
+        // (create_graph=True: force matching, Hessians) would silently see d(force)/d(positions, charges) = 0 from here.
+        TORCH_CHECK(!torch::GradMode::is_enabled(),
+                    "pme_direct: second derivatives are not implemented (backward was called with create_graph=True)");
         const auto saved = ctx->get_saved_variables();
         return {saved[0] * grad_outputs[0], saved[1] * grad_outputs[0], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
@@ -919,6 +936,10 @@ Tensor pme_direct_entry(const Tensor& positions, const Tensor& charges, const Te
 
 TORCH_LIBRARY_IMPL(pme, AutogradCUDA, m) { m.impl("pme_direct", pme_direct_entry); }
 TORCH_LIBRARY_IMPL(pme, AutogradCPU, m) { m.impl("pme_direct", pme_direct_entry); }
+// ... and the backend keys themselves (the reference registers its autograd Function under CPU, pmeCPU.cpp:381): below
+// autograd -- torch.inference_mode(), AutoDispatchBelowAutograd -- the same entry runs without recording a graph
+TORCH_LIBRARY_IMPL(pme, CUDA, m) { m.impl("pme_direct", pme_direct_entry); }
+TORCH_LIBRARY_IMPL(pme, CPU, m) { m.impl("pme_direct", pme_direct_entry); }
 
 // =============================================================================================
 // BatchedLinear (reference src/pytorch/BatchedNN.cpp:30-50): y = W v + b broadcast over

@@ -201,3 +201,20 @@ def test_minimum_image_ties_take_the_division(monkeypatch, dtype):
     tie = np.abs(want[1][:, 0]) == 5.0
     assert np.array_equal(got[1][~tie], want[1][~tie]) and np.array_equal(np.abs(got[1][tie]), np.abs(want[1][tie]))
     np.testing.assert_allclose(got[2], want[2], rtol=1e-6 if dtype == torch.float32 else 1e-14)
+
+
+def test_division_free_cell_split_is_exact_on_grids_of_millions_of_cells(tmp_path):
+    """celllist.h::split_cell (the cell index -> (cx, cy, cz) of every stencil walk, no integer division) against c / n over
+    whole grids of up to 16.7 M cells -- sizes the per-kernel tests cannot reach (round-2 advisor finding: the uncorrected
+    float floor fails above ~2.7 M cells and would silently walk the wrong stencil).  The checker is compiled here with
+    hipcc from the same header the library is built from."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "split_cell_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-I", os.path.join(root, "nnpops_amd", "csrc"),
+                           os.path.join(root, "tools", "ubench", "split_cell_check.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr

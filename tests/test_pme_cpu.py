@@ -54,3 +54,34 @@ def test_pme_argument_errors_match_the_reference():
         pme.compute_direct(torch.zeros(4, 3), torch.zeros(4), 0.4, torch.eye(3))
     with pytest.raises(RuntimeError, match="reciprocal-space"):
         pme.compute_reciprocal(torch.zeros(3, 3), torch.zeros(3), torch.eye(3))
+
+
+def test_ops_run_below_autograd_and_validate_their_arguments(golden_dir):
+    """Round-2 advisor findings: (i) getNeighborPairs / pme_direct under torch.inference_mode() (the reference registers
+    them under the CPU backend key, getNeighborPairsCPU.cpp:102, pmeCPU.cpp:381); (ii) a pair list whose arrays do not match
+    is refused instead of read out of bounds; (iii) a recorded backward pass (create_graph=True) is refused."""
+    from NNPOps.neighbors import getNeighborPairs
+    k, c = next(_cases(golden_dir))
+    pos, q, box = torch.tensor(c["positions"]), torch.tensor(c["charges"]), torch.tensor(c["box"])
+    excl = torch.tensor(_sorted_excl(c["exclusions"]).astype(np.int32)).reshape(len(c["positions"]), -1)
+    with torch.inference_mode():
+        nb, dl, ds, n = getNeighborPairs(pos, float(c["cutoff"]), -1, box)
+        e = torch.ops.pme.pme_direct(pos, q, nb, dl, ds, excl, float(c["alpha"]), float(c["coulomb"]))
+    assert abs(float(e) - float(c["energy"])) <= 1e-5 * max(abs(float(c["energy"])), 1.0)
+    nb, dl, ds, n = getNeighborPairs(pos, float(c["cutoff"]), -1, box)
+    with pytest.raises(RuntimeError, match="deltas must have shape"):
+        torch.ops.pme.pme_direct(pos, q, nb, dl[:-1], ds, excl, 0.5, 1.0)
+    with pytest.raises(RuntimeError, match="distances must have shape"):
+        torch.ops.pme.pme_direct(pos, q, nb, dl, ds[:-1], excl, 0.5, 1.0)
+    with pytest.raises(RuntimeError, match="integer indices"):
+        torch.ops.pme.pme_direct(pos, q, nb.float(), dl, ds, excl, 0.5, 1.0)
+    bad = nb.clone()
+    bad[1, 0] = len(pos) + 5
+    bad[0, 0] = 0
+    with pytest.raises(RuntimeError, match="out of range"):
+        torch.ops.pme.pme_direct(pos, q, bad, dl, ds, excl, 0.5, 1.0)
+    p2 = pos.clone().requires_grad_(True)
+    e = torch.ops.pme.pme_direct(p2, q, nb, dl, ds, excl, float(c["alpha"]), float(c["coulomb"]))
+    torch.autograd.grad(e, p2, retain_graph=True)
+    with pytest.raises(RuntimeError, match="second derivatives are not implemented"):
+        torch.autograd.grad(e, p2, create_graph=True)

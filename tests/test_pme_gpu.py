@@ -103,11 +103,16 @@ def test_double_derivative_raises():
     pos.requires_grad_(); charges.requires_grad_()
     pme = PME(14, 16, 15, 5, 5.0, 138.935, torch.zeros(9, 0, dtype=torch.int32))
     edir = pme.compute_direct(pos, charges, 0.5, box)
-    ddir = torch.autograd.grad(edir, pos, retain_graph=True, create_graph=True)
+    ddir = torch.autograd.grad(edir, pos, retain_graph=True)              # the reference's own sequence: first derivative ...
     with pytest.raises(Exception):
-        torch.autograd.grad(ddir[0].sum(), pos, retain_graph=True)
+        torch.autograd.grad(ddir[0].sum(), pos, retain_graph=True)      # ... is a leaf, nothing to differentiate
     with pytest.raises(Exception):
         torch.autograd.grad(ddir[0].sum(), charges, retain_graph=True)
+    # a RECORDED backward pass (force matching, Hessians) would silently treat the PME part of d(force)/dx as zero: refused
+    with pytest.raises(RuntimeError, match="second derivatives are not implemented"):
+        torch.autograd.grad(edir, pos, retain_graph=True, create_graph=True)
+    with pytest.raises(RuntimeError, match="second derivatives are not implemented"):
+        torch.autograd.grad(edir, charges, retain_graph=True, create_graph=True)
     with pytest.raises(RuntimeError, match="reciprocal"):
         pme.compute_reciprocal(pos, charges, box)
 
