@@ -238,6 +238,48 @@ int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float*
                       long strideBias, const float* Y, long ldy, long strideY, int prologue, const float* PY, long ldpy,
                       long stridePY, const float* pv, long stridePv, float alpha, float a_scale, const int* a_rows, const int* c_rows);
 
+/* ---- the atomic networks of a whole frame in two launches (replaces the four BatchedLinear + CELU calls and the
+ * sum of BatchedNN.py:100-111 inside OptimizedTorchANI.py:49-52, and their autograd backward to the AEV) ----
+ * Per atom and ensemble member: Linear(F,H1) CELU Linear(H1,H2) CELU Linear(H2,H3) CELU Linear(H3,1).  The atoms are
+ * grouped by species ("kind"): rows[] lists, kind after kind, the row of x (and of dx) that holds each atom's AEV.
+ * A workgroup carries 64 atoms of one kind and one member through all four layers with the activations in LDS /
+ * registers; with_gradient the same launch runs the backward pass of layers 6, 4 and 2 and leaves dE/dy1 (split fp16
+ * planes, workspace d1); nnpops_mlp_input_grad then forms dE/dx = W0^T dE/dy1 and writes the rows of dx.
+ * Arithmetic: fp32 in and out; every operand of a product is carried as two fp16 planes (22 significant bits after a
+ * fixed 1/16 scale, exact products, fp32 accumulation) -- keep |activation| below 1e6.
+ * Weights arrive packed (nnpops_mlp_pack): W [rows][cols] fp32 -> fragment planes of nnpops_mlp_packed_halves(rows, cols)
+ * fp16 values; rows = outputs, cols = inputs of the product the planes are the left operand of.  For a torch Linear
+ * weight W_l [out][in] of member m, with widths padded to multiples of 32 (zero rows / columns):
+ *   w0  = pack(h1, F,  W_0, permute 0)                     w2 = pack(h2, h1, W_2, permute 1)    w4 = pack(h3, h2, W_4, 1)
+ *   w4t = pack(h2, h3, W_4, transpose 1, permute 1)        w2t = pack(h1, h2, W_2, transpose 1, permute 1)
+ * members one after the other in each buffer; w0t = pack(F, M*h1, [W_0 of all members stacked: M*h1 x F], transpose 1,
+ * permute 1), one buffer for all members.  permute 1 selects the K order in which a matrix-core accumulator hands its
+ * rows to the next product (mlp_fused.hip).  Biases b0 [M][h1], b2 [M][h2], b4 [M][h3], last layer w6 [M][h3], b6 [M]. */
+#define NNPOPS_MLP_MAX_KINDS 8
+typedef struct {
+    int num_atoms;                       /* atoms of this kind: the next num_atoms entries of rows[] */
+    int h1, h2, h3;                      /* packed layer widths: multiples of 32 in 32..256 */
+    const void *w0, *w2, *w4;            /* forward planes (device) */
+    const void *w4t, *w2t, *w0t;         /* gradient planes (device; may be NULL when with_gradient == 0) */
+    const float *b0, *b2, *b4, *w6, *b6; /* device */
+    void* d1;                            /* device workspace, nnpops_mlp_d1_halves(num_atoms, M, h1) fp16 values (gradient only) */
+} nnpops_mlp_kind;
+typedef struct {
+    int num_kinds, num_features, num_members;
+    const float* x; int ldx;             /* device [atoms][ldx], ldx >= num_features, rows 16-byte aligned; num_features % 8 == 0 */
+    const int32_t* rows;                 /* device [sum of num_atoms] */
+    float* energies;                     /* device [sum of num_atoms][num_members]: output of every (grouped atom, member) network */
+    float alpha;                         /* CELU alpha (0.1 in TorchANI) */
+    float* dx; int lddx;                 /* nnpops_mlp_input_grad: device [atoms][lddx]; rows listed in rows[] are overwritten */
+    const float* upstream;               /* optional device scalar: dx is multiplied by it (dE_total/dE of this sum); NULL = 1 */
+    nnpops_mlp_kind kinds[NNPOPS_MLP_MAX_KINDS];
+} nnpops_mlp_frame;
+int64_t nnpops_mlp_packed_halves(int rows, int cols);
+int64_t nnpops_mlp_d1_halves(int num_atoms, int num_members, int h1);
+int nnpops_mlp_pack(void* stream, int rows, int cols, const float* w, long ldw, int transpose, int permute, void* out);
+int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gradient);
+int nnpops_mlp_input_grad(void* stream, const nnpops_mlp_frame* frame);
+
 #ifdef __cplusplus
 }
 #endif

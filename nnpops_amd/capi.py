@@ -61,6 +61,11 @@ SIGNATURES = {
                                     C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long,
                                     C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long,
                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "nnpops_mlp_packed_halves": (C.c_int64, [C.c_int, C.c_int]),
+    "nnpops_mlp_d1_halves": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "nnpops_mlp_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "nnpops_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "nnpops_mlp_input_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_workspace_bytes": (C.c_int64, [C.c_int]),
     "nnpops_neighbor_pairs_forward": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -455,3 +460,102 @@ def gemm_split(a, planes, bias=None, celu_of=None, alpha=0.1, a_scale=1.0, out=N
                                    0, None, 0, 0, None, 0, float(alpha), float(a_scale),
                                    _ptr(a_rows) if a_rows is not None else None, _ptr(c_rows) if c_rows is not None else None))
     return out
+
+
+# ---- the atomic networks of a frame in two launches (mlp_fused.hip) ----
+MLP_MAX_KINDS = 8
+
+
+class _MlpKind(C.Structure):
+    _fields_ = [("num_atoms", C.c_int), ("h1", C.c_int), ("h2", C.c_int), ("h3", C.c_int),
+                ("w0", C.c_void_p), ("w2", C.c_void_p), ("w4", C.c_void_p), ("w4t", C.c_void_p), ("w2t", C.c_void_p), ("w0t", C.c_void_p),
+                ("b0", C.c_void_p), ("b2", C.c_void_p), ("b4", C.c_void_p), ("w6", C.c_void_p), ("b6", C.c_void_p), ("d1", C.c_void_p)]
+
+
+class _MlpFrame(C.Structure):
+    _fields_ = [("num_kinds", C.c_int), ("num_features", C.c_int), ("num_members", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int),
+                ("rows", C.c_void_p), ("energies", C.c_void_p), ("alpha", C.c_float), ("dx", C.c_void_p), ("lddx", C.c_int),
+                ("upstream", C.c_void_p), ("kinds", _MlpKind * MLP_MAX_KINDS)]
+
+
+def mlp_pack(w, rows, cols, transpose=False, permute=False):
+    """fp32 device matrix -> the fragment planes nnpops_mlp_forward / _input_grad take as the LEFT operand of a product with
+    `rows` outputs and `cols` inputs (`w` is [rows][cols], or [cols][rows] with transpose)."""
+    w = _dev_f32(w, "w")
+    out = torch.empty((lib().nnpops_mlp_packed_halves(rows, cols),), dtype=torch.float16, device=w.device)
+    _check(lib().nnpops_mlp_pack(_stream_ptr(w.device), rows, cols, _ptr(w), w.shape[1], int(transpose), int(permute), _ptr(out)))
+    return out
+
+
+def _up32(v):
+    return (v + 31) // 32 * 32
+
+
+class FusedMLP:
+    """The atomic networks of one frame (reference BatchedNN.py:37-122) on nnpops_mlp_forward / nnpops_mlp_input_grad.
+    ``kinds``: one dict per species present, in the order the atoms are grouped: w0 [M,H1,F], b0 [M,H1], w2 [M,H2,H1], b2,
+    w4 [M,H3,H2], b4, w6 [M,H3], b6 [M] (float32 device tensors, torch Linear layout) and ``atoms`` (int32 device tensor:
+    the rows of x that hold the atoms of the kind).  Widths are zero padded to multiples of 32 here."""
+
+    def __init__(self, kinds, num_features, alpha=0.1):
+        if not 1 <= len(kinds) <= MLP_MAX_KINDS:
+            raise ValueError(f"1..{MLP_MAX_KINDS} kinds")
+        self.F, self.alpha = int(num_features), float(alpha)
+        self.M = int(kinds[0]["w0"].shape[0])
+        self._keep = []
+        self.frame = _MlpFrame()
+        self.frame.num_kinds, self.frame.num_features, self.frame.num_members, self.frame.alpha = len(kinds), self.F, self.M, self.alpha
+        dev = kinds[0]["w0"].device
+        self.device = dev
+        rows = []
+        for k, kd in enumerate(kinds):
+            M, H1, F = kd["w0"].shape
+            H2, H3 = kd["w2"].shape[1], kd["w4"].shape[1]
+            assert F == self.F and M == self.M
+            h1, h2, h3 = _up32(H1), _up32(H2), _up32(H3)
+
+            def pad(t, *shape):
+                out = torch.zeros(shape, dtype=torch.float32, device=dev)
+                out[tuple(slice(0, n) for n in t.shape)] = t
+                return out.contiguous()
+            w0, w2, w4 = pad(kd["w0"], M, h1, F), pad(kd["w2"], M, h2, h1), pad(kd["w4"], M, h3, h2)
+            b0, b2, b4, w6 = pad(kd["b0"], M, h1), pad(kd["b2"], M, h2), pad(kd["b4"], M, h3), pad(kd["w6"], M, h3)
+            b6 = kd["b6"].to(torch.float32).contiguous()
+            planes = {
+                "w0": torch.cat([mlp_pack(w0[m], h1, F) for m in range(M)]),
+                "w2": torch.cat([mlp_pack(w2[m], h2, h1, permute=True) for m in range(M)]),
+                "w4": torch.cat([mlp_pack(w4[m], h3, h2, permute=True) for m in range(M)]),
+                "w4t": torch.cat([mlp_pack(w4[m], h2, h3, transpose=True, permute=True) for m in range(M)]),
+                "w2t": torch.cat([mlp_pack(w2[m], h1, h2, transpose=True, permute=True) for m in range(M)]),
+                "w0t": mlp_pack(w0.reshape(M * h1, F), F, M * h1, transpose=True, permute=True),
+            }
+            n = int(kd["atoms"].numel())
+            d1 = torch.empty((max(int(lib().nnpops_mlp_d1_halves(n, M, h1)), 1),), dtype=torch.float16, device=dev)
+            self._keep += [planes, b0, b2, b4, w6, b6, d1]
+            fk = self.frame.kinds[k]
+            fk.num_atoms, fk.h1, fk.h2, fk.h3 = n, h1, h2, h3
+            for name, t in planes.items():
+                setattr(fk, name, t.data_ptr())
+            fk.b0, fk.b2, fk.b4, fk.w6, fk.b6, fk.d1 = b0.data_ptr(), b2.data_ptr(), b4.data_ptr(), w6.data_ptr(), b6.data_ptr(), d1.data_ptr()
+            rows.append(kd["atoms"].to(torch.int32))
+        self.rows = torch.cat(rows).contiguous()
+        self.frame.rows = self.rows.data_ptr()
+        self.energies = torch.empty((self.rows.numel(), self.M), dtype=torch.float32, device=dev)
+        self.frame.energies = self.energies.data_ptr()
+
+    def forward(self, x, with_gradient=True):
+        """x [atoms][>= F] float32 -> energies [grouped atoms][M] (every member's network output per atom)."""
+        x = _dev_f32(x, "x")
+        self.frame.x, self.frame.ldx = x.data_ptr(), x.shape[1]
+        _check(lib().nnpops_mlp_forward(_stream_ptr(x.device), C.byref(self.frame), int(with_gradient)))
+        return self.energies
+
+    def input_grad(self, like, upstream=None, out=None):
+        """dE/dx of the summed energies of the last forward(with_gradient=True): [atoms][F] float32 (rows of atoms that
+        belong to no kind are left as they are)."""
+        if out is None:
+            out = torch.zeros((like.shape[0], self.F), dtype=torch.float32, device=like.device)
+        self.frame.dx, self.frame.lddx = out.data_ptr(), out.shape[1]
+        self.frame.upstream = upstream.data_ptr() if upstream is not None else None
+        _check(lib().nnpops_mlp_input_grad(_stream_ptr(out.device), C.byref(self.frame)))
+        return out
