@@ -550,10 +550,8 @@ def run_torchani(args, R):
     model = workloads.torchani_like_model(n_models=8, seed=2)
     pos, species, box = workloads.water_box(667, seed=1)
     numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=dev)
-    opt = OptimizedTorchANI(model, numbers.cpu())
-    if args.nn_layout != "fused":
-        opt.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=args.nn_layout)
-    opt = opt.to(dev)
+    opt = OptimizedTorchANI(model, numbers.cpu(), nn_layout=args.nn_layout, fused_step=not args.no_fused_step).to(dev)
+    one_node = type(opt).__name__ == "FusedOptimizedTorchANI"
     # (pbc stays on the host: the wrapper reads it with .tolist(), reference SymmetryFunctions.py:113, which on a
     # device tensor is a synchronising copy and cannot be captured)
     cell, pbc = torch.tensor(box, device=dev), torch.tensor([True, True, True])
@@ -610,33 +608,69 @@ def run_torchani(args, R):
     flops_fwd = 2.0 * 8 * sum(macs[int(s)] for s in species)
     nn_weight_bytes = sum(b.numel() * 4 for name, b in opt.neural_networks.named_buffers() if "layer" in name)
     tflops = 2 * flops_fwd / elapsed * steps / 1e12
-    fused = args.nn_layout == "fused"
+    split = args.nn_layout in ("fused", "gemm")
+    kernel_name = {"fused": "mlp_forward + mlp_input_grad (mlp_fused.hip: a 64-atom tile of one species and one member through all "
+                            "four layers in one workgroup, activations in LDS / registers)",
+                   "gemm": "gemm_h2 (batched_nn.hip: one split-fp16 GEMM per layer and species, fused activations)",
+                   "grouped": "BatchedNN GEMMs (hipBLASLt via torch.matmul)", "reference": "BatchedLinear on per-atom replicated weights"}[args.nn_layout]
     out = {
         "metric": "OptimizedTorchANI energy+forces evaluations/sec, 2001-atom periodic water box, 8 models, fp32",
         "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
         "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" + (" (network GEMMs: operands split into two fp16 planes, products exact, fp32 accumulation)" if fused else ""),
+        "dtype": "f32" + (" (network products: operands split into two fp16 planes, products exact, fp32 accumulation)" if split else ""),
         "data": "synthetic",
         "config": {"workload": f"OptimizedTorchANI, {n}-atom periodic water box (667 H2O), ANI-2x AEV + 8 x ANI-2x-shaped networks, "
-                               f"random weights, BatchedNN layout = {args.nn_layout}" + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
-                   "nn_weight_bytes": nn_weight_bytes},
-        "roofline": {"bound": "mfma", "kernel": ("gemm_h2 (batched_nn.hip: split-fp16 GEMMs with fused activations)" if fused
-                                                else "BatchedNN GEMMs (hipBLASLt via torch.matmul)") + ", forward + input-gradient backward",
+                               f"random weights, BatchedNN layout = {args.nn_layout}, "
+                               + ("AEV + networks as one autograd node (8 launches per energy+forces step)" if one_node else "four-module composition")
+                               + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
+                   "nn_weight_bytes": nn_weight_bytes, "nn_layout": args.nn_layout, "one_autograd_node": one_node},
+        "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",
                      "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,
                      "issued": ({"instruction": "v_mfma_f32_16x16x32_f16, 3 products per fp32 product", "tflops": round(3 * tflops, 2),
-                                 "peak": F16_DENSE_PEAK, "frac": round(3 * tflops / F16_DENSE_PEAK, 5)} if fused else None),
-                     "note": "whole step time (AEV + NN + autograd overhead) against the NN's algorithmic flops; `frac` is against the "
-                             "fp32 matrix peak the reference's arithmetic would be priced at, `issued` against the dense fp16 peak of "
-                             "the instruction actually issued"},
+                                 "peak": F16_DENSE_PEAK, "frac": round(3 * tflops / F16_DENSE_PEAK, 5)} if split else None),
+                     "note": "whole step time (neighbour search + AEV + networks, forward and backward) against the NETWORKS' algorithmic "
+                             "flops; `frac` is against the fp32 matrix peak the reference's arithmetic would be priced at, `issued` against "
+                             "the dense fp16 peak of the instruction actually issued"},
     }
     if not args.no_cpu_baseline:
+        # the reference CPU AEV op (single thread) + BatchedLinear on the CPU.  The AEV leg is the
+        # reference's own core compiled in place; the network leg is the reference's per-atom layout (BatchedNN.py:55-111:
+        # matmul on [1, atoms, members, out, in] weights -- 10.8 MB per atom and member set) on a SAMPLE of atoms, scaled
+        # by the atom count (the layout is per atom: the cost is linear in atoms by construction).
         kind, cls = _cpu_classes()
         rf, af = workloads.ani2x_functions()
         dt = _ani_eval_seconds(cls, pos, species, box, rf, af)
-        out["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "evals/s (AEV fwd+bwd only)", "cores": 1, "kind": kind,
-                               "sample": f"one AEV fwd+bwd of the same {n}-atom water box ({dt:.2f} s); the reference's CPU BatchedNN "
-                                         "(ATen matmuls on 21.7 GB of per-atom replicated weights) is not timed"}
+        sample = 150                                           # 50 waters: 1.6 GB of replicated weights on the host
+        sp_s = species[:sample]
+        numbers_s = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in sp_s]])
+        nn_cpu = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers_s, layout="reference")
+        aev_s = torch.rand((1, sample, 1008)).requires_grad_(True)
+        sp_t = torch.tensor(sp_s).unsqueeze(0)
+        threads = torch.get_num_threads()
+
+        def nn_step():
+            aev_s.grad = None
+            nn_cpu((sp_t, aev_s)).energies.sum().backward()
+        nn_step()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            nn_step()
+        dt_nn = (time.perf_counter() - t1) / 3 * n / sample
+        torch.set_num_threads(1)
+        nn_step()
+        t1 = time.perf_counter()
+        nn_step()
+        dt_nn1 = (time.perf_counter() - t1) * n / sample
+        torch.set_num_threads(threads)
+        out["cpu_baseline"] = {"value": round(1.0 / (dt + dt_nn1), 4), "unit": "evals/s (AEV + networks, fwd+bwd)", "cores": 1, "kind": kind,
+                               "aev_seconds": round(dt, 3), "networks_seconds_1_thread": round(dt_nn1, 3),
+                               "networks_seconds_all_threads": round(dt_nn, 3), "networks_threads": threads,
+                               "sample": f"AEV: one fwd+bwd of the same {n}-atom water box by the reference's CPU core ({dt:.2f} s, serial). "
+                                         f"Networks: the reference's per-atom BatchedLinear layout (matmul over [1, atoms, 8, out, in] weights, "
+                                         f"fwd + input-gradient bwd) on the first {sample} atoms with ATen on the host, scaled by {n}/{sample}: "
+                                         f"{dt_nn1:.2f} s with 1 thread, {dt_nn:.2f} s with {threads} threads (ATen's own threading; the op is this "
+                                         "repository's restatement of BatchedNN.cpp:30-47 -- the same two ATen calls)"}
     return out
 
 
@@ -926,8 +960,10 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the short runs of the other BASELINE configurations")
     ap.add_argument("--strict-side", action="store_true", help="exit with status 3 when a side workload failed (the line is still printed)")
     ap.add_argument("--graph", action="store_true", help="torchani / cfconv workloads: replay the step as one captured HIP graph")
-    ap.add_argument("--nn-layout", default="fused", choices=["fused", "grouped", "reference"],
-                    help="torchani workload: species-grouped GEMMs (default) or the reference's per-atom replicated weights")
+    ap.add_argument("--nn-layout", default="fused", choices=["fused", "gemm", "grouped", "reference"],
+                    help="torchani workload: the fused network kernels (default), per-layer split-fp16 GEMMs, library GEMMs, or the "
+                         "reference's per-atom replicated weights")
+    ap.add_argument("--no-fused-step", action="store_true", help="torchani workload: the four-module composition instead of one autograd node")
     ap.add_argument("--neighbor-algorithm", type=int, default=0)
     ap.add_argument("--workload", default="aev", choices=sorted(WORKLOADS),
                     help="aev: the headline metric (default, with the others attached under 'side'); the rest run one BASELINE "

@@ -272,6 +272,7 @@ typedef struct {
     float alpha;                         /* CELU alpha (0.1 in TorchANI) */
     float* dx; int lddx;                 /* nnpops_mlp_input_grad: device [atoms][lddx]; rows listed in rows[] are overwritten */
     const float* upstream;               /* optional device scalar: dx is multiplied by it (dE_total/dE of this sum); NULL = 1 */
+    float dx_scale;                      /* host scalar, also multiplied into dx (e.g. 1 / num_members for an ensemble mean); 0 is read as 1 */
     nnpops_mlp_kind kinds[NNPOPS_MLP_MAX_KINDS];
 } nnpops_mlp_frame;
 int64_t nnpops_mlp_packed_halves(int rows, int cols);

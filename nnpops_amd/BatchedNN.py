@@ -5,7 +5,7 @@ common shape, four BatchedLinear calls with CELU(0.1) in between, and one fused 
 Buffer names (``layer{0,2,4,6}_{weights,biases}``) and the ModuleList-of-one structure are kept so
 that state dicts and TorchScript files stay interchangeable.
 """
-from typing import List, NamedTuple, Tuple
+from typing import List, NamedTuple, Optional, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -153,9 +153,124 @@ def _planes(w: Tensor) -> Tuple[Tensor, Tensor]:
     return hi, lo
 
 
+def _pack_fragments(w: Tensor, permute: bool) -> Tensor:
+    """fp32 [rows, cols] -> the fragment planes of csrc/mlp_fused.hip (what ``nnpops_mlp_pack`` writes; the GPU test compares
+    the two): [row block][K step][plane][lane = r16 + 16 kg][8] fp16, ``w = hi + 2^-11 lo``; K order inside a step natural, or
+    -- ``permute`` -- (4 kg + i | 16 + 4 kg + i - 4), the order in which a matrix-core accumulator hands over its rows."""
+    rows, cols = w.shape
+    nb, steps = (rows + 15) // 16, (cols + 31) // 32
+    padded = torch.zeros((nb * 16, steps * 32), dtype=torch.float32, device=w.device)
+    padded[:rows, :cols] = w
+    kg = torch.arange(4, device=w.device).view(4, 1)
+    i = torch.arange(8, device=w.device).view(1, 8)
+    within = torch.where(i < 4, 4 * kg + i, 16 + 4 * kg + i - 4) if permute else 8 * kg + i          # [kg, i] -> k inside the step
+    g = padded.view(nb, 16, steps, 32)[:, :, :, within.reshape(-1)]                                  # [rb, r16, s, (kg, i)]
+    g = g.view(nb, 16, steps, 4, 8).permute(0, 2, 3, 1, 4)                                           # [rb, s, kg, r16, i]
+    hi = g.half()
+    lo = ((g - hi.float()) * 2048.0).half()
+    return torch.stack([hi, lo], dim=2).reshape(-1)                                                  # [rb, s, plane, kg, r16, i]
+
+
+def _up32(v: int) -> int:
+    return (v + 31) // 32 * 32
+
+
 class _FusedSpeciesNN(_SpeciesGroupedNN):
-    """The species-grouped networks on the library's own GEMM (``torch.ops.NNPOpsBatchedNN.GroupedMLP``,
-    csrc/batched_nn.hip): fp32 in and out, products as split-fp16 matrix instructions with fp32 accumulation, bias + CELU
+    """The species-grouped networks as TWO launches (``torch.ops.NNPOpsBatchedNN.FusedMLP``, csrc/mlp_fused.hip): a workgroup
+    carries 64 atoms of one species and one ensemble member through all four layers -- and back through the small layers of
+    the gradient -- with the activations in LDS / registers; a second launch forms dE/dAEV.  fp32 in and out, products as
+    split-fp16 matrix instructions with fp32 accumulation.  Same buffers (and state dicts) as :class:`_SpeciesGroupedNN`; the
+    packed operand planes are derived from them (non-persistent buffers, rebuilt when a state dict is loaded), each species at
+    its OWN widths (the zero padding to the widest species that the reference's layout carries is stripped).  Frames with
+    several molecules, CPU tensors, double precision and networks outside the kernels' shape (widths above 256, an input
+    width that is not a multiple of 8, more than 8 species present) take the parent's path.
+
+    Inside :class:`OptimizedTorchANI` the same kernels run behind ``torch.ops.NNPOpsANISymmetryFunctions.energy`` -- AEV and
+    networks, forward and backward, as one autograd node (``fused_energy``)."""
+
+    widths: List[int]
+
+    def __init__(self, converter, ensemble, atomicNumbers: Tensor):
+        super().__init__(converter, ensemble, atomicNumbers)
+        self.num_models = int(self.layer0_weights.shape[1])
+        self.widths = []
+        self.fused_ok = True
+        self.register_buffer('atom_order32', self.atom_order.to(torch.int32), persistent=False)
+        for name in ('mlp_planes', 'mlp_floats'):
+            self.register_buffer(name, torch.empty(0), persistent=False)
+        self._refresh_planes()
+
+    @staticmethod
+    def _true_width(w: Tensor, b: Tensor) -> int:
+        """Rows of a (zero padded) layer that are not identically zero, rounded up to 32: w [models, out, in], b [models, out, 1]."""
+        used = (w.abs().amax(dim=(0, 2)) > 0) | (b.abs().amax(dim=(0, 2)) > 0)
+        last = int(torch.nonzero(used).max()) + 1 if bool(used.any()) else 1
+        return _up32(last)
+
+    @torch.jit.unused
+    def _refresh_planes(self) -> None:
+        w0, w2, w4, w6 = self.layer0_weights.float(), self.layer2_weights.float(), self.layer4_weights.float(), self.layer6_weights.float()
+        b0, b2, b4, b6 = self.layer0_biases.float(), self.layer2_biases.float(), self.layer4_biases.float(), self.layer6_biases.float()
+        kinds, M, F = w0.shape[0], w0.shape[1], w0.shape[3]
+        planes, floats, widths = [], [], []
+        for k in range(kinds):
+            h1, h2, h3 = self._true_width(w0[k], b0[k]), self._true_width(w2[k], b2[k]), self._true_width(w4[k], b4[k])
+            h1, h2, h3 = min(h1, _up32(w0.shape[2])), min(h2, _up32(w2.shape[2])), min(h3, _up32(w4.shape[2]))
+            widths += [h1, h2, h3]
+
+            def cut(t: Tensor, rows: int, cols: int) -> Tensor:          # [M, out, in] -> [M, rows, cols], zero padded / trimmed
+                out = torch.zeros((M, rows, cols), dtype=torch.float32, device=t.device)
+                r, c = min(rows, t.shape[1]), min(cols, t.shape[2])
+                out[:, :r, :c] = t[:, :r, :c]
+                return out
+            k0, k2, k4 = cut(w0[k], h1, F), cut(w2[k], h2, h1), cut(w4[k], h3, h2)
+            planes += [_pack_fragments(k0[m], False) for m in range(M)]
+            planes += [_pack_fragments(k2[m], True) for m in range(M)]
+            planes += [_pack_fragments(k4[m], True) for m in range(M)]
+            planes += [_pack_fragments(k4[m].t(), True) for m in range(M)]
+            planes += [_pack_fragments(k2[m].t(), True) for m in range(M)]
+            planes.append(_pack_fragments(k0.reshape(M * h1, F).t(), True))
+            floats += [cut(b0[k], h1, 1).reshape(-1), cut(b2[k], h2, 1).reshape(-1), cut(b4[k], h3, 1).reshape(-1),
+                       cut(w6[k][:, 0:1, :].transpose(1, 2), h3, 1).reshape(-1), b6[k].reshape(M, -1)[:, 0].reshape(-1)]
+        self.mlp_planes = torch.cat(planes).contiguous()
+        self.mlp_floats = torch.cat(floats).contiguous()
+        self.widths = widths
+        # the kernels scale every activation by 1/16 before the fp16 split: activations must stay below ~1e6.  A crude
+        # bound from the weights (AEV entries are sums of at most a few dozen terms <= 1) decides; networks that could
+        # exceed it keep the library-GEMM path.  The backward operands take the same planes: |d3| <= |w6|,
+        # |d2| <= |d3| ||W4||_1, |d1| <= |d2| ||W2||_1 (CELU' <= 1).
+        bound = torch.full((1,), 64.0, device=w0.device)
+        for w, b in ((w0, b0), (w2, b2), (w4, b4)):
+            bound = (w.abs().sum(-1).amax() * bound + b.abs().amax()).reshape(1)
+        back = w6.abs().amax().reshape(1)
+        for w in (w4, w2):
+            back = (w.abs().sum(-2).amax() * back).reshape(1)
+        self.fused_ok = (bool(torch.isfinite(bound).all()) and float(bound) < 1.0e6 and bool(torch.isfinite(back).all()) and float(back) < 1.0e6
+                         and F % 8 == 0 and max(widths) <= 256 and kinds <= 8 and int(w6.shape[2]) == 1)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        self._refresh_planes()
+
+    def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
+        species, aev = species_aev
+        if (aev.shape[0] != 1 or not aev.is_cuda or aev.dtype != torch.float32 or self.mlp_planes.dtype != torch.float16
+                or self.atom_order32.dtype != torch.int32 or not self.fused_ok):
+            return self._grouped_forward(species_aev)
+        total = torch.ops.NNPOpsBatchedNN.FusedMLP(aev[0].contiguous(), self.atom_order32, self.group_sizes, self.widths, self.num_models,
+                                                   self.mlp_planes, self.mlp_floats)
+        return SpeciesEnergies(species, total / self.num_models)
+
+    def fused_energy(self, positions: Tensor, cell: Optional[Tensor]) -> Tensor:
+        """AEV + networks of the whole frame as one autograd node (only inside OptimizedTorchANI, which hands over the AEV
+        holder): positions [N, 3] -> ensemble-mean energy [1]."""
+        return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
+                                                           self.num_models, self.mlp_planes, self.mlp_floats)
+
+
+class _SplitGemmSpeciesNN(_SpeciesGroupedNN):
+    """(Round-1/2 default, kept as ``layout='gemm'`` for comparison and for widths the fused kernels do not take.)  The
+    species-grouped networks on the library's own GEMM (``torch.ops.NNPOpsBatchedNN.GroupedMLP``, csrc/batched_nn.hip): fp32 in and out, products as split-fp16 matrix instructions with fp32 accumulation, bias + CELU
     fused into the epilogues and CELU' into the input-gradient pass -- six launches per species and step instead of
     GEMM + elementwise kernels for every layer.  Same buffers (and state dicts) as :class:`_SpeciesGroupedNN`; the packed
     operand planes are derived from them (non-persistent buffers, rebuilt when a state dict is loaded).  Frames with
@@ -229,15 +344,19 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
 
 
 class TorchANIBatchedNN(nn.ModuleList):
-    """``layout='fused'`` (default): species-grouped layers on the library's split-fp16 GEMM with fused activations;
-    ``'grouped'``: the same grouping on torch's library GEMMs; ``'reference'``: the reference's per-atom replicated
-    weights through ``BatchedLinear`` (interchange with reference state dicts / archives)."""
+    """``layout='fused'`` (default): species-grouped networks as two launches of the fused kernels (csrc/mlp_fused.hip);
+    ``'gemm'``: one split-fp16 GEMM per layer and species with fused activations (csrc/batched_nn.hip); ``'grouped'``: the same
+    grouping on torch's library GEMMs; ``'reference'``: the reference's per-atom replicated weights through ``BatchedLinear``
+    (interchange with reference state dicts / archives)."""
 
     def __init__(self, converter, ensemble, atomicNumbers: Tensor, layout: str = 'fused'):
-        if layout not in ('fused', 'grouped', 'reference'):
-            raise ValueError("layout must be 'fused', 'grouped' or 'reference'")
-        impl = {'fused': _FusedSpeciesNN, 'grouped': _SpeciesGroupedNN, 'reference': _BatchedNN}[layout]
+        if layout not in ('fused', 'gemm', 'grouped', 'reference'):
+            raise ValueError("layout must be 'fused', 'gemm', 'grouped' or 'reference'")
+        impl = {'fused': _FusedSpeciesNN, 'gemm': _SplitGemmSpeciesNN, 'grouped': _SpeciesGroupedNN, 'reference': _BatchedNN}[layout]
         super().__init__([impl(converter, ensemble, atomicNumbers)])
 
     def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
         return self[0].forward(species_aev)
+
+    def fused_energy(self, positions: Tensor, cell: Optional[Tensor]) -> Tensor:
+        return self[0].fused_energy(positions, cell)

@@ -5,20 +5,28 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
-from .BatchedNN import TorchANIBatchedNN
+from .BatchedNN import TorchANIBatchedNN, _FusedSpeciesNN
 from .EnergyShifter import SpeciesEnergies, TorchANIEnergyShifter
 from .SpeciesConverter import TorchANISpeciesConverter
 from .SymmetryFunctions import TorchANISymmetryFunctions
 
 
 class OptimizedTorchANI(torch.nn.Module):
+    """The reference's four-module composition.  ``nn_layout`` (additive) picks the layout of the networks
+    (:class:`TorchANIBatchedNN`); with the default ``'fused'`` and networks the fused kernels take, the instance becomes a
+    :class:`FusedOptimizedTorchANI`: same modules, same state dict, same results, but AEV and networks run as ONE autograd
+    node (``fused_step=False`` keeps the plain composition)."""
 
-    def __init__(self, model, atomicNumbers: Tensor) -> None:
+    def __init__(self, model, atomicNumbers: Tensor, nn_layout: str = 'fused', fused_step: bool = True) -> None:
         super().__init__()
         self.species_converter = TorchANISpeciesConverter(model.species_converter, atomicNumbers)
         self.aev_computer = TorchANISymmetryFunctions(model.species_converter, model.aev_computer, atomicNumbers)
-        self.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, atomicNumbers)
+        self.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, atomicNumbers, layout=nn_layout)
         self.energy_shifter = TorchANIEnergyShifter(model.species_converter, model.energy_shifter, atomicNumbers)
+        nets = self.neural_networks[0]
+        if fused_step and isinstance(nets, _FusedSpeciesNN) and nets.fused_ok:
+            nets.holder = self.aev_computer.holder        # the networks' fused_energy() drives the AEV kernels itself
+            self.__class__ = FusedOptimizedTorchANI
 
     def forward(self, species_coordinates: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
                 pbc: Optional[Tensor] = None) -> SpeciesEnergies:
@@ -26,3 +34,19 @@ class OptimizedTorchANI(torch.nn.Module):
         species_aevs = self.aev_computer(species_coordinates, cell, pbc)
         species_energies = self.neural_networks(species_aevs)
         return self.energy_shifter(species_energies)
+
+
+class FusedOptimizedTorchANI(OptimizedTorchANI):
+    """OptimizedTorchANI whose forward is ``torch.ops.NNPOpsANISymmetryFunctions.energy``: neighbour search + AEV + the four
+    layers of every atomic network (+, when the positions require a gradient, the networks' input gradient and the AEV
+    backward) issued back to back from one C++ call -- 8 kernel launches, one autograd node whose backward is a single
+    multiplication -- instead of the ~45 launches the composition records.  Not constructed directly: ``OptimizedTorchANI(...)``
+    turns into it.  Second derivatives are refused (use ``fused_step=False``)."""
+
+    def forward(self, species_coordinates: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
+                pbc: Optional[Tensor] = None) -> SpeciesEnergies:
+        converted = self.species_converter(species_coordinates)
+        species, positions = converted.species, converted.coordinates
+        self.aev_computer.check_arguments(species, cell, pbc)
+        energies = self.neural_networks.fused_energy(positions[0], cell)
+        return self.energy_shifter((species, energies))

@@ -73,10 +73,8 @@ class TorchANISymmetryFunctions(torch.nn.Module):
         features = torch.ops.NNPOpsANISymmetryFunctions.aev(holder, flat, None)
         return species, features.reshape(batch, len(self._species), -1)
 
-    def forward(self, species_positions: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
-                pbc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-        """(species, positions[1, N, 3]) -> (species, aev[1, N, S*nR + S(S+1)/2*nA])"""
-        species, positions = species_positions
+    def check_arguments(self, species: Tensor, cell: Optional[Tensor], pbc: Optional[Tensor]) -> None:
+        """The reference's argument errors (SymmetryFunctions.py:110-118)."""
         if species.shape[0] != 1:
             raise ValueError('Batched computation of molecules is not supported')
         if cell is not None:
@@ -86,6 +84,12 @@ class TorchANISymmetryFunctions(torch.nn.Module):
                 pbc_: List[bool] = pbc.tolist()
                 if pbc_ != [True, True, True]:
                     raise ValueError('Only fully periodic systems are supported, i.e. pbc = [True, True, True]')
+
+    def forward(self, species_positions: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
+                pbc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """(species, positions[1, N, 3]) -> (species, aev[1, N, S*nR + S(S+1)/2*nA])"""
+        species, positions = species_positions
+        self.check_arguments(species, cell, pbc)
         # the reference concatenates the two outputs of `operation` (SymmetryFunctions.py:120-122); `aev` has the kernels
         # write both parts into one [N, 1008] array in place (same values, no 4 KB/atom copy forward and backward)
         features = torch.ops.NNPOpsANISymmetryFunctions.aev(self.holder, positions[0], cell).unsqueeze(0)

@@ -475,7 +475,7 @@ class _MlpKind(C.Structure):
 class _MlpFrame(C.Structure):
     _fields_ = [("num_kinds", C.c_int), ("num_features", C.c_int), ("num_members", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int),
                 ("rows", C.c_void_p), ("energies", C.c_void_p), ("alpha", C.c_float), ("dx", C.c_void_p), ("lddx", C.c_int),
-                ("upstream", C.c_void_p), ("kinds", _MlpKind * MLP_MAX_KINDS)]
+                ("upstream", C.c_void_p), ("dx_scale", C.c_float), ("kinds", _MlpKind * MLP_MAX_KINDS)]
 
 
 def mlp_pack(w, rows, cols, transpose=False, permute=False):
@@ -550,12 +550,13 @@ class FusedMLP:
         _check(lib().nnpops_mlp_forward(_stream_ptr(x.device), C.byref(self.frame), int(with_gradient)))
         return self.energies
 
-    def input_grad(self, like, upstream=None, out=None):
+    def input_grad(self, like, upstream=None, out=None, scale=1.0):
         """dE/dx of the summed energies of the last forward(with_gradient=True): [atoms][F] float32 (rows of atoms that
         belong to no kind are left as they are)."""
         if out is None:
             out = torch.zeros((like.shape[0], self.F), dtype=torch.float32, device=like.device)
         self.frame.dx, self.frame.lddx = out.data_ptr(), out.shape[1]
         self.frame.upstream = upstream.data_ptr() if upstream is not None else None
+        self.frame.dx_scale = float(scale)
         _check(lib().nnpops_mlp_input_grad(_stream_ptr(out.device), C.byref(self.frame)))
         return out

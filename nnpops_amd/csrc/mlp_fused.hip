@@ -69,6 +69,7 @@ struct MlpArgs {
     float alpha;
     float* dx; int lddx;                    // input_grad only
     const float* upstream;                  // optional device scalar multiplying dx
+    float dx_scale;                         // host scalar multiplying dx
     KindDesc kinds[NNPOPS_MLP_MAX_KINDS];
 };
 
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void mlp_input_grad(const MlpArgs g) {
             __syncthreads();
         }
     }
-    const float up = g.upstream ? *g.upstream : 1.0f;
+    const float up = (g.upstream ? *g.upstream : 1.0f) * g.dx_scale;
     const int kgD = lane >> 4, a16 = lane & 15;
 #pragma unroll
     for (int cb = 0; cb < kCB; cb++) {
@@ -479,7 +480,7 @@ int check_and_fill(const nnpops_mlp_frame* fr, MlpArgs& g, bool grad, int blocks
     NNPOPS_REQUIRE(fr->alpha > 0, "alpha must be positive");
     g.num_kinds = fr->num_kinds; g.F = fr->num_features; g.M = fr->num_members; g.ldx = fr->ldx;
     g.x = fr->x; g.rows = fr->rows; g.energies = fr->energies; g.alpha = fr->alpha;
-    g.dx = fr->dx; g.lddx = fr->lddx; g.upstream = fr->upstream;
+    g.dx = fr->dx; g.lddx = fr->lddx; g.upstream = fr->upstream; g.dx_scale = fr->dx_scale == 0.f ? 1.0f : fr->dx_scale;
     int blocks = 0, first = 0;
     for (int k = 0; k < fr->num_kinds; k++) {
         const nnpops_mlp_kind& s = fr->kinds[k];

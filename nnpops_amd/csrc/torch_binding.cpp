@@ -60,6 +60,68 @@ bool stream_is_capturing(void* stream) {
     return status != hipStreamCaptureStatusNone;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The atomic networks of a frame on nnpops_mlp_forward / nnpops_mlp_input_grad (mlp_fused.hip).  The packed parameters
+// travel as two flat buffers (what nnpops_amd/BatchedNN.py::_FusedSpeciesNN registers): per kind, one after the other,
+//   planes (fp16): w0 (M members) | w2 (M) | w4 (M) | w4t (M) | w2t (M) | w0t          floats: b0 | b2 | b4 | w6 | b6
+// with the packed widths h1, h2, h3 of every kind in `widths` (multiples of 32).
+// ---------------------------------------------------------------------------------------------
+struct MlpCall {
+    nnpops_mlp_frame frame{};
+    Tensor energies;                  // [atoms][members]
+    std::vector<Tensor> keep;         // workspaces
+};
+
+int64_t mlp_halves(int64_t rows, int64_t cols) { return nnpops_mlp_packed_halves((int)rows, (int)cols); }
+
+MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64_t>& kind_atoms, const std::vector<int64_t>& widths,
+                    int64_t members, const Tensor& planes, const Tensor& floats, bool with_gradient) {
+    TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.scalar_type() == torch::kFloat32 && x.is_contiguous(),
+                "the fused networks take a contiguous [atoms, features] float32 device tensor");
+    const int64_t kinds = (int64_t)kind_atoms.size(), F = x.size(1), atoms = x.size(0);
+    TORCH_CHECK(kinds >= 1 && kinds <= NNPOPS_MLP_MAX_KINDS && (int64_t)widths.size() == 3 * kinds, "1..", NNPOPS_MLP_MAX_KINDS, " kinds, three widths each");
+    TORCH_CHECK(rows.scalar_type() == torch::kInt32 && rows.is_contiguous() && rows.device() == x.device() && rows.numel() == atoms,
+                "rows must be an int32 permutation of the atoms on the device of x");
+    TORCH_CHECK(planes.scalar_type() == torch::kFloat16 && planes.is_contiguous() && planes.device() == x.device() &&
+                floats.scalar_type() == torch::kFloat32 && floats.is_contiguous() && floats.device() == x.device(),
+                "packed network parameters must be contiguous fp16 / fp32 buffers on the device of x");
+    MlpCall c;
+    nnpops_mlp_frame& fr = c.frame;
+    fr.num_kinds = (int)kinds; fr.num_features = (int)F; fr.num_members = (int)members;
+    fr.x = x.data_ptr<float>(); fr.ldx = (int)F; fr.rows = rows.data_ptr<int32_t>(); fr.alpha = 0.1f;       // BatchedNN.py:103
+    c.energies = torch::empty({atoms, members}, x.options());
+    fr.energies = c.energies.data_ptr<float>();
+    const at::Half* ph = planes.data_ptr<at::Half>();
+    const float* pf = floats.data_ptr<float>();
+    int64_t oh = 0, of = 0, total = 0;
+    for (int64_t k = 0; k < kinds; k++) {
+        const int64_t h1 = widths[3 * k], h2 = widths[3 * k + 1], h3 = widths[3 * k + 2], M = members;
+        nnpops_mlp_kind& kd = fr.kinds[k];
+        kd.num_atoms = (int)kind_atoms[k]; kd.h1 = (int)h1; kd.h2 = (int)h2; kd.h3 = (int)h3;
+        total += kind_atoms[k];
+        kd.w0 = ph + oh;  oh += M * mlp_halves(h1, F);
+        kd.w2 = ph + oh;  oh += M * mlp_halves(h2, h1);
+        kd.w4 = ph + oh;  oh += M * mlp_halves(h3, h2);
+        kd.w4t = ph + oh; oh += M * mlp_halves(h2, h3);
+        kd.w2t = ph + oh; oh += M * mlp_halves(h1, h2);
+        kd.w0t = ph + oh; oh += mlp_halves(F, M * h1);
+        kd.b0 = pf + of; of += M * h1;
+        kd.b2 = pf + of; of += M * h2;
+        kd.b4 = pf + of; of += M * h3;
+        kd.w6 = pf + of; of += M * h3;
+        kd.b6 = pf + of; of += M;
+        if (with_gradient) {
+            Tensor d1 = torch::empty({std::max<int64_t>(nnpops_mlp_d1_halves((int)kind_atoms[k], (int)M, (int)h1), 1)}, planes.options());
+            kd.d1 = d1.data_ptr();
+            c.keep.push_back(d1);
+        }
+    }
+    TORCH_CHECK(total == atoms, "the kinds hold ", total, " atoms, x has ", atoms);
+    TORCH_CHECK(oh == planes.numel() && of == floats.numel(), "packed network parameters do not match the widths (", oh, " / ", planes.numel(),
+                " fp16 values, ", of, " / ", floats.numel(), " floats)");
+    return c;
+}
+
 void require_device_tensor(const Tensor& t, const char* name) {
     if (!t.is_cuda())
         throw std::runtime_error(std::string("Unsupported device for \"") + name + "\": " + t.device().str() +
@@ -313,6 +375,49 @@ Tensor aev(const c10::optional<HolderPtr>& holder, const Tensor& positions, cons
     return FusedAutogradFunction::apply(*holder, positions, periodicBoxVectors);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Additive: the whole OptimizedTorchANI step (reference OptimizedTorchANI.py:49-52: aev_computer -> neural_networks) as ONE
+// autograd node.  forward: AEV kernels -> the fused networks (mlp_fused.hip) -> ensemble-mean energy; when the positions
+// require a gradient the same call runs the networks' input-gradient pass and the AEV backward and keeps dE/dpositions, so
+// that backward() is one multiplication -- no autograd graph over the ~20 small tensor ops the four-module composition
+// records, no [N, 1008] gradient held by autograd between the passes.  (The reference's PME op keeps its derivatives
+// the same way, pmeCPU.cpp:161-171.)
+// ---------------------------------------------------------------------------------------------
+class EnergyFunction : public torch::autograd::Function<EnergyFunction> {
+public:
+    static Tensor forward(AutogradContext* ctx, const HolderPtr& holder, const Tensor& positions, const c10::optional<Tensor>& cell,
+                          const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
+                          const Tensor& planes, const Tensor& floats, bool need_gradient) {
+        const Tensor aev = holder->forwardImpl(positions, cell, true)[0];
+        c10::hip::HIPGuard guard(aev.device().index());
+        void* stream = current_stream(aev.device());
+        MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient);
+        if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+        Tensor energy = call.energies.sum().reshape({1}) / (double)members;        // BatchedNN.py:109
+        if (need_gradient) {
+            Tensor daev = torch::empty_like(aev);
+            call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = 1.0f / (float)members;
+            if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+            ctx->save_for_backward({holder->backwardFused(daev)[1]});
+        }
+        return energy;
+    }
+    static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
+        TORCH_CHECK(!torch::GradMode::is_enabled(),
+                    "NNPOpsANISymmetryFunctions::energy: second derivatives are not implemented (backward was called with create_graph=True); "
+                    "use the four-module composition for that");
+        const auto saved = ctx->get_saved_variables();
+        TORCH_CHECK(!saved.empty(), "energy() was evaluated without a gradient request");
+        return {Tensor(), saved[0] * grads[0], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor energy(const c10::optional<HolderPtr>& holder, const Tensor& positions, const c10::optional<Tensor>& cell, const Tensor& rows,
+              std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members, const Tensor& planes, const Tensor& floats) {
+    const bool need = torch::GradMode::is_enabled() && positions.requires_grad();
+    return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, need);
+}
+
 TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
     m.class_<Holder>("Holder")
         .def(torch::init<int64_t, double, double, const std::vector<double>&, const std::vector<double>&,
@@ -326,6 +431,8 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
                     [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
     m.def("operation", operation);
     m.def("aev", aev);
+    m.def("energy(__torch__.torch.classes.NNPOpsANISymmetryFunctions.Holder? holder, Tensor positions, Tensor? cell, Tensor rows, int[] kind_atoms, "
+          "int[] widths, int members, Tensor planes, Tensor floats) -> Tensor", energy);
 }
 
 }  // namespace ANISymmetryFunctions
@@ -1092,8 +1199,46 @@ Tensor GroupedMLP(const Tensor& x, const Tensor& order, std::vector<int64_t> gro
     return GroupedMLPFunction::apply(x, order, group_sizes, num_models, h1, h2, h3, fwd_hi, fwd_lo, bwd_hi, bwd_lo, biases, last_w, last_b);
 }
 
+// =============================================================================================
+// FusedMLP: the atomic networks of one frame on mlp_fused.hip -- sum over atoms AND members of the networks' outputs
+// (BatchedNN.py:100-111 up to the division by the number of members).  When x requires a gradient the input-gradient pass
+// runs inside forward and backward is one multiplication (see EnergyFunction above).
+// =============================================================================================
+class FusedMLPFunction : public torch::autograd::Function<FusedMLPFunction> {
+public:
+    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths,
+                          int64_t members, const Tensor& planes, const Tensor& floats, bool need_gradient) {
+        c10::hip::HIPGuard guard(x.device().index());
+        void* stream = current_stream(x.device());
+        MlpCall call = mlp_prepare(x, rows, kind_atoms, widths, members, planes, floats, need_gradient);
+        if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsBatchedNN::FusedMLP");
+        Tensor total = call.energies.sum().reshape({1});
+        if (need_gradient) {
+            Tensor dx = torch::empty_like(x);
+            call.frame.dx = dx.data_ptr<float>(); call.frame.lddx = (int)dx.size(1); call.frame.dx_scale = 1.0f;
+            if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsBatchedNN::FusedMLP");
+            ctx->save_for_backward({dx});
+        }
+        return total;
+    }
+    static tensor_list backward(AutogradContext* ctx, const tensor_list& grads) {
+        TORCH_CHECK(!torch::GradMode::is_enabled(), "NNPOpsBatchedNN::FusedMLP: second derivatives are not implemented (create_graph=True); "
+                                                    "use layout='grouped' for that");
+        const auto saved = ctx->get_saved_variables();
+        TORCH_CHECK(!saved.empty(), "FusedMLP was evaluated without a gradient request");
+        return {saved[0] * grads[0], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor FusedMLP(const Tensor& x, const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
+                const Tensor& planes, const Tensor& floats) {
+    const bool need = torch::GradMode::is_enabled() && x.requires_grad();
+    return FusedMLPFunction::apply(x, rows, kind_atoms, widths, members, planes, floats, need);
+}
+
 TORCH_LIBRARY(NNPOpsBatchedNN, m) {
     m.def("BatchedLinear", BatchedLinear);
+    m.def("FusedMLP(Tensor x, Tensor rows, int[] kind_atoms, int[] widths, int members, Tensor planes, Tensor floats) -> Tensor", FusedMLP);
     m.def("GroupedMLP(Tensor x, Tensor order, int[] group_sizes, int num_models, int h1, int h2, int h3, Tensor fwd_hi, Tensor fwd_lo, "
           "Tensor bwd_hi, Tensor bwd_lo, Tensor biases, Tensor last_w, float[] last_b) -> Tensor", GroupedMLP);
 }

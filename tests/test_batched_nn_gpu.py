@@ -54,16 +54,18 @@ def test_large_inputs_are_scaled_into_range():
     assert (out.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
 
 
-def test_fused_networks_match_the_library_gemm_path():
-    """TorchANIBatchedNN's default layout (GroupedMLP: split-fp16 GEMMs with fused activations) against the same
-    grouping on torch's fp32 library GEMMs: energies and AEV gradients, every ANI-2x species present, 8 members."""
+@pytest.mark.parametrize("layout", ["fused", "gemm"])
+def test_fused_networks_match_the_library_gemm_path(layout):
+    """TorchANIBatchedNN's default layout (the fused kernels of mlp_fused.hip) and the per-layer split-fp16 GEMMs ('gemm')
+    against the same grouping on torch's fp32 library GEMMs: energies and AEV gradients, every ANI-2x species present,
+    8 members."""
     from nnpops_amd import workloads
     from NNPOps.BatchedNN import TorchANIBatchedNN
     model = workloads.torchani_like_model(n_models=8, seed=11)
     pos, species, _ = workloads.water_box(200, seed=3)
     species = np.concatenate([species, [1, 2, 4, 6, 5, 1, 2, 2]]).astype(np.int32)
     numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
-    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu()).to(DEV)
+    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=layout).to(DEV)
     grouped = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").to(DEV)
     sp = torch.tensor(species, device=DEV).unsqueeze(0)
     aev = torch.randn(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4)).abs()
@@ -85,7 +87,8 @@ def test_fused_networks_match_the_library_gemm_path():
     torch.testing.assert_close(scripted((sp, aev)).energies, e1.detach(), rtol=1e-6, atol=1e-6)
 
 
-def test_fused_networks_edge_cases():
+@pytest.mark.parametrize("layout", ["fused", "gemm"])
+def test_fused_networks_edge_cases(layout):
     """A species with a single atom, species that do not occur at all, inference without gradients, and the paths the
     fused op hands back to the library GEMMs (two molecules in a frame, float64)."""
     from nnpops_amd import workloads
@@ -93,7 +96,7 @@ def test_fused_networks_edge_cases():
     model = workloads.torchani_like_model(n_models=2, seed=21)
     species = np.array([0] * 37 + [3] * 5 + [6], dtype=np.int32)            # H, O and one Cl: four kinds never occur
     numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
-    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu()).to(DEV)
+    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=layout).to(DEV)
     grouped = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").to(DEV)
     sp = torch.tensor(species, device=DEV).unsqueeze(0)
     aev = torch.randn(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).abs()
@@ -113,7 +116,8 @@ def test_fused_networks_edge_cases():
     assert e64.dtype == torch.float64 and abs(float(e64) - float(e2)) <= 1e-5 * abs(float(e2)) + 1e-4
 
 
-def test_networks_with_huge_weights_keep_the_library_gemms():
+@pytest.mark.parametrize("layout", ["fused", "gemm"])
+def test_networks_with_huge_weights_keep_the_library_gemms(layout):
     """The fused path carries activations through fp16 planes (after a 1/16 scale): networks whose weights allow
     activations beyond ~1e6 are detected when the operand planes are built and evaluated by the library GEMMs instead."""
     from nnpops_amd import workloads
@@ -123,7 +127,7 @@ def test_networks_with_huge_weights_keep_the_library_gemms():
         net[2].weight.data *= 300.0
     species = np.array([0, 0, 3, 1], dtype=np.int32)
     numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
-    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu()).to(DEV)
+    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=layout).to(DEV)
     grouped = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").to(DEV)
     assert not fused[0].fused_ok
     sp = torch.tensor(species, device=DEV).unsqueeze(0)
@@ -154,7 +158,7 @@ def _golden_case(golden_dir, k):
     return c, model
 
 
-@pytest.mark.parametrize("layout", ["fused", "grouped", "reference"])
+@pytest.mark.parametrize("layout", ["fused", "gemm", "grouped", "reference"])
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_reference_batched_linear_goldens(golden_dir, k, layout):
     """Energies and dE/dAEV produced by the REFERENCE's BatchedLinear CPU op (src/pytorch/BatchedNN.cpp:30-42) in the
@@ -189,3 +193,16 @@ def test_batched_linear_op_matches_reference_first_layer(golden_dir):
     y = torch.ops.NNPOpsBatchedNN.BatchedLinear(v, nn[0].layer0_weights, nn[0].layer0_biases)
     ref = torch.tensor(c["first_layer_atom0"], device=DEV)
     torch.testing.assert_close(y[0, 0, :, :, 0], ref, rtol=2e-5, atol=2e-5)
+
+
+def test_python_packer_equals_the_c_abi_packer():
+    """nnpops_amd/BatchedNN.py::_pack_fragments (torch ops; what a module runs at construction, on any device) writes the
+    planes nnpops_mlp_pack (the C ABI's device kernel) writes, bit for bit."""
+    from nnpops_amd.BatchedNN import _pack_fragments
+    from nnpops_amd.capi import mlp_pack
+    gen = torch.Generator().manual_seed(7)
+    for rows, cols in ((192, 1008), (160, 256), (40, 72), (1008, 512)):
+        w = torch.randn((rows, cols), generator=gen) / np.sqrt(cols)
+        for permute in (False, True):
+            assert torch.equal(_pack_fragments(w, permute), mlp_pack(w.to(DEV), rows, cols, permute=permute).cpu())
+            assert torch.equal(_pack_fragments(w.t(), permute), mlp_pack(w.to(DEV), cols, rows, transpose=True, permute=permute).cpu())

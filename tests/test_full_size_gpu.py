@@ -264,7 +264,7 @@ def _torchani_reference(model, species, aev_ref):
     return float(energy.detach()), aev.grad.numpy().astype(np.float32)
 
 
-@pytest.mark.parametrize("layout", ["fused", "grouped", "reference"])
+@pytest.mark.parametrize("layout", ["fused", "fused-composition", "gemm", "grouped", "reference"])
 def test_config2_optimized_torchani_against_the_oracle_at_full_size(layout):
     """BASELINE config 2 in its own shape -- OptimizedTorchANI (species converter + HIP AEV + BatchedNN + shifter) on the
     2 001-atom periodic water box with an 8-member ANI-2x-shaped ensemble -- against the oracle pipeline: the CPU oracle's
@@ -280,14 +280,15 @@ def test_config2_optimized_torchani_against_the_oracle_at_full_size(layout):
     pos, species, box = workloads.water_box(667, seed=1)
     assert len(species) == 2001
     numbers = _numbers(species)
-    opt = OptimizedTorchANI(model, numbers.cpu())
-    if layout != "fused":
-        if layout == "reference":             # 21.6 GB of per-atom weights: assemble them on the device
-            torch.set_default_device(dev)
-        try:
-            opt.neural_networks = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=layout)
-        finally:
-            torch.set_default_device("cpu")
+    if layout == "reference":                 # 21.6 GB of per-atom weights: assemble them on the device
+        torch.set_default_device(dev)
+    try:
+        opt = OptimizedTorchANI(model, numbers.cpu(), nn_layout=layout.split("-")[0], fused_step=layout != "fused-composition")
+    finally:
+        torch.set_default_device("cpu")
+    # 'fused': AEV + networks as ONE autograd node (torch.ops.NNPOpsANISymmetryFunctions.energy); the others: the reference's
+    # four-module composition with the networks in the named layout
+    assert (type(opt).__name__ == "FusedOptimizedTorchANI") == (layout == "fused")
     opt = opt.to(dev)
     tpos = torch.tensor(pos, device=dev).unsqueeze(0).requires_grad_(True)
     cell, pbc = torch.tensor(box, device=dev), torch.tensor([True, True, True], device=dev)

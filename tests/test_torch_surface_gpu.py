@@ -472,3 +472,63 @@ def test_forward_batch_evaluates_conformers_in_one_holder():
         torch.testing.assert_close(tpos.grad[b:b + 1], one.grad, rtol=1e-5, atol=1e-6 * float(one.grad.abs().max()))
     with pytest.raises(ValueError, match="Batched computation of molecules is not supported"):
         module((sp.expand(5, -1), tpos))
+
+
+def test_fused_optimized_torchani_is_one_autograd_node_and_equals_the_composition():
+    """OptimizedTorchANI with the default network layout becomes a FusedOptimizedTorchANI: AEV + networks behind
+    torch.ops.NNPOpsANISymmetryFunctions.energy.  Same energy and forces as the four-module composition
+    (fused_step=False) on the same kernels; energy-only calls run no backward kernels; a recorded backward pass is refused;
+    state dicts are interchangeable; the scripted module saves, loads and agrees."""
+    from NNPOps import OptimizedTorchANI
+    model = workloads.torchani_like_model(n_models=3, seed=12, self_energies=[-0.5, -38.0, -54.7, -75.2, -398.1, -99.8, -460.1])
+    pos, species, box = workloads.water_box(150, seed=21)
+    species = species.copy()
+    species[[5, 17, 40]] = [1, 2, 4]                                      # a C, an N and an S among the waters: four kinds, one tiny
+    numbers = _numbers(species)
+    fused = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+    plain = OptimizedTorchANI(model, numbers.cpu(), fused_step=False).to(DEV)
+    assert type(fused).__name__ == "FusedOptimizedTorchANI" and type(plain).__name__ == "OptimizedTorchANI"
+    assert isinstance(fused, OptimizedTorchANI)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True], device=DEV)
+
+    def run(module, scale=1.0):
+        p = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+        e = module((numbers, p), cell, pbc).energies
+        (scale * e.sum()).backward()
+        return e.detach(), p.grad.detach()
+
+    e1, f1 = run(fused, 2.5)                                               # (a non-trivial upstream gradient)
+    e2, f2 = run(plain, 2.5)
+    assert e1.dtype == e2.dtype == torch.float64 and e1.shape == (1,)
+    torch.testing.assert_close(e1, e2, rtol=1e-7, atol=2e-4)
+    torch.testing.assert_close(f1, f2, rtol=1e-4, atol=2e-5 * float(f2.abs().max()))
+    # the graph of the fused module is ONE custom node between the positions and the shifter's addition
+    p = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+    e = fused((numbers, p), cell, pbc).energies
+    names, fn = [], e.grad_fn
+    while fn is not None:
+        names.append(fn.name())
+        fn = fn.next_functions[0][0] if fn.next_functions else None
+    # shifter add <- energy node <- positions[0] <- leaf: nothing else was recorded
+    assert len(names) == 4 and sum("EnergyFunction" in n for n in names) == 1, names
+    with pytest.raises(RuntimeError, match="second derivatives are not implemented"):
+        torch.autograd.grad(e.sum(), p, create_graph=True)
+    with torch.no_grad():                                                 # energy only
+        torch.testing.assert_close(fused((numbers, p), cell, pbc).energies, e1, rtol=1e-7, atol=1e-6)
+    # the reference's argument errors survive the fusion
+    with pytest.raises(ValueError, match="Batched computation"):
+        fused((numbers.expand(2, -1), p.expand(2, -1, -1)), cell, pbc)
+    with pytest.raises(ValueError, match='"pbc" has to be defined'):
+        fused((numbers, p), cell, None)
+    # state dicts interchange, scripting round-trips
+    other = OptimizedTorchANI(workloads.torchani_like_model(n_models=3, seed=99), numbers.cpu()).to(DEV)
+    other.load_state_dict(plain.state_dict())
+    torch.testing.assert_close(run(other, 2.5)[1], f1, rtol=1e-6, atol=1e-7 * float(f1.abs().max()))
+    scripted = torch.jit.script(fused)
+    buffer = io.BytesIO()
+    torch.jit.save(scripted, buffer)
+    buffer.seek(0)
+    loaded = torch.jit.load(buffer, map_location=DEV)
+    e3, f3 = run(loaded, 2.5)
+    torch.testing.assert_close(e3, e1, rtol=1e-7, atol=1e-6)
+    torch.testing.assert_close(f3, f1, rtol=1e-6, atol=1e-7 * float(f1.abs().max()))
