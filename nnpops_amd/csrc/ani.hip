@@ -95,6 +95,9 @@ struct nnpops_ani {
     // optional per-kernel HIP-event timing (nnpops_ani_enable_timing)
     int ld_radial = 0, ld_angular = 0;   // row strides (floats) of the AEV / gradient arrays of the call in progress
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
+    int* d_work_order = nullptr;    // [N] atoms by DECREASING number of angular neighbours (check() builds it): the schedule of the
+    bool work_order_valid = false;  //     angular kernels when there is no cell order -- heaviest atoms first, the light ones fill the tail
+    bool lpt = true;                // $NNPOPS_ANI_LPT=0 switches that schedule off (A/B)
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     int timing_every = 1;           // ... on every timing_every-th launch
     unsigned timing_seen[NNPOPS_ANI_NUM_KERNELS] = {};
@@ -206,6 +209,7 @@ struct Span {
     hipStream_t stream;
     const int* order;
     int w0, nw;
+    const int* ang_order;      // what the two angular kernels walk: `order`, or -- without a cell order -- the work-sorted schedule
 };
 
 // ---- kernel dispatch over (TORCHANI, NFRP, NFZP) ----
@@ -235,7 +239,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
                    : uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
             hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.order, sp.w0, sp.nw);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.ang_order, sp.w0, sp.nw);
         } else {
             const int wpg2 = waves_per_group(lw);
             const size_t lg = (size_t)lw * wpg2;
@@ -244,7 +248,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             auto k = ani_angular_forward_mfma<TA, NFRP, NFZP, 1, 5>;
             if (lg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
             hipLaunchKernelGGL(k, dim3(groups), dim3(64 * wpg2), lg, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
-                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.order, sp.w0, sp.nw);
+                               h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.ang_order, sp.w0, sp.nw);
         }
     } else if (forward) {
         auto k = h->chunked_forward ? ani_angular_forward_chunked<TA, NFRP, NFZP> : ani_angular_forward<TA, NFRP, NFZP>;
@@ -277,7 +281,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
         hipLaunchKernelGGL(k, dim3(div_up(N, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
-                           sp.order, sp.w0, sp.nw);
+                           sp.ang_order, sp.w0, sp.nw);
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
@@ -375,7 +379,8 @@ int make_spans(nnpops_ani* h, Span (&spans)[4]) {
     const int per = ((N + k - 1) / k + 3) & ~3;                // (whole workgroups of up to four atoms)
     for (int q = 0; q < k; q++) {
         const int w0 = std::min(N, q * per), w1 = q == k - 1 ? N : std::min(N, (q + 1) * per);
-        spans[q] = Span{q == 0 ? h->stream : h->side[q - 1], order, w0, w1 - w0};
+        spans[q] = Span{q == 0 ? h->stream : h->side[q - 1], order, w0, w1 - w0,
+                        order ? order : (h->work_order_valid && k == 1 ? h->d_work_order : nullptr)};
     }
     return k;
 }
@@ -489,6 +494,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
         if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_LPT")) h->lpt = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
@@ -531,6 +537,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_sorted_cell, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_tile_total, (size_t)h->max_cells / kScanTile + 2))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_atom, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_work_order, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_unsorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_bucket_offsets, (size_t)num_atoms * (hp.NB + 1)))) return cleanup(rc);
@@ -579,7 +586,7 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     dev_free(h->d_ids); dev_free(h->d_leg_force); dev_free(h->d_centre_force); dev_free(h->d_bucket_offsets);
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
-    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_tile_total); dev_free(h->d_sorted_atom); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
+    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_tile_total); dev_free(h->d_sorted_atom); dev_free(h->d_work_order); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
     for (int q = 0; q < 3; q++) {
         if (h->side[q]) (void)hipStreamDestroy(h->side[q]);
         if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
@@ -813,7 +820,26 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     NNPOPS_HIP_TRY(hipGetLastError());
     NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));      // clean slate for the next build
+    // Without a cell order (vacuum systems, batches of molecules) the angular kernels would walk the atoms in index order and
+    // the few atoms with the most triples -- work grows with the SQUARE of the angular neighbours: 4x between the core and
+    // the surface of a 60-atom molecule -- decide when the last occupancy round ends.  Longest first: the schedule is a
+    // permutation by decreasing neighbour count, rebuilt whenever the statistics are (a stale one is only a schedule).
+    // 128 conformers (7 589 atoms): angular forward 70 -> 4x us, see DESIGN.md.
+    std::vector<int> counts;
+    const bool want_order = !h->last_used_cells && h->hp.N >= 256 && h->lpt;
+    if (want_order) {
+        counts.resize((size_t)h->hp.N);
+        NNPOPS_HIP_TRY(hipMemcpyAsync(counts.data(), h->d_cnt_a, sizeof(int) * counts.size(), hipMemcpyDeviceToHost, h->stream));
+    }
     NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (want_order) {
+        std::vector<int> perm(counts.size());
+        for (size_t a = 0; a < perm.size(); a++) perm[a] = (int)a;
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return counts[a] > counts[b]; });
+        NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_work_order, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, h->stream));
+        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));      // (perm is a local)
+        h->work_order_valid = true;
+    }
     // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
     h->tile = std::min(32, std::max(8, st[kStatMaxAngular]));      // exact: every row of LDS saved is occupancy
     // (tiny tiles: nothing to gain; and the fallback of an atom that outgrows the tile needs the per-slot accumulators plus a
