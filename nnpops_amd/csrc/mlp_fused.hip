@@ -10,7 +10,8 @@
 // the two small layers of the gradient -- without its activations ever leaving the CU:
 //   * everything is computed TRANSPOSED, Y^T[features x atoms] = W[features x K] . X^T[K x atoms]: the weights are the A
 //     operand of v_mfma_f32_16x16x32_f16 (rows = output features), the activations the B operand (columns = atoms).  A wave
-//     owns a quarter of the output features (row blocks w, w + 4, ...) for all 64 atoms, so its weight fragments are its own:
+//     (eight per workgroup, two per SIMD) owns an eighth of the output features (row blocks w, w + 8) for all 64 atoms, so its
+//     weight fragments are its own:
 //     they go from L2 straight into registers in the instruction's operand layout (the packed planes are stored fragment
 //     by fragment, 1 KiB per wave load) and never touch LDS;
 //   * the activations of a layer are the B operand of the next one: they cross the waves through LDS in B-FRAGMENT layout
@@ -43,7 +44,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
-constexpr int kRB = 4;                      // row blocks (16 output features each) per wave: layer widths up to 256
+constexpr int kWaves = 8;                   // waves per workgroup: two per SIMD, so that one computes while the other waits for its weights
+constexpr int kThreads = 64 * kWaves;
+constexpr int kRB = 2;                      // row blocks (16 output features each) per wave: layer widths up to 16 * kRB * kWaves = 256
 constexpr int kCB = 4;                      // column blocks (16 atoms each) per workgroup: tiles of 64 atoms
 constexpr int kTile = 16 * kCB;
 constexpr int kFrag = 512;                  // halves per fragment plane: 64 lanes x 8
@@ -93,12 +96,12 @@ __device__ __forceinline__ void split4(const f32x4& v, f16x4& h, f16x4& l) {
 
 struct AFrag { f16x8 h[kRB], l[kRB]; };
 
-// fragments of K step s of this wave's row blocks (w, w + 4, ...); blocks past the layer are read from the last valid one
+// fragments of K step s of this wave's row blocks (w, w + kWaves, ...); blocks past the layer are read from the last valid one
 // (straight-line loads: a branch around a load makes the compiler drain the whole load queue where the paths meet)
 __device__ __forceinline__ void load_a(AFrag& a, const _Float16* __restrict__ wp, int steps, int nb, int s, int w, int lane) {
 #pragma unroll
     for (int j = 0; j < kRB; j++) {
-        const int rb = min(w + 4 * j, nb - 1);
+        const int rb = min(w + kWaves * j, nb - 1);
         const _Float16* p = wp + ((size_t)(rb * steps + s) * 2) * kFrag + lane * 8;
         a.h[j] = *reinterpret_cast<const f16x8*>(p);
         a.l[j] = *reinterpret_cast<const f16x8*>(p + kFrag);
@@ -154,7 +157,7 @@ template <typename F>
 __device__ __forceinline__ void for_blocks(int nmine, int w, F&& f) {
 #pragma unroll
     for (int j = 0; j < kRB; j++)
-        if (j < nmine) f(j, w + 4 * j);
+        if (j < nmine) f(j, w + kWaves * j);
 }
 
 // hand a block of fp32 values (D layout) to the next layer: 8-byte half slot of its B fragment, both planes
@@ -166,7 +169,7 @@ __device__ __forceinline__ void put_fragment(char* __restrict__ act, int rb, int
     *reinterpret_cast<f16x4*>(p + 1024) = l;
 }
 
-__device__ __forceinline__ int blocks_of_wave(int nb, int w) { return nb > w ? (nb - w + 3) / 4 : 0; }
+__device__ __forceinline__ int blocks_of_wave(int nb, int w) { return nb > w ? (nb - w + kWaves - 1) / kWaves : 0; }
 
 __device__ __forceinline__ const KindDesc& kind_of_block(const MlpArgs& g, int b) {
     int k = 0;
@@ -180,7 +183,7 @@ __device__ __forceinline__ const KindDesc& kind_of_block(const MlpArgs& g, int b
 // forward through all four layers (+ backward through layers 6, 4, 2 when GRAD)
 // =============================================================================================
 template <bool GRAD>
-__global__ __launch_bounds__(256, 1) void mlp_forward(const MlpArgs g) {
+__global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* xstage = lds;                                     // 2 x 8 KiB: the AEV columns of a K step, split, fragment layout
     char* actA = lds + 2 * kStageBytes;                     // 64 KiB
@@ -203,26 +206,24 @@ __global__ __launch_bounds__(256, 1) void mlp_forward(const MlpArgs g) {
     // ---------------- layer 0: the AEV rows of the tile stream through LDS, 32 columns per step ----------------
     {
         const _Float16* wp = kd.w0 + (size_t)m * nb1 * s0 * 2 * kFrag;
-        // staging role: thread -> (atom a = tid / 4, K group = tid % 4): eight consecutive columns
-        const int sa = tid >> 2, skg = tid & 3;
+        // staging role: thread -> (atom a = tid / 8, piece = tid % 8): four consecutive columns, one 8-byte half of a fragment slot
+        const int sa = tid >> 3, piece = tid & 7;
         const int srow = g.rows[kd.first + min(r0 + sa, kd.n - 1)];
-        const float* xsrc = g.x + (size_t)srow * g.ldx + skg * 8;
-        char* xdst = xstage + ((sa >> 4) * 2) * 1024 + ((sa & 15) + 16 * skg) * 16;
-        float xv[8];
+        const float* xsrc = g.x + (size_t)srow * g.ldx + piece * 4;
+        char* xdst = xstage + ((sa >> 4) * 2) * 1024 + ((sa & 15) + 16 * (piece >> 1)) * 16 + 8 * (piece & 1);
+        f32x4 xv;
         auto fetch_x = [&](int s) {
-            const int k = 32 * s + skg * 8;
-            const bool in = k < g.F;                         // (F is a multiple of 8: all eight or none)
-            const float* p = xsrc + (in ? 32 * s : -skg * 8);
-            const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+            const int k = 32 * s + piece * 4;
+            const bool in = k < g.F;                         // (F is a multiple of 8: all four or none)
+            const float4 v = *reinterpret_cast<const float4*>(xsrc + (in ? 32 * s : -piece * 4));
             const float z = in ? 1.0f : 0.0f;
-            xv[0] = lo.x * z; xv[1] = lo.y * z; xv[2] = lo.z * z; xv[3] = lo.w * z;
-            xv[4] = hi.x * z; xv[5] = hi.y * z; xv[6] = hi.z * z; xv[7] = hi.w * z;
+            xv = f32x4{v.x * z, v.y * z, v.z * z, v.w * z};
         };
         auto stage_x = [&](int stage) {
-            f16x8 h, l;
-            split8(xv, h, l);
-            *reinterpret_cast<f16x8*>(xdst + stage * kStageBytes) = h;
-            *reinterpret_cast<f16x8*>(xdst + stage * kStageBytes + 1024) = l;
+            f16x4 h, l;
+            split4(xv, h, l);
+            *reinterpret_cast<f16x4*>(xdst + stage * kStageBytes) = h;
+            *reinterpret_cast<f16x4*>(xdst + stage * kStageBytes + 1024) = l;
         };
         zero_acc(acc1, acc2);
         AFrag a0, a1;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward(const MlpArgs g) {
         });
     }
     // energies: sum over the K groups of a wave (lanes 16 apart), then over the waves
-    float* red = reinterpret_cast<float*>(xstage);          // 4 waves x 64 atoms (the x stages are idle now)
+    float* red = reinterpret_cast<float*>(xstage);          // kWaves x 64 atoms (the x stages are idle now)
 #pragma unroll
     for (int cb = 0; cb < kCB; cb++) {
         float p = part[cb];
@@ -308,7 +309,12 @@ __global__ __launch_bounds__(256, 1) void mlp_forward(const MlpArgs g) {
     }
     __syncthreads();
     if (tid < kTile && r0 + tid < kd.n)
-        g.energies[(size_t)(kd.first + r0 + tid) * g.M + m] = red[tid] + red[kTile + tid] + red[2 * kTile + tid] + red[3 * kTile + tid] + kd.b6[m];
+    {
+        float e = kd.b6[m];
+#pragma unroll
+        for (int v = 0; v < kWaves; v++) e += red[v * kTile + tid];
+        g.energies[(size_t)(kd.first + r0 + tid) * g.M + m] = e;
+    }
     if (!GRAD) return;
     // ---------------- backward: d2 = (W4^T d3) * CELU'(2), d1 = (W2^T d2) * CELU'(1) ----------------
     layer_resident(kd.w4t + (size_t)m * nb2 * s3 * 2 * kFrag, s3, nb2, n2, w, lane, actA, acc1, acc2);
@@ -342,9 +348,9 @@ __global__ __launch_bounds__(256, 1) void mlp_forward(const MlpArgs g) {
 // =============================================================================================
 // dE/dAEV^T [F x atoms] = W0^T [F x M*H1] . dE/dy1^T: workgroup = (tile of 64 atoms, 8 row blocks = 128 AEV columns)
 // =============================================================================================
-constexpr int kGradBlocks = 8;              // row blocks of F per workgroup (two per wave)
+constexpr int kGradBlocks = kWaves;         // row blocks of F per workgroup: one per wave
 
-__global__ __launch_bounds__(256, 2) void mlp_input_grad(const MlpArgs g) {
+__global__ __launch_bounds__(kThreads, 2) void mlp_input_grad(const MlpArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];     // 2 stages x 8 KiB of B fragments
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const KindDesc& kd = kind_of_block(g, blockIdx.x);
@@ -353,94 +359,74 @@ __global__ __launch_bounds__(256, 2) void mlp_input_grad(const MlpArgs g) {
     const int chunk = local % chunks, tile = local / chunks;
     const int r0 = tile * kTile;
     const int s1 = kd.h1 >> 5, steps = g.M * s1;
-    const int rbase = chunk * kGradBlocks + 2 * w;          // this wave: row blocks rbase, rbase + 1
-    const int nmine = max(0, min(2, nbf - rbase));
-    const _Float16* bsrc = kd.d1 + (size_t)tile * steps * (kCB * 2 * kFrag) + tid * 8;     // 256 threads x 16 B x 2 = 8 KiB per step
-    const _Float16* wp = kd.w0t;
+    const int rb = chunk * kGradBlocks + w;                 // this wave's row block of F
+    const bool mine = rb < nbf;
+    const _Float16* bsrc = kd.d1 + (size_t)tile * steps * (kCB * 2 * kFrag) + tid * 8;     // 512 threads x 16 B = 8 KiB per step
+    const _Float16* wp = kd.w0t + ((size_t)min(rb, nbf - 1) * steps * 2) * kFrag + lane * 8;
 
-    f32x4 acc1[2][kCB], acc2[2][kCB];
+    f32x4 acc1[kCB], acc2[kCB];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int cb = 0; cb < kCB; cb++) { acc1[j][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int cb = 0; cb < kCB; cb++) { acc1[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    struct A2 { f16x8 h[2], l[2]; };
-    auto load_a2 = [&](A2& a, int s) {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int rb = min(rbase + j, nbf - 1);
-            const _Float16* p = wp + ((size_t)(rb * steps + s) * 2) * kFrag + lane * 8;
-            a.h[j] = *reinterpret_cast<const f16x8*>(p);
-            a.l[j] = *reinterpret_cast<const f16x8*>(p + kFrag);
-        }
+    struct A1 { f16x8 h, l; };
+    auto load_a1 = [&](A1& a, int s) {
+        const _Float16* p = wp + (size_t)s * 2 * kFrag;
+        a.h = *reinterpret_cast<const f16x8*>(p);
+        a.l = *reinterpret_cast<const f16x8*>(p + kFrag);
     };
-    f16x8 bv0, bv1;
-    auto fetch_b = [&](int s) {
-        const _Float16* p = bsrc + (size_t)s * (kCB * 2 * kFrag);
-        bv0 = *reinterpret_cast<const f16x8*>(p);
-        bv1 = *reinterpret_cast<const f16x8*>(p + 256 * 8);
-    };
-    auto stage_b = [&](int stage) {
-        char* d = lds + stage * kStageBytes + tid * 16;
-        *reinterpret_cast<f16x8*>(d) = bv0;
-        *reinterpret_cast<f16x8*>(d + 4096) = bv1;
-    };
-    auto mma = [&](const A2& a, const char* bstage) {
+    f16x8 bv;
+    auto fetch_b = [&](int s) { bv = *reinterpret_cast<const f16x8*>(bsrc + (size_t)s * (kCB * 2 * kFrag)); };
+    auto stage_b = [&](int stage) { *reinterpret_cast<f16x8*>(lds + stage * kStageBytes + tid * 16) = bv; };
+    auto mma = [&](const A1& a, const char* bstage) {
         f16x8 bh[kCB], bl[kCB];
 #pragma unroll
         for (int cb = 0; cb < kCB; cb++) {
             bh[cb] = *reinterpret_cast<const f16x8*>(bstage + (cb * 2) * 1024 + lane * 16);
             bl[cb] = *reinterpret_cast<const f16x8*>(bstage + (cb * 2 + 1) * 1024 + lane * 16);
         }
+        if (mine) {
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-            if (j < nmine) {
-#pragma unroll
-                for (int cb = 0; cb < kCB; cb++) {
-                    acc1[j][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[j], bh[cb], acc1[j][cb], 0, 0, 0);
-                    acc2[j][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h[j], bl[cb], acc2[j][cb], 0, 0, 0);
-                    acc2[j][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l[j], bh[cb], acc2[j][cb], 0, 0, 0);
-                }
+            for (int cb = 0; cb < kCB; cb++) {
+                acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, bh[cb], acc1[cb], 0, 0, 0);
+                acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, bl[cb], acc2[cb], 0, 0, 0);
+                acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, bh[cb], acc2[cb], 0, 0, 0);
             }
+        }
     };
-    A2 a0, a1;
+    // weights four steps ahead (four register sets, 8 registers each), B fragments two steps ahead through two LDS stages
+    A1 a0, a1, a2, a3;
     fetch_b(0);
-    load_a2(a0, 0);
+    load_a1(a0, 0); load_a1(a1, min(1, steps - 1)); load_a1(a2, min(2, steps - 1));
     stage_b(0);
     fetch_b(min(1, steps - 1));
     __syncthreads();
-    for (int s = 0; s < steps; s += 2) {
-        load_a2(a1, min(s + 1, steps - 1));
-        mma(a0, lds + (s & 1) * kStageBytes);
+    auto step = [&](int s, const A1& cur, A1& refill) {
+        load_a1(refill, min(s + 3, steps - 1));
+        mma(cur, lds + (s & 1) * kStageBytes);
         stage_b((s + 1) & 1);
         fetch_b(min(s + 2, steps - 1));
         __syncthreads();
-        if (s + 1 < steps) {
-            load_a2(a0, min(s + 2, steps - 1));
-            mma(a1, lds + ((s + 1) & 1) * kStageBytes);
-            stage_b(s & 1);
-            fetch_b(min(s + 3, steps - 1));
-            __syncthreads();
-        }
+    };
+    for (int s = 0; s < steps; s += 4) {
+        step(s, a0, a3);
+        if (s + 1 < steps) step(s + 1, a1, a0);
+        if (s + 2 < steps) step(s + 2, a2, a1);
+        if (s + 3 < steps) step(s + 3, a3, a2);
     }
     const float up = (g.upstream ? *g.upstream : 1.0f) * g.dx_scale;
     const int kgD = lane >> 4, a16 = lane & 15;
+    const int col = rb * 16 + kgD * 4;
+    if (mine && col < g.F) {                                 // (F is a multiple of 4)
 #pragma unroll
-    for (int cb = 0; cb < kCB; cb++) {
-        const int r = r0 + cb * 16 + a16;
-        if (r >= kd.n) continue;
-        float* out = g.dx + (size_t)g.rows[kd.first + r] * g.lddx;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = (rbase + j) * 16 + kgD * 4;
-            if (j < nmine && col < g.F) {                    // (F is a multiple of 4)
-                float4 v;
-                v.x = (acc1[j][cb][0] + kLoInv * acc2[j][cb][0]) * kUnscale * up;
-                v.y = (acc1[j][cb][1] + kLoInv * acc2[j][cb][1]) * kUnscale * up;
-                v.z = (acc1[j][cb][2] + kLoInv * acc2[j][cb][2]) * kUnscale * up;
-                v.w = (acc1[j][cb][3] + kLoInv * acc2[j][cb][3]) * kUnscale * up;
-                *reinterpret_cast<float4*>(out + col) = v;
-            }
+        for (int cb = 0; cb < kCB; cb++) {
+            const int r = r0 + cb * 16 + a16;
+            if (r >= kd.n) continue;
+            float4 v;
+            v.x = (acc1[cb][0] + kLoInv * acc2[cb][0]) * kUnscale * up;
+            v.y = (acc1[cb][1] + kLoInv * acc2[cb][1]) * kUnscale * up;
+            v.z = (acc1[cb][2] + kLoInv * acc2[cb][2]) * kUnscale * up;
+            v.w = (acc1[cb][3] + kLoInv * acc2[cb][3]) * kUnscale * up;
+            *reinterpret_cast<float4*>(g.dx + (size_t)g.rows[kd.first + r] * g.lddx + col) = v;
         }
     }
 }
@@ -539,8 +525,8 @@ int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gra
         NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    if (with_gradient) hipLaunchKernelGGL(mlp_forward<true>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(mlp_forward<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, g);
+    if (with_gradient) hipLaunchKernelGGL(mlp_forward<true>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(mlp_forward<false>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
@@ -554,7 +540,7 @@ int nnpops_mlp_input_grad(void* stream, const nnpops_mlp_frame* frame) {
     int rc = check_and_fill(frame, g, true, chunks, &blocks);
     if (rc != NNPOPS_OK) return rc;
     if (blocks == 0) return NNPOPS_OK;
-    hipLaunchKernelGGL(mlp_input_grad, dim3(blocks), dim3(256), 2 * kStageBytes, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(mlp_input_grad, dim3(blocks), dim3(kThreads), 2 * kStageBytes, (hipStream_t)stream, g);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
