@@ -944,7 +944,73 @@ def run_cfconv(args, R):
     return out_json
 
 
-WORKLOADS = {"aev": run_aev, "cfconv": run_cfconv, "conformers": run_conformers, "neighbors": run_neighbors,
+# =============================================================================================
+# The reference's OWN CFConv benchmark (src/schnet/BenchmarkCudaCFConv.cu:62-110): width 128, 50 Gaussians, cutoff 10 A,
+# Gaussian width 0.2, shifted softplus, N(0, 1) weights; one iteration = ONE neighbour build + SIX x (compute + backprop)
+# -- the regime a SchNet runs in (3-6 interaction layers per list), where the build is amortised.
+# =============================================================================================
+def run_cfconv_reference(args, R):
+    import numpy as np
+    import torch
+    from nnpops_amd import workloads
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    dev = R.dev
+    n, W, G, cutoff, sigma, layers = args.atoms, 128, 50, 10.0, 0.2, 6
+    pos, _, box = workloads.random_box(n, density=0.1, seed=3)
+    rng = np.random.default_rng(0)
+    w1, w2 = rng.standard_normal((W, G)).astype(np.float32), rng.standard_normal((W, W)).astype(np.float32)
+    b1, b2 = rng.standard_normal(W).astype(np.float32), rng.standard_normal(W).astype(np.float32)
+    x = rng.standard_normal((n, W)).astype(np.float32)
+    gy = rng.standard_normal((n, W)).astype(np.float32)
+    nb = CFConvNeighbors(n, cutoff, periodic=True, device=R.local_rank)
+    cf = CFConv(n, W, G, cutoff, sigma, "ssp", w1, b1, w2, b2, periodic=True, device=R.local_rank)
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    tx, tg = torch.tensor(x, device=dev), torch.tensor(gy, device=dev)
+    out = torch.empty_like(tx)
+    nb.build(tpos, tbox, check=True)
+    pairs = nb.num_pairs()
+
+    def iteration():
+        nb.build(tpos, tbox, check=False)
+        for _ in range(layers):
+            cf.compute(nb, tpos, tx, tbox, out)
+            xg, pg = cf.backprop(nb, tpos, tx, tg, tbox)
+        return xg, pg
+
+    xg, pg = iteration()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(xg).all()) and bool(torch.isfinite(pg).all())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record(); nb.build(tpos, tbox, check=False)
+    ev[1].record(); cf.compute(nb, tpos, tx, tbox, out)
+    ev[2].record(); cf.backprop(nb, tpos, tx, tg, tbox)
+    ev[3].record()
+    torch.cuda.synchronize()
+    tb, tf, tbw = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    iters = max(3, min(args.steps, 10))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    torch.cuda.synchronize()
+    elapsed = (time.perf_counter() - t0) / iters
+    flops_fwd = 2.0 * (G * W + W * W) * pairs
+    tflops = flops_fwd / (tf * 1e-3) / 1e12
+    return {
+        "metric": "iterations/sec of the reference's CFConv benchmark (1 neighbour build + 6 x (compute + backprop)), W=128 G=50 cutoff 10 A",
+        "value": round(1.0 / elapsed, 3), "unit": "iterations/s", "n_gpus": 1, "steps": iters, "warmup": 1,
+        "ms_per_step": round(1e3 * elapsed, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (dense layers: operands split into two fp16 planes when the weights keep them inside the fp16 range)", "data": "synthetic",
+        "config": {"workload": f"BenchmarkCudaCFConv.cu:62-110 on a {n}-atom periodic box at 0.1 atoms/A^3: W={W}, G={G}, cutoff {cutoff} A, "
+                               f"sigma {sigma}, ssp, N(0,1) weights, {layers} convolution layers (forward + backward) per neighbour build",
+                   "half_pairs": pairs, "layers_per_build": layers},
+        "phases_ms": {"build": round(tb, 4), "forward_one_layer": round(tf, 4), "backward_one_layer": round(tbw, 4)},
+        "roofline": {"bound": "mfma", "kernel": "cfconv filters + gather (forward of one layer)", "achieved": round(tflops, 3),
+                     "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s", "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,
+                     "note": "algorithmic flops (half-pair count) / measured forward time of one layer, against the fp32 matrix peak"},
+    }
+
+
+WORKLOADS = {"aev": run_aev, "cfconv": run_cfconv, "cfconv_reference": run_cfconv_reference, "conformers": run_conformers, "neighbors": run_neighbors,
              "torchani": run_torchani, "latency": run_latency}
 
 
@@ -982,7 +1048,7 @@ def main():
     if not args.no_side:
         sargs = argparse.Namespace(**vars(args))
         sargs.steps, sargs.warmup, sargs.atoms = min(args.steps, 100), min(args.warmup, 10), 10000
-        names = ["conformers"] if R.world > 1 else ["latency", "torchani", "cfconv", "conformers", "neighbors"]
+        names = ["conformers"] if R.world > 1 else ["latency", "torchani", "cfconv", "cfconv_reference", "conformers", "neighbors"]
         for name in names:
             try:
                 res = WORKLOADS[name](sargs, R)

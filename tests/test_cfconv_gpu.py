@@ -211,3 +211,16 @@ def test_many_gaussians_at_a_matrix_width():
     step aside for the vector kernel with streamed weights (any G up to 256 is accepted)."""
     pos, _ = workloads.conformer(60, seed=91)
     _case(pos, None, 128, 200, 5.0, 0.05, "ssp", seed=31)
+
+
+def test_reference_benchmark_parameters():
+    """The parameters of the reference's own CFConv benchmark (src/schnet/BenchmarkCudaCFConv.cu:64-67,87: width 128,
+    50 Gaussians, cutoff 10 A, Gaussian width 0.2, shifted softplus, N(0, 1) weights) against the oracle, on a periodic box just
+    large enough for that cutoff (1 000 atoms, 21.5 A: ~420 neighbours per atom, rows far longer than a wave)."""
+    pos, _, box = workloads.random_box(1000, density=0.1, seed=13)
+    rng = np.random.default_rng(0)
+    W, G = 128, 50
+    w = (rng.standard_normal((W, G)).astype(np.float32), rng.standard_normal(W).astype(np.float32),
+         rng.standard_normal((W, W)).astype(np.float32), rng.standard_normal(W).astype(np.float32),
+         rng.standard_normal((1000, W)).astype(np.float32))
+    _case(pos, box, W, G, 10.0, 0.2, "ssp", seed=1, w=w)
