@@ -96,8 +96,8 @@ struct nnpops_ani {
     int ld_radial = 0, ld_angular = 0;   // row strides (floats) of the AEV / gradient arrays of the call in progress
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
     int* d_work_order = nullptr;    // [N] atoms by DECREASING number of angular neighbours (check() builds it): the schedule of the
-    bool work_order_valid = false;  //     angular kernels when there is no cell order -- heaviest atoms first, the light ones fill the tail
-    bool lpt = true;                // $NNPOPS_ANI_LPT=0 switches that schedule off (A/B)
+    bool work_order_valid = false;  //     angular kernels -- heaviest atoms first, the light ones fill the tail
+    int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     int timing_every = 1;           // ... on every timing_every-th launch
     unsigned timing_seen[NNPOPS_ANI_NUM_KERNELS] = {};
@@ -209,7 +209,7 @@ struct Span {
     hipStream_t stream;
     const int* order;
     int w0, nw;
-    const int* ang_order;      // what the two angular kernels walk: `order`, or -- without a cell order -- the work-sorted schedule
+    const int* ang_order;      // what the two angular kernels walk: the work-sorted schedule (check() builds it), else `order`
 };
 
 // ---- kernel dispatch over (TORCHANI, NFRP, NFZP) ----
@@ -380,7 +380,7 @@ int make_spans(nnpops_ani* h, Span (&spans)[4]) {
     for (int q = 0; q < k; q++) {
         const int w0 = std::min(N, q * per), w1 = q == k - 1 ? N : std::min(N, (q + 1) * per);
         spans[q] = Span{q == 0 ? h->stream : h->side[q - 1], order, w0, w1 - w0,
-                        order ? order : (h->work_order_valid && k == 1 ? h->d_work_order : nullptr)};
+                        h->work_order_valid && k == 1 && (!order || h->lpt == 2) ? h->d_work_order : order};
     }
     return k;
 }
@@ -494,7 +494,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         h->forward_kernel = h->mfma_ok ? 2 : -1;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
         if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0 ? 1 : 0;
-        if (const char* e = std::getenv("NNPOPS_ANI_LPT")) h->lpt = std::atoi(e) != 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_LPT")) h->lpt = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
@@ -820,13 +820,14 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
     NNPOPS_HIP_TRY(hipGetLastError());
     NNPOPS_HIP_TRY(hipMemcpyAsync(st, h->d_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     NNPOPS_HIP_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int) * kStatWords, h->stream));      // clean slate for the next build
-    // Without a cell order (vacuum systems, batches of molecules) the angular kernels would walk the atoms in index order and
-    // the few atoms with the most triples -- work grows with the SQUARE of the angular neighbours: 4x between the core and
-    // the surface of a 60-atom molecule -- decide when the last occupancy round ends.  Longest first: the schedule is a
-    // permutation by decreasing neighbour count, rebuilt whenever the statistics are (a stale one is only a schedule).
-    // 128 conformers (7 589 atoms): angular forward 70 -> 4x us, see DESIGN.md.
+    // The two angular kernels touch nothing but their own atom's records, so the order in which they walk the atoms is free.
+    // In index or cell order the few atoms with the most triples -- work grows with the SQUARE of the angular neighbours: 4x
+    // between the core and the surface of a 60-atom molecule, 45..300 triples in a liquid -- decide when the last occupancy
+    // round ends.  Longest first: the schedule is a permutation by decreasing neighbour count, built here from the counts of
+    // this frame and kept (a stale one is only a schedule; rebuilt whenever the statistics are).  128 conformers (7 589
+    // atoms): angular forward 70 -> 46 us, backward 48 -> 38; 10 000-atom liquid: 19.2 -> 17.6 and 17.6 -> 15.7 us.
     std::vector<int> counts;
-    const bool want_order = !h->last_used_cells && h->hp.N >= 256 && h->lpt;
+    const bool want_order = (!h->last_used_cells || h->lpt == 2) && h->hp.N >= 256 && h->lpt;
     if (want_order) {
         counts.resize((size_t)h->hp.N);
         NNPOPS_HIP_TRY(hipMemcpyAsync(counts.data(), h->d_cnt_a, sizeof(int) * counts.size(), hipMemcpyDeviceToHost, h->stream));
