@@ -39,6 +39,14 @@ FP32_MATRIX_PEAK = 157.3   # TFLOP/s, v_mfma_f32_* with fp32 operands (same guid
 F16_DENSE_PEAK = 2500.0    # TFLOP/s, dense fp16/bf16 MFMA (same guide)
 
 ROOFLINE_KERNELS = ("neighbors", "angular_forward", "angular_backward", "radial_backward")
+# kernel-name fragments of the rocprofv3 trace -> the keys above (the two cell-grid kernels are reported with the step)
+PMC_KERNEL_OF = {"ani_neighbors_cells": "neighbors", "ani_angular_forward_mfma": "angular_forward",
+                 "ani_angular_backward_pair": "angular_backward", "ani_radial_backward_lanes": "radial_backward",
+                 "bin_atoms": "cell_grid", "order_binned": "cell_grid"}
+# seconds of SIMD issue time per instruction, measured on the MI355X by tools/ubench/valu_issue.hip with >= 2 waves per SIMD
+# (profiles/r02_valu_issue_ubench.txt): plain VALU 1.1 ns, v_mfma_f32_4x4x1 3.5 ns; transcendentals are NOT priced extra -- their
+# pipe overlaps the plain VALU of the other waves (round 3: replacing five of them by fourteen multiplies made the kernels slower)
+VALU_ISSUE_NS, MFMA4X4_ISSUE_NS, SIMDS = 1.1, 3.5, 1024
 ROCPROF_NAME = {"neighbors": "ani_neighbors_cells (neighbour rows + radial AEV)", "angular_forward": "ani_angular_forward_mfma",
                 "angular_backward": "ani_angular_backward_pair", "radial_backward": "ani_radial_backward_lanes (+ force gather)"}
 
@@ -148,6 +156,68 @@ def cpu_baseline(pos, species, box, rf, af, budget_s=12.0, all_cores=True):
                                     "sample": f"{done} independent {m}-atom frames, one process per core: slowest {busy:.2f} s against "
                                               f"{t_single:.2f} s alone; that speed-up applied to the single-core {n}-atom figure"}
     return out
+
+
+# =============================================================================================
+# hardware counters of the headline kernels, measured IN THIS RUN: bench.py profiles three steps of itself under rocprofv3
+# (separate --pmc passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes) and reads the rocpd databases
+# =============================================================================================
+def _pmc_pass(counters, atoms, workdir, tag):
+    """One rocprofv3 pass over `bench.py --steps 3` -> {roofline key: {counter: chip total per dispatch}} (None when rocprofv3
+    is missing or the pass fails)."""
+    import glob
+    import shutil
+    import sqlite3
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = os.path.join(workdir, tag)
+    cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", out, "-o", tag, "--output-format", "rocpd", "--", sys.executable,
+           os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--settle", "0", "--atoms", str(atoms), "--no-side",
+           "--no-cpu-baseline", "--no-pmc"]
+    env = dict(os.environ, TMPDIR=workdir)
+    try:
+        subprocess.run(cmd, cwd=workdir, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+        dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+        if not dbs:
+            return None
+        con = sqlite3.connect(dbs[0])
+        rows = con.execute("select k.name, p.counter_name, sum(p.counter_value), count(distinct k.dispatch_id) "
+                           "from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+    except Exception:
+        return None
+    res = {}
+    for name, counter, total, ndisp in rows:
+        for frag, key in PMC_KERNEL_OF.items():
+            if frag in name:
+                slot = res.setdefault(key, {})
+                slot[counter] = slot.get(counter, 0.0) + total / max(ndisp, 1)
+    return res
+
+
+def measure_counters(atoms):
+    """-> ({kernel: HBM bytes per launch}, {kernel: {valu, mfma, waves}}) from four rocprofv3 passes of this very workload, or
+    ({}, {}) when rocprofv3 is not available.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE reports half
+    the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is."""
+    import shutil
+    import tempfile
+    workdir = tempfile.mkdtemp(prefix="nnpops_pmc_")
+    try:
+        fetch = _pmc_pass(["FETCH_SIZE"], atoms, workdir, "fetch")
+        write = _pmc_pass(["WRITE_SIZE"], atoms, workdir, "write") if fetch else None
+        sq = _pmc_pass(["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA"], atoms, workdir, "sq") if fetch else None
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    traffic, insts = {}, {}
+    if fetch and write:
+        for k in fetch:
+            if k in write and "FETCH_SIZE" in fetch[k] and "WRITE_SIZE" in write[k]:
+                traffic[k] = int((2.0 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024)
+    if sq:
+        for k, c in sq.items():
+            insts[k] = {"valu": c.get("SQ_INSTS_VALU", 0.0), "mfma": c.get("SQ_INSTS_MFMA", 0.0), "salu": c.get("SQ_INSTS_SALU", 0.0),
+                        "lds": c.get("SQ_INSTS_LDS", 0.0), "waves": c.get("SQ_WAVES", 0.0)}
+    return traffic, insts
 
 
 # =============================================================================================
@@ -277,7 +347,8 @@ def run_aev(args, R):
     import gc
     gc.collect()
     gc.disable()
-    for _ in range(2500 if n <= 20000 else 250):              # (a COUNT, the same on every rank: every step holds a collective)
+    settle = args.settle if args.settle >= 0 else (2500 if n <= 20000 else 250)
+    for _ in range(settle):                                  # (a COUNT, the same on every rank: every step holds a collective)
         step()
     drain()
     torch.cuda.synchronize()
@@ -330,18 +401,27 @@ def run_aev(args, R):
            "neighbors": n * 16 + n * nr_w * 4,                # positions+species in, the radial AEV out (it is fused here)
            "radial_backward": n * nr_w * 4 + n * 12}          # the radial gradient row in, forces out
     step_bytes = n * (16 + 2 * (na_w + nr_w) * 4 + 12)        # N * (16 + 2 * 4032 + 12)
-    traffic_all = {}
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if tj.get("atoms") == n:
-            traffic_all = tj
-    except (OSError, ValueError):
-        pass
+    # HBM traffic and instruction counts of these kernels, measured now (rocprofv3 on three steps of this same workload; the
+    # counters come from their own passes, the TIMES above from the un-profiled run)
+    traffic_all, insts = ({}, {}) if (args.no_pmc or world > 1) else measure_counters(n)
+    traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run: (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch" if traffic_all else None
+
+    def valu_floor(k):
+        """SIMD issue time the kernel's vector instructions need at the measured issue prices, against its measured duration: a
+        kernel at frac ~0.7 is bound by vector-instruction issue, not by HBM."""
+        c = insts.get(k)
+        if not c or kern.get(k, 0) <= 0:
+            return None
+        plain = c["valu"] - c["mfma"]
+        floor_s = (plain * VALU_ISSUE_NS + c["mfma"] * MFMA4X4_ISSUE_NS) * 1e-9 / SIMDS
+        return {"valu_per_atom": round(c["valu"] / n, 1), "mfma_per_atom": round(c["mfma"] / n, 1), "salu_per_atom": round(c["salu"] / n, 1),
+                "lds_per_atom": round(c["lds"] / n, 1), "issue_floor_us": round(1e6 * floor_s, 2),
+                "frac": round(floor_s / kern[k], 4)}
 
     def roof(k):
         ach = alg[k] / kern[k] / 1e9 if kern.get(k, 0) > 0 else 0.0
         return {"kernel": ROCPROF_NAME[k], "us": round(1e6 * kern.get(k, 0.0), 2), "algorithmic_bytes_per_launch": alg[k],
-                "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(k)}
+                "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(k), "valu": valu_floor(k)}
 
     dom = roof(dominant)
     out = {
@@ -356,14 +436,16 @@ def run_aev(args, R):
         "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
         "event_pair_overhead_us": round(1e6 * event_overhead, 2),
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                     "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "valu": dom["valu"],
                      "limiter": "not HBM: the per-atom kernels are bound by vector-instruction issue while the chip is full and by "
                                 "latency in the last occupancy round (DESIGN.md s3/s6: 390-1160 VALU instructions per atom per "
                                 "kernel, 1.2-2.8 rounds of resident waves at 10 000 atoms)",
                      "angular": {"forward": roof("angular_forward"), "backward": roof("angular_backward")},
                      "per_kernel": {k: roof(k) for k in ROOFLINE_KERNELS},
                      "step": {"algorithmic_bytes": step_bytes, "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                              "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
+                              "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                              "traffic": (sum(traffic_all.values()) if traffic_all else None)}},
     }
     if not args.no_cpu_baseline and world == 1:              # the CPU leg is timed on rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(pos, species, box, rf, af)
@@ -1024,6 +1106,8 @@ def main():
     ap.add_argument("--atoms", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (HBM traffic, instruction counts) of the headline kernels")
+    ap.add_argument("--settle", type=int, default=-1, help="untimed settling steps before the warm-up (-1: 2500 for frames up to 20 000 atoms)")
     ap.add_argument("--strict-side", action="store_true", help="exit with status 3 when a side workload failed (the line is still printed)")
     ap.add_argument("--graph", action="store_true", help="torchani / cfconv workloads: replay the step as one captured HIP graph")
     ap.add_argument("--nn-layout", default="fused", choices=["fused", "gemm", "grouped", "reference"],
