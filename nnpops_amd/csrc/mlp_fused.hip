@@ -85,12 +85,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& h, f16x8& l) 
     }
 }
 
+// v (already scaled into range) -> hi + 2^-11 lo'.  The high plane is rounded toward zero two values at a time
+// (v_cvt_pkrtz_f16_f32: any fp16 near v will do, the low plane carries the exact remainder), the low plane to nearest.
 __device__ __forceinline__ void split4(const f32x4& v, f16x4& h, f16x4& l) {
+    typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float s = v[i] * kScale;
-        h[i] = (_Float16)s;
-        l[i] = (_Float16)((s - (float)h[i]) * kLoScale);
+    for (int i = 0; i < 4; i += 2) {
+        const pk2 hh = __builtin_amdgcn_cvt_pkrtz(v[i], v[i + 1]);
+        h[i] = (_Float16)hh[0]; h[i + 1] = (_Float16)hh[1];
+        l[i] = (_Float16)((v[i] - (float)hh[0]) * kLoScale);
+        l[i + 1] = (_Float16)((v[i + 1] - (float)hh[1]) * kLoScale);
     }
 }
 
@@ -137,18 +141,23 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc1)[kRB][kCB], f32x4 (&acc2)[
 }
 
 // A layer whose B operand is already resident in LDS (an activation region in fragment layout): no barrier inside.
+// The weights are requested three K steps ahead (four register sets of 16: an L2 round trip is longer than a step).
 __device__ __forceinline__ void layer_resident(const _Float16* __restrict__ wp, int steps, int nb, int nmine, int w, int lane,
                                                const char* __restrict__ act, f32x4 (&acc1)[kRB][kCB], f32x4 (&acc2)[kRB][kCB]) {
     zero_acc(acc1, acc2);
-    AFrag a0, a1;
+    AFrag a0, a1, a2, a3;
     load_a(a0, wp, steps, nb, 0, w, lane);
-    for (int s = 0; s < steps; s += 2) {
-        load_a(a1, wp, steps, nb, min(s + 1, steps - 1), w, lane);
-        mma_step(a0, act + (size_t)s * kStageBytes, nmine, lane, acc1, acc2);
-        if (s + 1 < steps) {
-            load_a(a0, wp, steps, nb, min(s + 2, steps - 1), w, lane);
-            mma_step(a1, act + (size_t)(s + 1) * kStageBytes, nmine, lane, acc1, acc2);
-        }
+    load_a(a1, wp, steps, nb, min(1, steps - 1), w, lane);
+    load_a(a2, wp, steps, nb, min(2, steps - 1), w, lane);
+    auto step = [&](int s, const AFrag& cur, AFrag& refill) {
+        load_a(refill, wp, steps, nb, min(s + 3, steps - 1), w, lane);
+        mma_step(cur, act + (size_t)s * kStageBytes, nmine, lane, acc1, acc2);
+    };
+    for (int s = 0; s < steps; s += 4) {
+        step(s, a0, a3);
+        if (s + 1 < steps) step(s + 1, a1, a0);
+        if (s + 2 < steps) step(s + 2, a2, a1);
+        if (s + 3 < steps) step(s + 3, a3, a2);
     }
 }
 
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
             const bool in = k < g.F;                         // (F is a multiple of 8: all four or none)
             const float4 v = *reinterpret_cast<const float4*>(xsrc + (in ? 32 * s : -piece * 4));
             const float z = in ? 1.0f : 0.0f;
-            xv = f32x4{v.x * z, v.y * z, v.z * z, v.w * z};
+            const float zs = z * kScale;
+            xv = f32x4{v.x * zs, v.y * zs, v.z * zs, v.w * zs};
         };
         auto stage_x = [&](int stage) {
             f16x4 h, l;
@@ -226,41 +236,44 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
             *reinterpret_cast<f16x4*>(xdst + stage * kStageBytes + 1024) = l;
         };
         zero_acc(acc1, acc2);
-        AFrag a0, a1;
+        AFrag a0, a1, a2, a3;                                // weights three steps ahead, the AEV columns two (one in LDS, one in registers)
         fetch_x(0);
         load_a(a0, wp, s0, nb1, 0, w, lane);
+        load_a(a1, wp, s0, nb1, min(1, s0 - 1), w, lane);
+        load_a(a2, wp, s0, nb1, min(2, s0 - 1), w, lane);
         stage_x(0);
         fetch_x(min(1, s0 - 1));
         __syncthreads();
-        for (int s = 0; s < s0; s += 2) {
-            load_a(a1, wp, s0, nb1, min(s + 1, s0 - 1), w, lane);
-            mma_step(a0, xstage + (s & 1) * kStageBytes, n1, lane, acc1, acc2);
+        auto step = [&](int s, const AFrag& cur, AFrag& refill) {
+            load_a(refill, wp, s0, nb1, min(s + 3, s0 - 1), w, lane);
+            mma_step(cur, xstage + (s & 1) * kStageBytes, n1, lane, acc1, acc2);
             stage_x((s + 1) & 1);                            // step s + 1 (fetched one iteration ago)
             fetch_x(min(s + 2, s0 - 1));
             __syncthreads();
-            if (s + 1 < s0) {
-                load_a(a0, wp, s0, nb1, min(s + 2, s0 - 1), w, lane);
-                mma_step(a1, xstage + ((s + 1) & 1) * kStageBytes, n1, lane, acc1, acc2);
-                stage_x(s & 1);                              // step s + 2
-                fetch_x(min(s + 3, s0 - 1));
-                __syncthreads();
-            }
+        };
+        for (int s = 0; s < s0; s += 4) {
+            step(s, a0, a3);
+            if (s + 1 < s0) step(s + 1, a1, a0);
+            if (s + 2 < s0) step(s + 2, a2, a1);
+            if (s + 3 < s0) step(s + 3, a3, a2);
         }
     }
-    // bias + CELU; y1 -> region A
+    // bias + CELU; y1 -> region A.  Everything is kept divided by 16 (the operand scale): vs = v / 16 comes straight out of the
+    // accumulators (acc1 + acc2 / 2048 + b / 16), CELU(v) / 16 = vs > 0 ? vs : (alpha / 16) (exp(16 vs / alpha) - 1).
+    const float exp_scale = kUnscale * inv_alpha * 1.44269504089f, alpha_s = g.alpha * kScale;
     auto activate = [&](const float* __restrict__ bias, int nmine, f32x4 (&c)[kRB][kCB], char* act) {
         for_blocks(nmine, w, [&](int j, int rb) {
             const float4 b = *reinterpret_cast<const float4*>(bias + rb * 16 + kgD * 4);
-            const float bq[4] = {b.x, b.y, b.z, b.w};
+            const float bq[4] = {b.x * kScale, b.y * kScale, b.z * kScale, b.w * kScale};
 #pragma unroll
             for (int cb = 0; cb < kCB; cb++) {
                 f32x4 y;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const float v = (acc1[j][cb][q] + kLoInv * acc2[j][cb][q]) * kUnscale + bq[q];
-                    const float e = __expf(fminf(v, 0.f) * inv_alpha);      // CELU'(v) for v <= 0
-                    y[q] = v > 0.f ? v : g.alpha * (e - 1.0f);              // CELU (BatchedNN.py:103-109)
-                    if (GRAD) c[j][cb][q] = v > 0.f ? 1.0f : e;
+                    const float vs = fmaf(kLoInv, acc2[j][cb][q], acc1[j][cb][q]) + bq[q];
+                    const float e = __builtin_amdgcn_exp2f(fminf(vs, 0.f) * exp_scale);       // CELU'(v) for v <= 0
+                    y[q] = vs > 0.f ? vs : fmaf(alpha_s, e, -alpha_s);                        // CELU / 16 (BatchedNN.py:103-109)
+                    if (GRAD) c[j][cb][q] = vs > 0.f ? 1.0f : e;
                 }
                 put_fragment(act, rb, cb, lane, y);
             }
@@ -282,17 +295,19 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
         for_blocks(n3, w, [&](int j, int rb) {
             const float4 b = *reinterpret_cast<const float4*>(bias + rb * 16 + kgD * 4);
             const float4 wl = *reinterpret_cast<const float4*>(w6 + rb * 16 + kgD * 4);
-            const float bq[4] = {b.x, b.y, b.z, b.w}, wq[4] = {wl.x, wl.y, wl.z, wl.w};
+            const float bq[4] = {b.x * kScale, b.y * kScale, b.z * kScale, b.w * kScale};
+            const float wq[4] = {wl.x * kUnscale, wl.y * kUnscale, wl.z * kUnscale, wl.w * kUnscale};      // (times the scaled y3)
+            const float ws[4] = {wl.x * kScale, wl.y * kScale, wl.z * kScale, wl.w * kScale};              // d3 / 16
 #pragma unroll
             for (int cb = 0; cb < kCB; cb++) {
                 f32x4 d;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const float v = (acc1[j][cb][q] + kLoInv * acc2[j][cb][q]) * kUnscale + bq[q];
-                    const float e = __expf(fminf(v, 0.f) * inv_alpha);
-                    const float y = v > 0.f ? v : g.alpha * (e - 1.0f);
-                    part[cb] += wq[q] * y;
-                    d[q] = wq[q] * (v > 0.f ? 1.0f : e);                    // dE/d(pre-activation 3) = w6 CELU'
+                    const float vs = fmaf(kLoInv, acc2[j][cb][q], acc1[j][cb][q]) + bq[q];
+                    const float e = __builtin_amdgcn_exp2f(fminf(vs, 0.f) * exp_scale);
+                    const float ys = vs > 0.f ? vs : fmaf(alpha_s, e, -alpha_s);
+                    part[cb] = fmaf(wq[q], ys, part[cb]);
+                    d[q] = vs > 0.f ? ws[q] : ws[q] * e;                    // dE/d(pre-activation 3) / 16 = w6 CELU' / 16
                 }
                 if (GRAD) put_fragment(actA, rb, cb, lane, d);              // (region A: layer 2 is done with it)
             }
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
         for (int cb = 0; cb < kCB; cb++) {
             f32x4 d;
 #pragma unroll
-            for (int q = 0; q < 4; q++) d[q] = (acc1[j][cb][q] + kLoInv * acc2[j][cb][q]) * kUnscale * c2[j][cb][q];
+            for (int q = 0; q < 4; q++) d[q] = fmaf(kLoInv, acc2[j][cb][q], acc1[j][cb][q]) * c2[j][cb][q];      // d2 / 16
             put_fragment(actB, rb, cb, lane, d);
         }
     });
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
         for (int cb = 0; cb < kCB; cb++) {
             f32x4 d;
 #pragma unroll
-            for (int q = 0; q < 4; q++) d[q] = (acc1[j][cb][q] + kLoInv * acc2[j][cb][q]) * kUnscale * c1[j][cb][q];
+            for (int q = 0; q < 4; q++) d[q] = fmaf(kLoInv, acc2[j][cb][q], acc1[j][cb][q]) * c1[j][cb][q];      // d1 / 16
             f16x4 h, l;
             split4(d, h, l);
             _Float16* p = d1 + ((size_t)(rb >> 1) * kCB + cb) * 2 * kFrag + lane * 8 + 4 * (rb & 1);
