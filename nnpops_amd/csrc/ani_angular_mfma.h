@@ -284,7 +284,11 @@ struct MfmaForward {
             sync();
             for (int q = tid; q < pieces; q += NT) {
                 const float4 v = reinterpret_cast<const float4*>(rowbuf)[q];
+#ifdef NNPOPS_PROTOTYPE_AEV_FROM_LDS      // tools/proto_fused_aev.py: the AEV rows stay in LDS (one token store per atom keeps the work alive)
+                if (q == 0 && v.x == 12345.678f) store_row16(out, mfma_f4{v.x, v.y, v.z, v.w}, 0);
+#else
                 store_row16(out + 4 * q, mfma_f4{v.x, v.y, v.z, v.w}, (vec_ok >> 1) & 3);
+#endif
             }
         } else {
 #pragma unroll

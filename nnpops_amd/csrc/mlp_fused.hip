@@ -224,7 +224,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
         auto fetch_x = [&](int s) {
             const int k = 32 * s + piece * 4;
             const bool in = k < g.F;                         // (F is a multiple of 8: all four or none)
+#ifdef NNPOPS_PROTOTYPE_AEV_FROM_LDS      // tools/proto_fused_aev.py: what the kernel would cost if the AEV never came from memory
+            const float4 v = make_float4(0.25f, 0.5f, 0.75f, 1.0f);
+#else
             const float4 v = *reinterpret_cast<const float4*>(xsrc + (in ? 32 * s : -piece * 4));
+#endif
             const float z = in ? 1.0f : 0.0f;
             const float zs = z * kScale;
             xv = f32x4{v.x * zs, v.y * zs, v.z * zs, v.w * zs};

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Upper bound on what fusion (A) of SURVEY s8f rank 1 -- AEV tiles handed to the first network layer through LDS, never
+through HBM -- could gain on BASELINE config 2 ("keep the prototype's numbers in profiles/").
+
+Builds a second copy of libnnpops_hip.so under /tmp with -DNNPOPS_PROTOTYPE_AEV_FROM_LDS: the angular forward assembles its
+rows in LDS as always but does not store them, and the fused networks take their layer-0 operand from registers instead of
+reading the [N, 1008] array.  Both kernels then do ALL of their arithmetic, LDS traffic and weight streaming and NONE of the
+AEV round trip; the difference to the product library is everything fusion (A) could remove (it would still have to pay for
+species-sorted tiles, eight-fold recomputation or a producer/consumer hand-over -- none of which is charged here).
+
+    python tools/proto_fused_aev.py          # on the GPU box (needs hipcc); prints one JSON line
+"""
+import ctypes as C
+import glob
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build_variant(workdir):
+    from nnpops_amd import build as hb
+    objs = []
+    procs = []
+    for src in hb._sources():
+        obj = os.path.join(workdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                                       f'-DNNPOPS_SOURCE_HASH="{hb.source_hash()}"', "-DNNPOPS_PROTOTYPE_AEV_FROM_LDS=1", "-c", src, "-o", obj]))
+    for p in procs:
+        assert p.wait() == 0
+    lib = os.path.join(workdir, "libnnpops_hip.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
+def measure(lib_path):
+    """AEV forward (kernel event times) and the fused networks (HIP events) of config 2 with the given library."""
+    code = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from nnpops_amd import capi, workloads
+capi.LIB_PATH = %r
+from nnpops_amd.capi import AniSymmetryFunctions, FusedMLP
+sys.path.insert(0, %r)
+pos, species, box = workloads.water_box(667, seed=1)
+rf, af = workloads.ani2x_functions()
+dev = torch.device("cuda:0")
+sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+aev = torch.zeros((len(species), 1008), device=dev)
+radial, angular = aev[:, :112], aev[:, 112:]
+import ctypes as C
+def aev_forward():
+    capi._check(capi.lib().nnpops_ani_set_stream(sym._h, capi._stream_ptr(dev)))
+    capi._check(capi.lib().nnpops_ani_compute_strided(sym._h, capi._ptr(tpos), capi._ptr(tbox), capi._ptr(aev), 1008, C.c_void_p(aev.data_ptr() + 448), 1008))
+sym.compute(tpos, tbox)          # calibrates capacities
+def t(fn, reps=300):
+    for _ in range(30): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return 1e3 * a.elapsed_time(b) / reps
+g = torch.Generator().manual_seed(0)
+def nets(w, s):
+    r = lambda *sh, fan: (torch.randn(sh, generator=g) / np.sqrt(fan)).float().cuda()
+    h1, h2, h3 = w
+    return dict(w0=r(8, h1, 1008, fan=1008), b0=r(8, h1, fan=100), w2=r(8, h2, h1, fan=h1), b2=r(8, h2, fan=100), w4=r(8, h3, h2, fan=h2),
+                b4=r(8, h3, fan=100), w6=r(8, h3, fan=h3), b6=r(8, fan=100))
+sp = torch.tensor(species)
+kinds = []
+for s, w in ((0, (256, 192, 160)), (3, (192, 160, 128))):
+    kd = nets(w, s); kd["atoms"] = torch.nonzero(sp == s).flatten().to(torch.int32).cuda(); kinds.append(kd)
+mlp = FusedMLP(kinds, 1008)
+aev_forward()
+out = {"aev_forward_us": t(aev_forward), "networks_forward_us": t(lambda: mlp.forward(aev, with_gradient=True))}
+print(json.dumps(out))
+''' % (ROOT, lib_path, ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def main():
+    from nnpops_amd import capi
+    product = measure(capi.LIB_PATH)
+    with tempfile.TemporaryDirectory(prefix="nnpops_proto_") as wd:
+        proto = measure(build_variant(wd))
+    saved = {k: round(product[k] - proto[k], 2) for k in product}
+    print(json.dumps({"workload": "BASELINE config 2: 2001-atom water box, AEV forward (fused build + forward) and the fused networks' forward launch",
+                      "product_us": {k: round(v, 2) for k, v in product.items()}, "aev_never_in_memory_us": {k: round(v, 2) for k, v in proto.items()},
+                      "upper_bound_of_fusion_A_us": saved, "total_upper_bound_us": round(sum(saved.values()), 2)}))
+
+
+if __name__ == "__main__":
+    main()
