@@ -16,9 +16,11 @@ def main():
     dur = {}
     for db in dbs:
         c = sqlite3.connect(db)
-        rows = c.execute("select k.name, p.counter_name, sum(p.counter_value), count(distinct k.dispatch_id), avg(k.duration) "
-                         "from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
-                         "where k.name like ? group by k.name, p.counter_name", (f"%{flt}%",)).fetchall()
+        rows = []
+        for one in flt.split(","):                               # --filter a,b: kernels whose name contains a OR b
+            rows += c.execute("select k.name, p.counter_name, sum(p.counter_value), count(distinct k.dispatch_id), avg(k.duration) "
+                              "from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
+                              "where k.name like ? group by k.name, p.counter_name", (f"%{one}%",)).fetchall()
         for name, counter, total, ndisp, d in rows:
             key = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("nnpops::", "")
             key = key.split("(")[0][:48]

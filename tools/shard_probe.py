@@ -20,7 +20,7 @@ lo, hi = shard_molecules(sizes, world)[0]
 sh = bench.ConformerShard(sizes, lo, hi, 0)
 buf = torch.empty((sh.n, 3), device="cuda")
 step = lambda: sh.step(buf)
-t_eager = bench._time_steps(step, 300, 30)
+t_eager = bench._time_steps(step, 300, 30, repeats=1)
 sh.sym.enable_timing(True)
 for _ in range(50):
     step()
@@ -34,6 +34,6 @@ torch.cuda.current_stream().wait_stream(side)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     step()
-t_graph = bench._time_steps(g.replay, 300, 30)
+t_graph = bench._time_steps(g.replay, 300, 30, repeats=1)
 print(f"{hi - lo} conformers, {sh.n} atoms: eager {1e3 * t_eager:.4f} ms, graph {1e3 * t_graph:.4f} ms; kernels (us, event brackets included): "
       + ", ".join(f"{k} {v:.1f}" for k, v in kt.items()), "max row / angular:", sh.sym.neighbor_stats())
