@@ -684,6 +684,22 @@ def run_torchani(args, R):
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(energy).all()) and bool(torch.isfinite(tpos.grad).all())
+    # the same eager loop without the per-call capacity check of the AEV holder (one host round trip per step): what a production
+    # loop at known density runs (set_check_interval, cf. check_errors of getNeighborPairs); one checked step follows
+    no_check_ms = None
+    if not args.graph:
+        opt.aev_computer.set_check_interval(0)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        no_check_ms = 1e3 * (time.perf_counter() - t1) / steps
+        opt.aev_computer.set_check_interval(1)
+        step()                                               # (raises if a neighbour buffer had overflowed)
+        torch.cuda.synchronize()
     # NN flops: 2 * models * sum over atoms of the MACs of its network; backward to the
     # inputs costs the same again
     macs = {s: 1008 * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}
@@ -706,6 +722,7 @@ def run_torchani(args, R):
                                + ("AEV + networks as one autograd node (8 launches per energy+forces step)" if one_node else "four-module composition")
                                + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
                    "nn_weight_bytes": nn_weight_bytes, "nn_layout": args.nn_layout, "one_autograd_node": one_node},
+        "ms_per_step_without_capacity_check": (round(no_check_ms, 4) if no_check_ms is not None else None),
         "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",
                      "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,

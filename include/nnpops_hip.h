@@ -280,6 +280,9 @@ int64_t nnpops_mlp_d1_halves(int num_atoms, int num_members, int h1);
 int nnpops_mlp_pack(void* stream, int rows, int cols, const float* w, long ldw, int transpose, int permute, void* out);
 int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gradient);
 int nnpops_mlp_input_grad(void* stream, const nnpops_mlp_frame* frame);
+/* out[0] = scale * sum(energies[0 .. count)) in double precision and a fixed order: the sum over atoms and the mean over
+ * members of BatchedNN.py:109 (scale = 1 / num_members) in one small launch.  Device pointers. */
+int nnpops_mlp_energy_mean(void* stream, const float* energies, int64_t count, float scale, float* out);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,7 @@ SIGNATURES = {
     "nnpops_mlp_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "nnpops_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "nnpops_mlp_input_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nnpops_mlp_energy_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "nnpops_neighbor_pairs_workspace_bytes": (C.c_int64, [C.c_int]),
     "nnpops_neighbor_pairs_forward": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -549,6 +550,12 @@ class FusedMLP:
         self.frame.x, self.frame.ldx = x.data_ptr(), x.shape[1]
         _check(lib().nnpops_mlp_forward(_stream_ptr(x.device), C.byref(self.frame), int(with_gradient)))
         return self.energies
+
+    def energy_mean(self, scale=1.0):
+        """scale * sum of the energies of the last forward(): one launch, double accumulation, fixed order."""
+        out = torch.empty((1,), dtype=torch.float32, device=self.energies.device)
+        _check(lib().nnpops_mlp_energy_mean(_stream_ptr(out.device), _ptr(self.energies), self.energies.numel(), float(scale), _ptr(out)))
+        return out
 
     def input_grad(self, like, upstream=None, out=None, scale=1.0):
         """dE/dx of the summed energies of the last forward(with_gradient=True): [atoms][F] float32 (rows of atoms that

@@ -475,6 +475,22 @@ __global__ __launch_bounds__(256) void mlp_pack(int rows, int cols, const float*
     }
 }
 
+// out[0] = scale * sum of v[0 .. n): one workgroup, double accumulation, fixed order (bitwise reproducible)
+__global__ __launch_bounds__(1024) void mlp_energy_mean(const float* __restrict__ v, long n, float scale, float* __restrict__ out) {
+    __shared__ double red[1024 / 64];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)v[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int w = 0; w < 1024 / 64; w++) e += red[w];
+        out[0] = (float)(e * (double)scale);
+    }
+}
+
 int check_and_fill(const nnpops_mlp_frame* fr, MlpArgs& g, bool grad, int blocks_per_tile_grad, int* total_blocks) {
     NNPOPS_REQUIRE(fr != nullptr, "NULL frame descriptor");
     NNPOPS_REQUIRE(fr->num_kinds >= 1 && fr->num_kinds <= NNPOPS_MLP_MAX_KINDS, "1..%d kinds per launch (got %d)", NNPOPS_MLP_MAX_KINDS, fr->num_kinds);
@@ -546,6 +562,13 @@ int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gra
     }
     if (with_gradient) hipLaunchKernelGGL(mlp_forward<true>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(mlp_forward<false>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+int nnpops_mlp_energy_mean(void* stream, const float* energies, int64_t count, float scale, float* out) {
+    NNPOPS_REQUIRE(energies && out && count > 0, "NULL device pointer or empty sum");
+    hipLaunchKernelGGL(mlp_energy_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, energies, (long)count, scale, out);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }

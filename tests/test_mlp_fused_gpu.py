@@ -55,9 +55,11 @@ def _run(kinds_host, x_host, features):
     assert float((e - e_ref).abs().max()) <= 1e-5 * float(e_ref.abs().max()), float((e - e_ref).abs().max())
     assert abs(float(e.sum() - e_ref.sum())) <= 1e-5 * float(e_ref.abs().sum())
     assert float((dx - dx_ref).abs().max()) <= 1e-4 * float(dx_ref.abs().max()), float((dx - dx_ref).abs().max() / dx_ref.abs().max())
-    # energy-only launch: same energies
+    # energy-only launch: same energies; the mean over members in one launch
     e2 = mlp.forward(x, with_gradient=False).cpu().double()
     assert torch.equal(e2, e)
+    mean = float(mlp.energy_mean(1.0 / e.shape[1]).cpu())
+    assert abs(mean - float(e_ref.sum()) / e.shape[1]) <= 1e-5 * float(e_ref.abs().sum()) / e.shape[1]
     return e, dx
 
 
