@@ -553,13 +553,9 @@ int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gra
     int rc = check_and_fill(frame, g, with_gradient != 0, frame ? frame->num_members : 1, &blocks);
     if (rc != NNPOPS_OK) return rc;
     if (blocks == 0) return NNPOPS_OK;
-    static bool configured = false;
-    const size_t lds = 2 * kStageBytes + 2 * kActBytes;      // 144 KiB
-    if (!configured) {
-        NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    const size_t lds = 2 * kStageBytes + 2 * kActBytes;      // 144 KiB: above the default limit of dynamic LDS, raised per device
+    if (with_gradient) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (with_gradient) hipLaunchKernelGGL(mlp_forward<true>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(mlp_forward<false>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
     NNPOPS_HIP_TRY(hipGetLastError());
