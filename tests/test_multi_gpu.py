@@ -171,3 +171,28 @@ def test_eight_rank_conformer_rehearsal_on_one_device():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["conformers"] == 1024 and 7000 < line["config"]["atoms_this_rank"] < 8400
+
+
+def test_default_bench_line_carries_measured_counters():
+    """`python bench.py` (shortened): ONE JSON line whose roofline carries the HBM traffic and the vector-issue floor of every
+    headline kernel, both measured in the run by the rocprofv3 counter passes bench.py starts on itself, and a step that adds up."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "8", "--settle", "50", "--no-side",
+                          "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["side_errors"] == {} and line["dtype"] == "f32"
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and roof["traffic_source"]
+    for name, k in roof["per_kernel"].items():
+        assert k["traffic"] is not None and k["traffic"] >= 0.9 * k["algorithmic_bytes_per_launch"], (name, k)
+        assert 0.05 < k["valu"]["frac"] <= 1.0 and k["valu"]["valu_per_atom"] > 100, (name, k)
+    assert roof["step"]["traffic"] == sum(k["traffic"] for k in roof["per_kernel"].values())
