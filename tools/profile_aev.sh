@@ -4,8 +4,8 @@ set -x
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof_kt -o kt --output-format rocpd -- python $R/bench.py --no-side --no-cpu-baseline > $O/${TAG}_bench_under_rocprofv3.json 2> $O/${TAG}_bench_under_rocprofv3.err
-P="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side"
+rocprofv3 --kernel-trace --stats -d $O/prof_kt -o kt --output-format rocpd -- python $R/bench.py --no-side --no-cpu-baseline --no-pmc > $O/${TAG}_bench_under_rocprofv3.json 2> $O/${TAG}_bench_under_rocprofv3.err
+P="python $R/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-side --no-pmc"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/prof_sq -o sq --output-format rocpd -- $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/prof_lds -o lds --output-format rocpd -- $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch -o fetch --output-format rocpd -- $P > /dev/null 2>&1
