@@ -177,7 +177,7 @@ def _pmc_pass(counters, atoms, workdir, tag):
            "--no-cpu-baseline", "--no-pmc"]
     env = dict(os.environ, TMPDIR=workdir)
     try:
-        subprocess.run(cmd, cwd=workdir, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+        subprocess.run(cmd, cwd=workdir, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60, check=True)
         dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
         if not dbs:
             return None
