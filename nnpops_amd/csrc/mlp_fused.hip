@@ -220,20 +220,23 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
         const int srow = g.rows[kd.first + min(r0 + sa, kd.n - 1)];
         const float* xsrc = g.x + (size_t)srow * g.ldx + piece * 4;
         char* xdst = xstage + ((sa >> 4) * 2) * 1024 + ((sa & 15) + 16 * (piece >> 1)) * 16 + 8 * (piece & 1);
-        f32x4 xv;
+        // (the loaded columns are NOT touched before they are staged one step later: an instruction that consumes them right
+        //  after the load makes the compiler wait for EVERY outstanding load there -- s_waitcnt vmcnt(0) after each barrier,
+        //  which drained the weight fragments requested three steps ahead with it)
+        float4 xraw;
+        float xscale;
         auto fetch_x = [&](int s) {
             const int k = 32 * s + piece * 4;
             const bool in = k < g.F;                         // (F is a multiple of 8: all four or none)
 #ifdef NNPOPS_PROTOTYPE_AEV_FROM_LDS      // tools/proto_fused_aev.py: what the kernel would cost if the AEV never came from memory
-            const float4 v = make_float4(0.25f, 0.5f, 0.75f, 1.0f);
+            xraw = make_float4(0.25f, 0.5f, 0.75f, 1.0f);
 #else
-            const float4 v = *reinterpret_cast<const float4*>(xsrc + (in ? 32 * s : -piece * 4));
+            xraw = *reinterpret_cast<const float4*>(xsrc + (in ? 32 * s : -piece * 4));
 #endif
-            const float z = in ? 1.0f : 0.0f;
-            const float zs = z * kScale;
-            xv = f32x4{v.x * zs, v.y * zs, v.z * zs, v.w * zs};
+            xscale = in ? kScale : 0.0f;
         };
         auto stage_x = [&](int stage) {
+            const f32x4 xv = {xraw.x * xscale, xraw.y * xscale, xraw.z * xscale, xraw.w * xscale};
             f16x4 h, l;
             split4(xv, h, l);
             *reinterpret_cast<f16x4*>(xdst + stage * kStageBytes) = h;
