@@ -195,4 +195,5 @@ def test_default_bench_line_carries_measured_counters():
     for name, k in roof["per_kernel"].items():
         assert k["traffic"] is not None and k["traffic"] >= 0.9 * k["algorithmic_bytes_per_launch"], (name, k)
         assert 0.05 < k["valu"]["frac"] <= 1.0 and k["valu"]["valu_per_atom"] > 100, (name, k)
-    assert roof["step"]["traffic"] == sum(k["traffic"] for k in roof["per_kernel"].values())
+    four = sum(k["traffic"] for k in roof["per_kernel"].values())            # (the step also counts the two cell-grid kernels)
+    assert four <= roof["step"]["traffic"] <= four + 16 * 2 ** 20
