@@ -688,7 +688,7 @@ def run_torchani(args, R):
     # loop at known density runs (set_check_interval, cf. check_errors of getNeighborPairs); one checked step follows
     no_check_ms = None
     if not args.graph:
-        opt.aev_computer.set_check_interval(0)
+        (opt if one_node else opt.aev_computer).set_check_interval(0)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -697,7 +697,7 @@ def run_torchani(args, R):
             step()
         torch.cuda.synchronize()
         no_check_ms = 1e3 * (time.perf_counter() - t1) / steps
-        opt.aev_computer.set_check_interval(1)
+        (opt if one_node else opt.aev_computer).set_check_interval(1)
         step()                                               # (raises if a neighbour buffer had overflowed)
         torch.cuda.synchronize()
     # NN flops: 2 * models * sum over atoms of the MACs of its network; backward to the

@@ -261,6 +261,10 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
                                                    self.mlp_planes, self.mlp_floats)
         return SpeciesEnergies(species, total / self.num_models)
 
+    def set_check_interval(self, interval: int) -> None:
+        """(inside OptimizedTorchANI) how often the AEV holder behind fused_energy() verifies its neighbour capacities."""
+        self.holder.set_check_interval(interval)
+
     def fused_energy(self, positions: Tensor, cell: Optional[Tensor]) -> Tensor:
         """AEV + networks of the whole frame as one autograd node (only inside OptimizedTorchANI, which hands over the AEV
         holder): positions [N, 3] -> ensemble-mean energy [1]."""
@@ -360,3 +364,6 @@ class TorchANIBatchedNN(nn.ModuleList):
 
     def fused_energy(self, positions: Tensor, cell: Optional[Tensor]) -> Tensor:
         return self[0].fused_energy(positions, cell)
+
+    def set_check_interval(self, interval: int) -> None:
+        self[0].set_check_interval(interval)

@@ -43,6 +43,14 @@ class FusedOptimizedTorchANI(OptimizedTorchANI):
     multiplication -- instead of the ~45 launches the composition records.  Not constructed directly: ``OptimizedTorchANI(...)``
     turns into it.  Second derivatives are refused (use ``fused_step=False``)."""
 
+    @torch.jit.export
+    def set_check_interval(self, interval: int) -> None:
+        """Extension (cf. TorchANISymmetryFunctions.set_check_interval): verify the neighbour-buffer capacities only on every
+        ``interval``-th call (0: only on the first).  Sets it on the AEV module's holder and on the one the fused step drives
+        (the same object until the module has been through torch.jit.save / load, two copies after)."""
+        self.aev_computer.set_check_interval(interval)
+        self.neural_networks.set_check_interval(interval)
+
     def forward(self, species_coordinates: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
                 pbc: Optional[Tensor] = None) -> SpeciesEnergies:
         converted = self.species_converter(species_coordinates)
