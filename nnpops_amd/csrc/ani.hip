@@ -97,6 +97,7 @@ struct nnpops_ani {
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
     int* d_work_order = nullptr;    // [N] atoms by DECREASING number of angular neighbours (check() builds it): the schedule of the
     bool work_order_valid = false;  //     angular kernels -- heaviest atoms first, the light ones fill the tail
+    int cell_atoms = 1800;          // systems of at least this many atoms search their neighbours through the cell grid ($NNPOPS_ANI_CELL_ATOMS)
     int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     int timing_every = 1;           // ... on every timing_every-th launch
@@ -495,6 +496,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
         if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("NNPOPS_ANI_LPT")) h->lpt = std::atoi(e);
+        if (const char* e = std::getenv("NNPOPS_ANI_CELL_ATOMS")) h->cell_atoms = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
@@ -666,7 +668,9 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
     const int wpg_b = waves_per_group(lds_bw);
     const size_t lds_b = (size_t)lds_bw * wpg_b;
     const dim3 ablock(64 * wpg_b);
-    const bool use_cells = !h->d_segment && (h->algorithm == 2 || (h->algorithm == 0 && N >= 1024 && !h->cells_disabled));
+    // (below ~1 800 atoms scanning every atom -- 28 batches of 64 -- costs less than the two launches of the grid build:
+    //  1 500 atoms 38.8 -> 34.4 us per fwd+bwd step, 2 001 atoms equal, 3 000 atoms 45 vs 52 us)
+    const bool use_cells = !h->d_segment && (h->algorithm == 2 || (h->algorithm == 0 && N >= h->cell_atoms && !h->cells_disabled));
     h->last_used_cells = use_cells;
     if (use_cells) {
         KernelTimer timer(h, NNPOPS_ANI_K_CELL_GRID);

@@ -110,9 +110,11 @@ def test_neighbor_algorithms_agree_with_oracle(algorithm, kind):
     _run_case(7, 5.1, 3.5, species, rf, af, pos, box, algorithm=algorithm)
 
 
-def test_cell_grid_falls_back_when_box_too_small():
-    """N >= 1024 selects the cell grid, but a 14.6 A box has < 3 cells per axis at Rcr 5.1: the
-    handle must notice on the device, switch to the all-pairs search and still be right (also grows the rows)."""
+def test_cell_grid_falls_back_when_box_too_small(monkeypatch):
+    """A system large enough for the cell grid (the threshold is lowered to this one's size), but a 14.6 A box has < 3 cells
+    per axis at Rcr 5.1: the handle must notice on the device, switch to the all-pairs search and still be right (also grows
+    the rows)."""
+    monkeypatch.setenv("NNPOPS_ANI_CELL_ATOMS", "1024")
     rf, af = workloads.ani2x_functions()
     pos, species, box = workloads.random_box(1100, density=0.35, seed=12, min_dist=0.5)
     assert box[0, 0] < 3 * 5.1
@@ -225,6 +227,7 @@ def test_fused_build_and_forward(monkeypatch, kind):
     of system, including the all-pairs search (vacuum) and a box too small for the cell stencil (the handle falls back
     and recomputes)."""
     monkeypatch.setenv("NNPOPS_ANI_FUSE", "1")
+    monkeypatch.setenv("NNPOPS_ANI_CELL_ATOMS", "1024")        # (the periodic cases below are meant to take the cell grid)
     rf, af = workloads.ani2x_functions()
     box = None
     if kind == "water":
@@ -259,6 +262,7 @@ def test_kernel_timing_brackets_and_stride(monkeypatch):
     angular forward: a system this small would otherwise take the fused kernel, which is timed as the build.)"""
     from nnpops_amd.capi import AniSymmetryFunctions
     monkeypatch.setenv("NNPOPS_ANI_FUSE", "0")
+    monkeypatch.setenv("NNPOPS_ANI_CELL_ATOMS", "1024")        # (the cell-grid kernels are among the bracketed ones)
     rf, af = workloads.ani2x_functions()
     pos, species, box = workloads.random_box(1500, seed=71)
     dev = torch.device("cuda:0")
