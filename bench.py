@@ -364,7 +364,18 @@ def run_aev(args, R):
     if not args.warmup:
         step()
     kern_all = {k: (1e-3 * ms / max(c, 1)) for k, (ms, c) in breakdown.items()}
-    dominant = max(ROOFLINE_KERNELS, key=lambda k: kern_all.get(k, 0.0))
+    # ALGORITHMIC bytes per launch = SURVEY.md s8(d) bytes only (what an ideal implementation must move): inputs read
+    # once, outputs written once, nothing of this implementation's intermediate arrays.
+    na_w, nr_w = sym.angular_width, sym.radial_width
+    alg = {"angular_forward": n * 16 + n * na_w * 4,          # positions+species in, the 896-float row out
+           "angular_backward": n * na_w * 4 + n * 12,         # the upstream row in, forces out
+           "neighbors": n * 16 + n * nr_w * 4,                # positions+species in, the radial AEV out (it is fused here)
+           "radial_backward": n * nr_w * 4 + n * 12}          # the radial gradient row in, forces out
+    # The HBM roofline line is about the kernel that has the most bytes to move (the angular forward pass: 44 % of the step's
+    # algorithmic bytes; the kernel the round-1 and round-2 lines were about).  The LONGEST kernel of the step is named beside it
+    # (`longest_kernel`): since round 3 that is the neighbour build, which moves an eighth of those bytes.
+    dominant = max(ROOFLINE_KERNELS, key=lambda k: alg[k])
+    longest = max(ROOFLINE_KERNELS, key=lambda k: kern_all.get(k, 0.0))
     R.barrier()
     event_overhead = sym.timing_overhead()                   # seconds reported for an EMPTY event bracket on this stream
     sym.enable_timing(True, only=[dominant], every=8)
@@ -393,13 +404,6 @@ def run_aev(args, R):
     kern = {k: max(v - event_overhead, 0.0) if v > 0 else 0.0 for k, v in kern_all.items()}   # s per launch (warm-up pass)
     ms_dom, c_dom = timing[dominant]
     kern[dominant] = max(1e-3 * ms_dom / max(c_dom, 1) - event_overhead, 1e-9)  # ... the dominant one from the timed region
-    # ALGORITHMIC bytes per launch = SURVEY.md s8(d) bytes only (what an ideal implementation must move): inputs read
-    # once, outputs written once, nothing of this implementation's intermediate arrays.
-    na_w, nr_w = sym.angular_width, sym.radial_width
-    alg = {"angular_forward": n * 16 + n * na_w * 4,          # positions+species in, the 896-float row out
-           "angular_backward": n * na_w * 4 + n * 12,         # the upstream row in, forces out
-           "neighbors": n * 16 + n * nr_w * 4,                # positions+species in, the radial AEV out (it is fused here)
-           "radial_backward": n * nr_w * 4 + n * 12}          # the radial gradient row in, forces out
     step_bytes = n * (16 + 2 * (na_w + nr_w) * 4 + 12)        # N * (16 + 2 * 4032 + 12)
     # HBM traffic and instruction counts of these kernels, measured now (rocprofv3 on three steps of this same workload; the
     # counters come from their own passes, the TIMES above from the un-profiled run)
@@ -438,6 +442,7 @@ def run_aev(args, R):
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "valu": dom["valu"],
+                     "longest_kernel": roof(longest),
                      "limiter": "not HBM: the per-atom kernels are bound by vector-instruction issue while the chip is full and by "
                                 "latency in the last occupancy round (DESIGN.md s3/s6: 390-1160 VALU instructions per atom per "
                                 "kernel, 1.2-2.8 rounds of resident waves at 10 000 atoms)",

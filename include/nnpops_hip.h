@@ -283,6 +283,14 @@ int nnpops_mlp_input_grad(void* stream, const nnpops_mlp_frame* frame);
 /* out[0] = scale * sum(energies[0 .. count)) in double precision and a fixed order: the sum over atoms and the mean over
  * members of BatchedNN.py:109 (scale = 1 / num_members) in one small launch.  Device pointers. */
 int nnpops_mlp_energy_mean(void* stream, const float* energies, int64_t count, float scale, float* out);
+/* The same sum, promoted to double and shifted by the molecule's self energy: out[0] = (double)(float)(scale * sum) + shift[0] --
+ * the `energies + self_energies` of the reference's EnergyShifter (pytorch/EnergyShifter.py:52) without a launch of its own.
+ * `shift` and `out` are device doubles. */
+int nnpops_mlp_energy_mean_shifted(void* stream, const float* energies, int64_t count, float scale, const double* shift, double* out);
+/* out[i] = in[i] * (float)factor[0] for i < count; `factor` is a DEVICE scalar, a double when factor_is_double != 0 and a float
+ * otherwise.  The backward of the one-node OptimizedTorchANI step (pytorch/OptimizedTorchANI.py:49-52): forces kept by the forward
+ * pass times the gradient autograd hands in, in one launch. */
+int nnpops_scale_by_scalar(void* stream, const float* in, int64_t count, const void* factor, int factor_is_double, float* out);
 
 #ifdef __cplusplus
 }

@@ -265,11 +265,12 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         """(inside OptimizedTorchANI) how often the AEV holder behind fused_energy() verifies its neighbour capacities."""
         self.holder.set_check_interval(interval)
 
-    def fused_energy(self, positions: Tensor, cell: Optional[Tensor]) -> Tensor:
+    def fused_energy(self, positions: Tensor, cell: Optional[Tensor], shift: Optional[Tensor] = None) -> Tensor:
         """AEV + networks of the whole frame as one autograd node (only inside OptimizedTorchANI, which hands over the AEV
-        holder): positions [N, 3] -> ensemble-mean energy [1]."""
+        holder): positions [N, 3] or [1, N, 3] -> ensemble-mean energy [1]; with ``shift`` (the molecule's self energy, one
+        float64 on the device) the energy comes back in float64, shifted as the reference's EnergyShifter does it."""
         return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
-                                                           self.num_models, self.mlp_planes, self.mlp_floats)
+                                                           self.num_models, self.mlp_planes, self.mlp_floats, shift)
 
 
 class _SplitGemmSpeciesNN(_SpeciesGroupedNN):
@@ -362,8 +363,8 @@ class TorchANIBatchedNN(nn.ModuleList):
     def forward(self, species_aev: Tuple[Tensor, Tensor]) -> SpeciesEnergies:
         return self[0].forward(species_aev)
 
-    def fused_energy(self, positions: Tensor, cell: Optional[Tensor]) -> Tensor:
-        return self[0].fused_energy(positions, cell)
+    def fused_energy(self, positions: Tensor, cell: Optional[Tensor], shift: Optional[Tensor] = None) -> Tensor:
+        return self[0].fused_energy(positions, cell, shift)
 
     def set_check_interval(self, interval: int) -> None:
         self[0].set_check_interval(interval)

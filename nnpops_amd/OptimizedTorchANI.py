@@ -56,5 +56,9 @@ class FusedOptimizedTorchANI(OptimizedTorchANI):
         converted = self.species_converter(species_coordinates)
         species, positions = converted.species, converted.coordinates
         self.aev_computer.check_arguments(species, cell, pbc)
-        energies = self.neural_networks.fused_energy(positions[0], cell)
-        return self.energy_shifter((species, energies))
+        # (positions go in as [1, N, 3] and the self-energy shift of EnergyShifter.py:52 is added by the kernel that takes the
+        #  ensemble mean: no select / add / type-promotion kernels around the node, forward or backward)
+        shift = self.energy_shifter.self_energies
+        if shift.dtype == torch.float64 and shift.numel() == 1 and shift.device == positions.device:
+            return SpeciesEnergies(species, self.neural_networks.fused_energy(positions, cell, shift))
+        return self.energy_shifter((species, self.neural_networks.fused_energy(positions, cell)))

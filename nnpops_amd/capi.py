@@ -67,6 +67,8 @@ SIGNATURES = {
     "nnpops_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "nnpops_mlp_input_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nnpops_mlp_energy_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "nnpops_mlp_energy_mean_shifted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "nnpops_scale_by_scalar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "nnpops_neighbor_pairs_workspace_bytes": (C.c_int64, [C.c_int]),
     "nnpops_neighbor_pairs_forward": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -557,6 +559,15 @@ class FusedMLP:
         _check(lib().nnpops_mlp_energy_mean(_stream_ptr(out.device), _ptr(self.energies), self.energies.numel(), float(scale), _ptr(out)))
         return out
 
+    def energy_mean_shifted(self, shift, scale=1.0):
+        """(double)(float)(scale * sum) + shift[0]: the mean of energy_mean() promoted and shifted like the reference's EnergyShifter
+        (``energies + self_energies``); ``shift`` a float64 device tensor, the result float64 [1]."""
+        assert shift.dtype == torch.float64 and shift.is_cuda and shift.numel() >= 1
+        out = torch.empty((1,), dtype=torch.float64, device=self.energies.device)
+        _check(lib().nnpops_mlp_energy_mean_shifted(_stream_ptr(out.device), _ptr(self.energies), self.energies.numel(), float(scale),
+                                                    _ptr(shift), _ptr(out)))
+        return out
+
     def input_grad(self, like, upstream=None, out=None, scale=1.0):
         """dE/dx of the summed energies of the last forward(with_gradient=True): [atoms][F] float32 (rows of atoms that
         belong to no kind are left as they are)."""
@@ -567,3 +578,14 @@ class FusedMLP:
         self.frame.dx_scale = float(scale)
         _check(lib().nnpops_mlp_input_grad(_stream_ptr(out.device), C.byref(self.frame)))
         return out
+
+
+def scale_by_scalar(values, factor):
+    """values (float32 device tensor) * float(factor[0]), ``factor`` a float32 or float64 DEVICE scalar: one launch
+    (nnpops_scale_by_scalar -- the backward of the one-node OptimizedTorchANI step)."""
+    values = _dev_f32(values, "values")
+    assert factor.is_cuda and factor.dtype in (torch.float32, torch.float64) and factor.numel() >= 1
+    out = torch.empty_like(values)
+    _check(lib().nnpops_scale_by_scalar(_stream_ptr(values.device), _ptr(values), values.numel(), _ptr(factor),
+                                        int(factor.dtype == torch.float64), _ptr(out)))
+    return out

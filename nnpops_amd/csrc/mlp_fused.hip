@@ -479,7 +479,10 @@ __global__ __launch_bounds__(256) void mlp_pack(int rows, int cols, const float*
 }
 
 // out[0] = scale * sum of v[0 .. n): one workgroup, double accumulation, fixed order (bitwise reproducible)
-__global__ __launch_bounds__(1024) void mlp_energy_mean(const float* __restrict__ v, long n, float scale, float* __restrict__ out) {
+// (shift != NULL: out is a double and gets (double)(float)mean + shift[0] -- the float energy promoted and shifted exactly as
+//  `energies + self_energies` does it in the reference's EnergyShifter.py:52)
+__global__ __launch_bounds__(1024) void mlp_energy_mean(const float* __restrict__ v, long n, float scale, float* __restrict__ out,
+                                                        const double* __restrict__ shift, double* __restrict__ out_shifted) {
     __shared__ double red[1024 / 64];
     double acc = 0.0;
     for (long i = threadIdx.x; i < n; i += 1024) acc += (double)v[i];
@@ -490,8 +493,18 @@ __global__ __launch_bounds__(1024) void mlp_energy_mean(const float* __restrict_
     if (threadIdx.x == 0) {
         double e = 0.0;
         for (int w = 0; w < 1024 / 64; w++) e += red[w];
-        out[0] = (float)(e * (double)scale);
+        const float mean = (float)(e * (double)scale);
+        if (shift) out_shifted[0] = (double)mean + shift[0];
+        else out[0] = mean;
     }
+}
+
+// out[i] = in[i] * (float)factor[0], the factor a device scalar of either precision (the chain-rule factor autograd hands to the
+// backward of the energy node: a double once the energy has been shifted)
+template <typename F>
+__global__ __launch_bounds__(256) void scale_by_scalar(const float* __restrict__ in, long n, const F* __restrict__ factor, float* __restrict__ out) {
+    const float f = (float)factor[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = in[i] * f;
 }
 
 int check_and_fill(const nnpops_mlp_frame* fr, MlpArgs& g, bool grad, int blocks_per_tile_grad, int* total_blocks) {
@@ -567,7 +580,28 @@ int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gra
 
 int nnpops_mlp_energy_mean(void* stream, const float* energies, int64_t count, float scale, float* out) {
     NNPOPS_REQUIRE(energies && out && count > 0, "NULL device pointer or empty sum");
-    hipLaunchKernelGGL(mlp_energy_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, energies, (long)count, scale, out);
+    hipLaunchKernelGGL(mlp_energy_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, energies, (long)count, scale, out,
+                       (const double*)nullptr, (double*)nullptr);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+int nnpops_mlp_energy_mean_shifted(void* stream, const float* energies, int64_t count, float scale, const double* shift, double* out) {
+    NNPOPS_REQUIRE(energies && out && shift && count > 0, "NULL device pointer or empty sum");
+    hipLaunchKernelGGL(mlp_energy_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, energies, (long)count, scale, (float*)nullptr, shift,
+                       out);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+int nnpops_scale_by_scalar(void* stream, const float* in, int64_t count, const void* factor, int factor_is_double, float* out) {
+    NNPOPS_REQUIRE(in && out && factor && count >= 0, "NULL device pointer");
+    if (count == 0) return NNPOPS_OK;
+    const int blocks = (int)std::min<int64_t>((count + 255) / 256, 2048);
+    if (factor_is_double)
+        hipLaunchKernelGGL(scale_by_scalar<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (long)count, (const double*)factor, out);
+    else
+        hipLaunchKernelGGL(scale_by_scalar<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (long)count, (const float*)factor, out);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }

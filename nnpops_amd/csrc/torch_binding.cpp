@@ -385,9 +385,14 @@ Tensor aev(const c10::optional<HolderPtr>& holder, const Tensor& positions, cons
 // ---------------------------------------------------------------------------------------------
 class EnergyFunction : public torch::autograd::Function<EnergyFunction> {
 public:
-    static Tensor forward(AutogradContext* ctx, const HolderPtr& holder, const Tensor& positions, const c10::optional<Tensor>& cell,
+    // `frame`: positions [N, 3], or [1, N, 3] as the torchani modules pass them (the gradient comes back in the same shape: no
+    // select / select-backward kernels around the node).  `shift`: optional float64 device scalar, the molecule's self energy
+    // (EnergyShifter.py:52); with it the energy comes back in double precision, promoted and shifted as the reference does it.
+    static Tensor forward(AutogradContext* ctx, const HolderPtr& holder, const Tensor& frame, const c10::optional<Tensor>& cell,
                           const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
-                          const Tensor& planes, const Tensor& floats, bool need_gradient) {
+                          const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift, bool need_gradient) {
+        TORCH_CHECK(frame.dim() == 2 || (frame.dim() == 3 && frame.size(0) == 1), "energy(): positions must be [atoms, 3] or [1, atoms, 3]");
+        const Tensor positions = frame.dim() == 3 ? frame[0] : frame;
         // (The capacity check of the AEV holder -- one host round trip per call unless set_check_interval says otherwise -- sits
         //  right after the AEV forward: everything behind it is queued while the device is still busy, and the next call's
         //  launches queue behind that.  Checking at the END of the step instead was measured: the device then idles through the
@@ -397,15 +402,26 @@ public:
         void* stream = current_stream(aev.device());
         MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient);
         if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
-        Tensor energy = torch::empty({1}, aev.options());
-        if (nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,     // BatchedNN.py:109
-                                   energy.data_ptr<float>()) != NNPOPS_OK)
-            raise_last("NNPOpsANISymmetryFunctions::energy");
+        Tensor energy;
+        int rc;
+        if (shift.has_value()) {
+            TORCH_CHECK(shift->scalar_type() == torch::kFloat64 && shift->device() == aev.device() && shift->numel() == 1 && shift->is_contiguous(),
+                        "energy(): the self-energy shift must be one float64 on the device of the positions");
+            energy = torch::empty({1}, aev.options().dtype(torch::kFloat64));
+            rc = nnpops_mlp_energy_mean_shifted(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,
+                                                shift->data_ptr<double>(), energy.data_ptr<double>());
+        } else {
+            energy = torch::empty({1}, aev.options());
+            rc = nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,     // BatchedNN.py:109
+                                        energy.data_ptr<float>());
+        }
+        if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
         if (need_gradient) {
             Tensor daev = torch::empty_like(aev);
             call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = 1.0f / (float)members;
             if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
             ctx->save_for_backward({holder->backwardFused(daev)[1]});
+            ctx->saved_data["lead"] = frame.dim() == 3;
         }
         return energy;
     }
@@ -415,14 +431,25 @@ public:
                     "use the four-module composition for that");
         const auto saved = ctx->get_saved_variables();
         TORCH_CHECK(!saved.empty(), "energy() was evaluated without a gradient request");
-        return {Tensor(), saved[0] * grads[0], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        const Tensor& kept = saved[0];                                       // dE/dpositions, [N, 3] float32
+        const Tensor g = grads[0].contiguous();
+        TORCH_CHECK(g.numel() == 1 && g.device() == kept.device() && (g.scalar_type() == torch::kFloat32 || g.scalar_type() == torch::kFloat64),
+                    "energy(): unexpected gradient of the energy");
+        c10::hip::HIPGuard guard(kept.device().index());
+        Tensor out = torch::empty_like(kept);
+        if (nnpops_scale_by_scalar(current_stream(kept.device()), kept.data_ptr<float>(), kept.numel(), g.data_ptr(),
+                                   g.scalar_type() == torch::kFloat64 ? 1 : 0, out.data_ptr<float>()) != NNPOPS_OK)
+            raise_last("NNPOpsANISymmetryFunctions::energy (backward)");
+        if (ctx->saved_data["lead"].toBool()) out = out.unsqueeze(0);
+        return {Tensor(), out, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
 Tensor energy(const c10::optional<HolderPtr>& holder, const Tensor& positions, const c10::optional<Tensor>& cell, const Tensor& rows,
-              std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members, const Tensor& planes, const Tensor& floats) {
+              std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members, const Tensor& planes, const Tensor& floats,
+              const c10::optional<Tensor>& shift) {
     const bool need = torch::GradMode::is_enabled() && positions.requires_grad();
-    return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, need);
+    return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, shift, need);
 }
 
 TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
@@ -439,7 +466,7 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
     m.def("operation", operation);
     m.def("aev", aev);
     m.def("energy(__torch__.torch.classes.NNPOpsANISymmetryFunctions.Holder? holder, Tensor positions, Tensor? cell, Tensor rows, int[] kind_atoms, "
-          "int[] widths, int members, Tensor planes, Tensor floats) -> Tensor", energy);
+          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None) -> Tensor", energy);
 }
 
 }  // namespace ANISymmetryFunctions

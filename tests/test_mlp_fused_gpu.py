@@ -127,3 +127,23 @@ def test_packer_layout():
                 hi = float(torch.tensor(v).half())
                 assert float(packed[rb, s, 0, lane, i]) == hi
                 assert float(packed[rb, s, 1, lane, i]) == float(torch.tensor((v - hi) * 2048.0).half())
+
+
+def test_shifted_energy_mean_and_scale_by_scalar():
+    """The two small launches around the one-node OptimizedTorchANI step (include/nnpops_hip.h): the ensemble mean promoted to
+    float64 and shifted by the self energy exactly as `energies + self_energies` does it (EnergyShifter.py:52), and
+    values * float(device scalar) for a float32 or a float64 factor -- bit for bit what the tensor expressions give."""
+    from nnpops_amd import capi
+    gen = torch.Generator().manual_seed(5)
+    kd = _networks((64, 32, 32), 3, 96, seed=8)
+    kd["atoms"] = torch.arange(37, dtype=torch.int32)
+    mlp = capi.FusedMLP([{k: v.to(DEV) for k, v in kd.items()}], 96)
+    x = torch.randn(37, 96, generator=gen).to(DEV)
+    mlp.forward(x, with_gradient=False)
+    shift = torch.tensor([-1234.56789012345], dtype=torch.float64, device=DEV)
+    plain = mlp.energy_mean(1.0 / 3)
+    shifted = mlp.energy_mean_shifted(shift, 1.0 / 3)
+    assert shifted.dtype == torch.float64 and torch.equal(shifted, plain + shift)
+    values = torch.randn(1001, 3, generator=gen).to(DEV)
+    for factor in (torch.tensor([2.5000001], device=DEV), torch.tensor([-0.3333333333333], dtype=torch.float64, device=DEV)):
+        assert torch.equal(capi.scale_by_scalar(values, factor), values * factor.float())

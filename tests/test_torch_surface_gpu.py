@@ -509,8 +509,19 @@ def test_fused_optimized_torchani_is_one_autograd_node_and_equals_the_compositio
     while fn is not None:
         names.append(fn.name())
         fn = fn.next_functions[0][0] if fn.next_functions else None
-    # shifter add <- energy node <- positions[0] <- leaf: nothing else was recorded
-    assert len(names) == 4 and sum("EnergyFunction" in n for n in names) == 1, names
+    # energy node <- leaf: nothing else was recorded (the positions go in as [1, N, 3], the self-energy shift is added by the
+    # kernel that takes the ensemble mean)
+    assert len(names) == 2 and "EnergyFunction" in names[0] and "AccumulateGrad" in names[1], names
+    # ... and that shift is the reference's `energies + self_energies` to the bit: the float32 mean, promoted, plus the float64 buffer
+    with torch.no_grad():
+        unshifted = fused.neural_networks.fused_energy(p[0], cell)
+        assert unshifted.dtype == torch.float32
+        assert torch.equal(e.detach(), unshifted + fused.energy_shifter.self_energies)
+    # a float32 upstream gradient (the energy cast down before the loss) takes the same node
+    p32 = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+    (2.5 * fused((numbers, p32), cell, pbc).energies.float().sum()).backward()
+    torch.testing.assert_close(p32.grad, f1, rtol=1e-6, atol=0.0)
+    assert p32.grad.shape == (1, len(species), 3)
     with pytest.raises(RuntimeError, match="second derivatives are not implemented"):
         torch.autograd.grad(e.sum(), p, create_graph=True)
     with torch.no_grad():                                                 # energy only
