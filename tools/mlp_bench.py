@@ -4,7 +4,8 @@ forward(+small-layer backward) and input-gradient launches, HIP events over 200 
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from nnpops_amd.capi import FusedMLP
 
 
