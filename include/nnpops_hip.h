@@ -98,6 +98,14 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
  * slack: a row that outgrows it is clamped (the builders raise a device-side flag that only check() reads), so call
  * check() every few hundred replays, or after anything that can change the density. */
 int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors);
+/* The same check in two halves for callers that have more work to queue behind compute(): _begin (right after compute) queues
+ * a 4-byte copy of the overflow word and an event and returns 1 -- or 0 when the check cannot be deferred (first calls, while
+ * capacities are still being fitted): call nnpops_ani_check() then.  _end (after the consumers of this build have been launched;
+ * they clamp their counts, so an overflowed build is incomplete but harmless to run) waits for that event only and returns what
+ * nnpops_ani_check() would: NNPOPS_OK, or NNPOPS_ERR_CAPACITY after growing the buffers -- compute() and everything queued
+ * behind it must then be issued again.  Additive (the reference has no capacity check: its neighbour list is the N x N matrix). */
+int nnpops_ani_check_begin(nnpops_ani_t h);
+int nnpops_ani_check_end(nnpops_ani_t h);
 /* Neighbour search used by compute(): 0 = automatic, 1 = all-pairs scan (the reference's
  * algorithm, O(N^2)), 2 = cell list (O(N); periodic boxes must be at least 3 cells wide per axis). */
 int nnpops_ani_set_neighbor_algorithm(nnpops_ani_t h, int algorithm);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "nnpops_ani_compute_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "nnpops_ani_backprop_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "nnpops_ani_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nnpops_ani_check_begin": (C.c_int, [C.c_void_p]),
+    "nnpops_ani_check_end": (C.c_int, [C.c_void_p]),
     "nnpops_ani_set_neighbor_algorithm": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_ani_set_molecules": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "nnpops_ani_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -243,6 +245,18 @@ class AniSymmetryFunctions:
         ms = C.c_double(0)
         _check(self._lib.nnpops_ani_timing_overhead(self._h, C.byref(ms)))
         return 1e-3 * ms.value
+
+    def check_begin(self):
+        """First half of the deferred capacity check (right after compute(check=False)): True when the check is in flight and
+        check_end() will finish it, False when it cannot be deferred (call neighbor_stats() / compute(check=True) instead)."""
+        return self._lib.nnpops_ani_check_begin(self._h) == 1
+
+    def check_end(self):
+        """Second half: OK, or ERR_CAPACITY after the buffers have grown (compute() and its consumers must be issued again)."""
+        code = self._lib.nnpops_ani_check_end(self._h)
+        if code not in (OK, ERR_CAPACITY):
+            _check(code)
+        return code
 
     def neighbor_stats(self):
         """(max neighbours within Rcr, max neighbours within Rca) of the last compute; blocks."""

@@ -70,6 +70,9 @@ struct nnpops_ani {
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
     int* d_status = nullptr;        // [kStatWords]
+    int* h_status = nullptr;        // pinned host copy of the overflow word (nnpops_ani_check_begin / _end)
+    hipEvent_t ev_check = nullptr;  // recorded behind that copy
+    bool check_pending = false;
     // cell grid (celllist.h)
     CellGrid* d_grid = nullptr;
     int* d_cell_count = nullptr;    // [max_cells]
@@ -594,6 +597,8 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
         if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_check) (void)hipEventDestroy(h->ev_check);
+    if (h->h_status) (void)hipHostFree(h->h_status);
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
         for (hipEvent_t e : h->ev_start[k]) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ev_stop[k]) (void)hipEventDestroy(e);
@@ -803,6 +808,36 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     if (rc != NNPOPS_OK) return rc;
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
+}
+
+// The capacity check in two halves, so that its host round trip does not stop the device: _begin queues the 4-byte copy of the
+// builders' overflow word (into pinned memory) and an event behind the neighbour build; the caller goes on launching the work
+// that consumes the rows (consumers clamp their counts, an overflowed row is incomplete but harmless); _end waits for THAT
+// event only -- long past by then -- and, when the word is clean, that was all.  Otherwise it is nnpops_ani_check().
+int nnpops_ani_check_begin(nnpops_ani_t h) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    h->check_pending = false;
+    if (!h->cap_fitted || h->backward_kernel == 0) return 0;          // the full check has decisions to make: not deferrable
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return 0;
+    if (!h->h_status && hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault) != hipSuccess) { h->h_status = nullptr; return 0; }
+    if (!h->ev_check && hipEventCreateWithFlags(&h->ev_check, hipEventDisableTiming) != hipSuccess) { h->ev_check = nullptr; return 0; }
+    if (hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipEventRecord(h->ev_check, h->stream) != hipSuccess)
+        return 0;
+    h->check_pending = true;
+    return 1;
+}
+
+int nnpops_ani_check_end(nnpops_ani_t h) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    if (!h->check_pending) return nnpops_ani_check(h, nullptr, nullptr);
+    h->check_pending = false;
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
+    NNPOPS_HIP_TRY(hipEventSynchronize(h->ev_check));
+    if (h->h_status[0] == 0) return NNPOPS_OK;
+    return nnpops_ani_check(h, nullptr, nullptr);                      // (statistics, growth, NNPOPS_ERR_CAPACITY)
 }
 
 int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors) {

@@ -175,7 +175,10 @@ public:
     // fused = true: ONE output, aev [N, S*nR + S(S+1)/2*nA] = (radial | angular) per row -- what TorchANI's AEVComputer
     // returns and what the Python wrapper otherwise builds with torch.cat: the kernels write the two parts in place
     // (nnpops_ani_compute_strided), no concatenation copy forward, no split copy backward.
-    tensor_list forwardImpl(const Tensor& positions, const c10::optional<Tensor>& cellOpt, bool fused) {
+    // defer_check: a caller with more launches to queue behind the AEV (EnergyFunction) takes the capacity check in two halves --
+    // the copy of the overflow word is queued here, finishDeferredCheck() reads it after those launches (nnpops_hip.h:
+    // nnpops_ani_check_begin / _end), so the host round trip no longer stops the device between the AEV and its consumers.
+    tensor_list forwardImpl(const Tensor& positions, const c10::optional<Tensor>& cellOpt, bool fused, bool defer_check = false) {
         // same checks, same messages as the reference (SymmetryFunctions.cpp:76-99)
         if (positions.scalar_type() != torch::kFloat32) throw std::runtime_error("The type of \"positions\" has to be float32");
         if (positions.dim() != 2) throw std::runtime_error("The shape of \"positions\" has to have 2 dimensions");
@@ -246,6 +249,7 @@ public:
             const bool due = calls == 0 || (checkInterval > 0 && calls % checkInterval == 0);
             calls++;
             if (!due && attempt == 0) break;
+            if (defer_check && nnpops_ani_check_begin(impl) == 1) { checkPending = true; break; }
             const int rc = nnpops_ani_check(impl, nullptr, nullptr);
             if (rc == NNPOPS_OK) break;
             if (rc != NNPOPS_ERR_CAPACITY || attempt > 8) raise_last("NNPOpsANISymmetryFunctions::forward");
@@ -297,6 +301,16 @@ public:
         return stream.str();
     }
 
+    // -> true: the neighbour buffers had overflowed and have been grown; the caller issues forwardImpl() and its consumers again
+    bool finishDeferredCheck() {
+        if (!checkPending) return false;
+        checkPending = false;
+        const int rc = nnpops_ani_check_end(impl);
+        if (rc == NNPOPS_OK) return false;
+        if (rc != NNPOPS_ERR_CAPACITY) raise_last("NNPOpsANISymmetryFunctions::forward");
+        return true;
+    }
+
     static HolderPtr deserialize(const std::string& state) {
         std::stringstream stream(state);
         torch::serialize::InputArchive archive;
@@ -335,6 +349,7 @@ private:
     nnpops_ani_t impl = nullptr;
     int64_t checkInterval = 1;      // capacity check every k-th forward (0: only the first); see setCheckInterval
     int64_t calls = 0;
+    bool checkPending = false;
 };
 
 class AutogradFunctions : public torch::autograd::Function<AutogradFunctions> {
@@ -393,34 +408,42 @@ public:
                           const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift, bool need_gradient) {
         TORCH_CHECK(frame.dim() == 2 || (frame.dim() == 3 && frame.size(0) == 1), "energy(): positions must be [atoms, 3] or [1, atoms, 3]");
         const Tensor positions = frame.dim() == 3 ? frame[0] : frame;
-        // (The capacity check of the AEV holder -- one host round trip per call unless set_check_interval says otherwise -- sits
-        //  right after the AEV forward: everything behind it is queued while the device is still busy, and the next call's
-        //  launches queue behind that.  Checking at the END of the step instead was measured: the device then idles through the
-        //  host's whole between-steps overhead, 0.22 -> 0.28 ms per step.)
-        const Tensor aev = holder->forwardImpl(positions, cell, true)[0];
-        c10::hip::HIPGuard guard(aev.device().index());
-        void* stream = current_stream(aev.device());
-        MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient);
-        if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
-        Tensor energy;
-        int rc;
-        if (shift.has_value()) {
-            TORCH_CHECK(shift->scalar_type() == torch::kFloat64 && shift->device() == aev.device() && shift->numel() == 1 && shift->is_contiguous(),
-                        "energy(): the self-energy shift must be one float64 on the device of the positions");
-            energy = torch::empty({1}, aev.options().dtype(torch::kFloat64));
-            rc = nnpops_mlp_energy_mean_shifted(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,
-                                                shift->data_ptr<double>(), energy.data_ptr<double>());
-        } else {
-            energy = torch::empty({1}, aev.options());
-            rc = nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,     // BatchedNN.py:109
-                                        energy.data_ptr<float>());
+        // (The capacity check of the AEV holder -- one host round trip per call unless set_check_interval says otherwise -- is
+        //  taken in two halves: its copy is queued right behind the AEV forward, its answer is read after everything else has been
+        //  launched.  A buffer that did overflow is grown there and the step issued again.  Before: the host waited for the AEV
+        //  forward, then launched the networks into an idle device; waiting at the END of the step for the whole stream was
+        //  worse still, 0.22 -> 0.28 ms.)
+        Tensor energy, kept;
+        for (int attempt = 0;; attempt++) {
+            TORCH_CHECK(attempt <= 8, "NNPOpsANISymmetryFunctions::energy: neighbour buffers kept overflowing");
+            const Tensor aev = holder->forwardImpl(positions, cell, true, /*defer_check=*/true)[0];
+            c10::hip::HIPGuard guard(aev.device().index());
+            void* stream = current_stream(aev.device());
+            MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient);
+            if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+            int rc;
+            if (shift.has_value()) {
+                TORCH_CHECK(shift->scalar_type() == torch::kFloat64 && shift->device() == aev.device() && shift->numel() == 1 && shift->is_contiguous(),
+                            "energy(): the self-energy shift must be one float64 on the device of the positions");
+                energy = torch::empty({1}, aev.options().dtype(torch::kFloat64));
+                rc = nnpops_mlp_energy_mean_shifted(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,
+                                                    shift->data_ptr<double>(), energy.data_ptr<double>());
+            } else {
+                energy = torch::empty({1}, aev.options());
+                rc = nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,     // BatchedNN.py:109
+                                            energy.data_ptr<float>());
+            }
+            if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+            if (need_gradient) {
+                Tensor daev = torch::empty_like(aev);
+                call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = 1.0f / (float)members;
+                if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+                kept = holder->backwardFused(daev)[1];
+            }
+            if (!holder->finishDeferredCheck()) break;
         }
-        if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
         if (need_gradient) {
-            Tensor daev = torch::empty_like(aev);
-            call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = 1.0f / (float)members;
-            if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
-            ctx->save_for_backward({holder->backwardFused(daev)[1]});
+            ctx->save_for_backward({kept});
             ctx->saved_data["lead"] = frame.dim() == 3;
         }
         return energy;

@@ -202,6 +202,38 @@ def test_denser_frame_after_the_last_check_is_still_exact():
     assert np.abs(grad.cpu().numpy() - g_ref).max() <= FORCE_RTOL * np.abs(g_ref).max()
 
 
+def test_capacity_check_in_two_halves():
+    """nnpops_ani_check_begin / _end (include/nnpops_hip.h): not deferrable before the capacities have been fitted; then _begin
+    queues the copy, consumers may be launched, _end says OK; a frame dense enough to overflow the fitted rows makes _end grow
+    them and return ERR_CAPACITY, after which compute() gives the oracle's numbers."""
+    from nnpops_amd.capi import AniSymmetryFunctions, OK, ERR_CAPACITY
+    rf, af = workloads.ani2x_functions()
+    pos, species, box = workloads.random_box(1200, seed=31)
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True)
+    dev = torch.device("cuda:0")
+    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    sym.compute(tpos, tbox, check=False)
+    assert sym.check_begin() is False                       # first frame: the full check has capacities to fit
+    sym.compute(tpos, tbox, check=True)
+    ref = [t.clone() for t in sym.compute(tpos, tbox, check=True)]
+    r, a = sym.compute(tpos, tbox, check=False)
+    assert sym.check_begin() is True
+    grad = sym.backprop(torch.ones_like(r), torch.ones_like(a))     # a consumer launched between the halves
+    assert sym.check_end() == OK
+    assert torch.equal(r, ref[0]) and torch.equal(a, ref[1]) and bool(torch.isfinite(grad).all())
+    shrink = np.float32(0.72)                               # 2.7 x the density: rows outgrow max_row * 1.25 + 8
+    pos2, box2 = pos * shrink, box * shrink
+    tpos2, tbox2 = torch.tensor(pos2, device=dev), torch.tensor(box2, device=dev)
+    sym.compute(tpos2, tbox2, check=False)
+    assert sym.check_begin() is True
+    sym.backprop(torch.ones_like(r), torch.ones_like(a))            # harmless on the clamped rows
+    assert sym.check_end() == ERR_CAPACITY
+    r2, a2 = sym.compute(tpos2, tbox2, check=True)
+    r_ref, a_ref = AniOracle(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=True).forward(pos2, box2)
+    np.testing.assert_allclose(r2.cpu().numpy(), r_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
+    np.testing.assert_allclose(a2.cpu().numpy(), a_ref, rtol=AEV_RTOL, atol=AEV_ATOL)
+
+
 @pytest.mark.parametrize("kernel", ["0", "1", "2"])
 @pytest.mark.parametrize("kind", ["water", "seven_species", "dense"])
 def test_both_angular_forward_kernels(monkeypatch, kernel, kind):

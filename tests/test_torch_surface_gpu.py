@@ -543,3 +543,33 @@ def test_fused_optimized_torchani_is_one_autograd_node_and_equals_the_compositio
     e3, f3 = run(loaded, 2.5)
     torch.testing.assert_close(e3, e1, rtol=1e-7, atol=1e-6)
     torch.testing.assert_close(f3, f1, rtol=1e-6, atol=1e-7 * float(f1.abs().max()))
+
+
+def test_fused_step_regrows_its_neighbour_buffers_behind_the_deferred_check():
+    """The one-node step reads the capacity check of its AEV holder AFTER it has launched the networks and the backward pass
+    (torch_binding.cpp: forwardImpl(defer_check) / finishDeferredCheck).  A frame dense enough to overflow the fitted rows
+    must therefore be detected there, the buffers grown and the whole step issued again: same energy and forces as a fresh
+    four-module composition on that frame."""
+    from NNPOps import OptimizedTorchANI
+    model = workloads.torchani_like_model(n_models=2, seed=4)
+    pos, species, box = workloads.water_box(120, seed=8)
+    numbers = _numbers(species)
+    fused = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+    assert type(fused).__name__ == "FusedOptimizedTorchANI"
+    pbc = torch.tensor([True, True, True], device=DEV)
+
+    def run(module, scale):
+        p = torch.tensor(pos * np.float32(scale), device=DEV).unsqueeze(0).requires_grad_(True)
+        e = module((numbers, p), torch.tensor(box * np.float32(scale), device=DEV), pbc).energies
+        e.sum().backward()
+        return e.detach(), p.grad.detach()
+
+    for _ in range(3):                                     # capacities fitted to this density, checks deferred from now on
+        run(fused, 1.0)
+    e1, f1 = run(fused, 0.72)                              # 2.7 x denser: overflows the fitted rows
+    plain = OptimizedTorchANI(model, numbers.cpu(), fused_step=False).to(DEV)
+    e2, f2 = run(plain, 0.72)
+    torch.testing.assert_close(e1, e2, rtol=1e-7, atol=2e-4)
+    torch.testing.assert_close(f1, f2, rtol=1e-4, atol=2e-5 * float(f2.abs().max()))
+    e3, f3 = run(fused, 0.72)                              # and once more, now without growth: bitwise the same
+    assert torch.equal(e1, e3) and torch.equal(f1, f3)
