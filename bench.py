@@ -914,7 +914,7 @@ def run_conformers(args, R):
                      "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(step_bytes / elapsed * steps / 1e9 / (HBM_PEAK_GBS * world), 5),
                      "traffic": None, "algorithmic_bytes_per_launch": step_bytes},
     }
-    if world == 1:
+    if world == 1 and not args.no_shard8:
         # What one GPU of an 8-GPU node would run: every block of shard_molecules(sizes, 8) timed alone on THIS device
         # (same handle type, same step).  projected_scaling = t(1024 conformers, 1 GPU) / max over the 8 blocks -- the
         # all_gather (0.74 MB in all) is off the critical path when it overlaps the next step; the second figure adds a
@@ -1138,6 +1138,7 @@ def main():
     ap.add_argument("--settle", type=int, default=-1, help="untimed settling steps before the warm-up (-1: 2500 for frames up to 20 000 atoms)")
     ap.add_argument("--strict-side", action="store_true", help="exit with status 3 when a side workload failed (the line is still printed)")
     ap.add_argument("--graph", action="store_true", help="torchani / cfconv workloads: replay the step as one captured HIP graph")
+    ap.add_argument("--no-shard8", action="store_true", help="conformers workload: skip the eight per-shard timings (profiles of the full batch alone)")
     ap.add_argument("--nn-layout", default="fused", choices=["fused", "gemm", "grouped", "reference"],
                     help="torchani workload: the fused network kernels (default), per-layer split-fp16 GEMMs, library GEMMs, or the "
                          "reference's per-atom replicated weights")
