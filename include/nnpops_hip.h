@@ -99,9 +99,9 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
  * check() every few hundred replays, or after anything that can change the density. */
 int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors);
 /* The same check in two halves for callers that have more work to queue behind compute(): _begin (right after compute) queues
- * a 4-byte copy of the overflow word and an event and returns 1 -- or 0 when the check cannot be deferred (first calls, while
+ * one single-thread launch that publishes the overflow word and a stamp into pinned host memory and returns 1 -- or 0 when the check cannot be deferred (first calls, while
  * capacities are still being fitted): call nnpops_ani_check() then.  _end (after the consumers of this build have been launched;
- * they clamp their counts, so an overflowed build is incomplete but harmless to run) waits for that event only and returns what
+ * they clamp their counts, so an overflowed build is incomplete but harmless to run) polls that stamp (no API call) and returns what
  * nnpops_ani_check() would: NNPOPS_OK, or NNPOPS_ERR_CAPACITY after growing the buffers -- compute() and everything queued
  * behind it must then be issued again.  Additive (the reference has no capacity check: its neighbour list is the N x N matrix). */
 int nnpops_ani_check_begin(nnpops_ani_t h);
@@ -271,6 +271,8 @@ typedef struct {
     const void *w4t, *w2t, *w0t;         /* gradient planes (device; may be NULL when with_gradient == 0) */
     const float *b0, *b2, *b4, *w6, *b6; /* device */
     void* d1;                            /* device workspace, nnpops_mlp_d1_halves(num_atoms, M, h1) fp16 values (gradient only) */
+    const void* w0tm;                    /* optional: W_0^T member by member, pack(F, h1, W_0 of member m, transpose 1, permute 1), members one
+                                          * after the other -- what the forward launch multiplies dE/dy1 with when the frame has dx_partial */
 } nnpops_mlp_kind;
 typedef struct {
     int num_kinds, num_features, num_members;
@@ -282,6 +284,23 @@ typedef struct {
     const float* upstream;               /* optional device scalar: dx is multiplied by it (dE_total/dE of this sum); NULL = 1 */
     float dx_scale;                      /* host scalar, also multiplied into dx (e.g. 1 / num_members for an ensemble mean); 0 is read as 1 */
     nnpops_mlp_kind kinds[NNPOPS_MLP_MAX_KINDS];
+    /* Networks over a SUBSET of the columns of x.  The AEV blocks of species a molecule does not contain are structurally zero
+     * (no neighbour of that species, no pair with it): their products need not be formed and their weights not be read.  With
+     * x_groups (device, num_features / 16 entries; num_features % 16 == 0) the planes w0 / w0t / w0tm are packed over
+     * num_features = 16 * (number of live blocks) columns and feature block f reads columns 16 * x_groups[f] .. + 15 of x (and
+     * writes those of dx).  dead_groups lists the other 16-column blocks of dx: nnpops_mlp_input_grad sets them to zero.  The
+     * result of the full product whenever the skipped columns of x are zero (up to the order of the fp32 additions: the live
+     * columns share K steps differently).  NULL / 0: all columns, as before. */
+    const int32_t* x_groups;
+    const int32_t* dead_groups; int num_dead_groups;
+    /* Optional device workspace [num_members][sum of num_atoms][num_features] floats, for num_features <= 256 and kinds with w0tm:
+     * nnpops_mlp_forward(with_gradient) then also forms every member's W_0^T dE/dy1 (d1 never leaves the CU) and
+     * nnpops_mlp_input_grad only adds the members up, in a fixed order. */
+    float* dx_partial;
+    /* Optional, honoured by nnpops_mlp_input_grad when dx_partial is set: the launch that adds the members up also takes the
+     * energy mean of nnpops_mlp_energy_mean (mean_out, a device float) or nnpops_mlp_energy_mean_shifted (mean_shift and
+     * mean_out_shifted, device doubles) with scale mean_scale -- same numbers, one launch fewer. */
+    float mean_scale; float* mean_out; const double* mean_shift; double* mean_out_shifted;
 } nnpops_mlp_frame;
 int64_t nnpops_mlp_packed_halves(int rows, int cols);
 int64_t nnpops_mlp_d1_halves(int num_atoms, int num_members, int h1);

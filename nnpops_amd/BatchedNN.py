@@ -189,15 +189,28 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
     networks, forward and backward, as one autograd node (``fused_energy``)."""
 
     widths: List[int]
+    live_blocks: List[int]
 
     def __init__(self, converter, ensemble, atomicNumbers: Tensor):
         super().__init__(converter, ensemble, atomicNumbers)
         self.num_models = int(self.layer0_weights.shape[1])
         self.widths = []
+        self.live_blocks = []
         self.fused_ok = True
         self.register_buffer('atom_order32', self.atom_order.to(torch.int32), persistent=False)
-        for name in ('mlp_planes', 'mlp_floats'):
+        for name in ('mlp_planes', 'mlp_floats', 'live_planes'):
             self.register_buffer(name, torch.empty(0), persistent=False)
+        for name in ('x_blocks', 'dead_blocks'):
+            self.register_buffer(name, torch.empty(0, dtype=torch.int32), persistent=False)
+        self._refresh_planes()
+
+    @torch.jit.unused
+    def set_live_blocks(self, blocks: List[int]) -> None:
+        """(inside OptimizedTorchANI) the 16-column blocks of the AEV that can be non-zero for this molecule
+        (TorchANISymmetryFunctions.live_column_blocks): fused_energy() then runs the networks over those columns only --
+        first layer packed over them, the others neither read nor multiplied, their gradient zero (nnpops_hip.h: x_groups)."""
+        F = int(self.layer0_weights.shape[3])
+        self.live_blocks = sorted(int(b) for b in blocks) if F % 16 == 0 and len(blocks) < F // 16 else []
         self._refresh_planes()
 
     @staticmethod
@@ -235,6 +248,36 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         self.mlp_planes = torch.cat(planes).contiguous()
         self.mlp_floats = torch.cat(floats).contiguous()
         self.widths = widths
+        # the same networks over the live column blocks of the AEV only (set_live_blocks): w0 | w2 | w4 | w4t | w2t | w0t [| w0tm]
+        dev = w0.device
+        if self.live_blocks:
+            cols = torch.tensor([16 * g + c for g in self.live_blocks for c in range(16)], dtype=torch.long, device=dev)
+            Fl = int(cols.numel())
+            live = []
+            for k in range(kinds):
+                h1, h2, h3 = widths[3 * k], widths[3 * k + 1], widths[3 * k + 2]
+
+                def cut(t: Tensor, rows: int, ncols: int) -> Tensor:
+                    out = torch.zeros((M, rows, ncols), dtype=torch.float32, device=t.device)
+                    r, c = min(rows, t.shape[1]), min(ncols, t.shape[2])
+                    out[:, :r, :c] = t[:, :r, :c]
+                    return out
+                k0, k2, k4 = cut(w0[k][:, :, cols], h1, Fl), cut(w2[k], h2, h1), cut(w4[k], h3, h2)
+                live += [_pack_fragments(k0[m], False) for m in range(M)]
+                live += [_pack_fragments(k2[m], True) for m in range(M)]
+                live += [_pack_fragments(k4[m], True) for m in range(M)]
+                live += [_pack_fragments(k4[m].t(), True) for m in range(M)]
+                live += [_pack_fragments(k2[m].t(), True) for m in range(M)]
+                live.append(_pack_fragments(k0.reshape(M * h1, Fl).t(), True))
+                if Fl <= 256:
+                    live += [_pack_fragments(k0[m].t(), True) for m in range(M)]
+            self.live_planes = torch.cat(live).contiguous()
+            self.x_blocks = torch.tensor(self.live_blocks, dtype=torch.int32, device=dev)
+            self.dead_blocks = torch.tensor([g for g in range(F // 16) if g not in set(self.live_blocks)], dtype=torch.int32, device=dev)
+        else:
+            self.live_planes = torch.empty(0, device=dev)
+            self.x_blocks = torch.empty(0, dtype=torch.int32, device=dev)
+            self.dead_blocks = torch.empty(0, dtype=torch.int32, device=dev)
         # the kernels scale every activation by 1/16 before the fp16 split: activations must stay below ~1e6.  A crude
         # bound from the weights (AEV entries are sums of at most a few dozen terms <= 1) decides; networks that could
         # exceed it keep the library-GEMM path.  The backward operands take the same planes: |d3| <= |w6|,
@@ -269,8 +312,12 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         """AEV + networks of the whole frame as one autograd node (only inside OptimizedTorchANI, which hands over the AEV
         holder): positions [N, 3] or [1, N, 3] -> ensemble-mean energy [1]; with ``shift`` (the molecule's self energy, one
         float64 on the device) the energy comes back in float64, shifted as the reference's EnergyShifter does it."""
+        if self.x_blocks.numel() > 0:
+            return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
+                                                               self.num_models, self.live_planes, self.mlp_floats, shift, self.x_blocks,
+                                                               self.dead_blocks)
         return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
-                                                           self.num_models, self.mlp_planes, self.mlp_floats, shift)
+                                                           self.num_models, self.mlp_planes, self.mlp_floats, shift, None, None)
 
 
 class _SplitGemmSpeciesNN(_SpeciesGroupedNN):

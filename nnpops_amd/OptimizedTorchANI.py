@@ -17,7 +17,7 @@ class OptimizedTorchANI(torch.nn.Module):
     :class:`FusedOptimizedTorchANI`: same modules, same state dict, same results, but AEV and networks run as ONE autograd
     node (``fused_step=False`` keeps the plain composition)."""
 
-    def __init__(self, model, atomicNumbers: Tensor, nn_layout: str = 'fused', fused_step: bool = True) -> None:
+    def __init__(self, model, atomicNumbers: Tensor, nn_layout: str = 'fused', fused_step: bool = True, live_columns: bool = True) -> None:
         super().__init__()
         self.species_converter = TorchANISpeciesConverter(model.species_converter, atomicNumbers)
         self.aev_computer = TorchANISymmetryFunctions(model.species_converter, model.aev_computer, atomicNumbers)
@@ -26,6 +26,8 @@ class OptimizedTorchANI(torch.nn.Module):
         nets = self.neural_networks[0]
         if fused_step and isinstance(nets, _FusedSpeciesNN) and nets.fused_ok:
             nets.holder = self.aev_computer.holder        # the networks' fused_energy() drives the AEV kernels itself
+            if live_columns:                               # ... and multiplies only the AEV blocks this molecule's species can fill
+                nets.set_live_blocks(self.aev_computer.live_column_blocks())
             self.__class__ = FusedOptimizedTorchANI
 
     def forward(self, species_coordinates: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,

@@ -47,6 +47,27 @@ class TorchANISymmetryFunctions(torch.nn.Module):
         self._species = [int(s) for s in species]
         self._batch_holders = {}
 
+    @torch.jit.unused
+    def live_column_blocks(self) -> List[int]:
+        """Extension: the 16-column blocks of this molecule's AEV rows that can be non-zero.  The radial block of a species and
+        the angular block of a species pair (columns in the order of SymmetryFunctions.cpp:110-120) are identically zero when the
+        molecule has no atom of that species -- nothing downstream needs to read, multiply or differentiate them
+        (:class:`OptimizedTorchANI` hands the list to the fused networks)."""
+        S = self.num_species
+        nR = len(self._ctor[3]) * len(self._ctor[4])
+        nA = len(self._ctor[5]) * len(self._ctor[6]) * len(self._ctor[7]) * len(self._ctor[8])
+        present = sorted(set(self._species))
+        live = [False] * (S * nR + S * (S + 1) // 2 * nA)
+        for s in present:
+            for c in range(s * nR, (s + 1) * nR):
+                live[c] = True
+        for i, a in enumerate(present):
+            for b in present[i:]:
+                bucket = a * S - a * (a - 1) // 2 + (b - a)          # upper-triangular row-major (CpuANISymmetryFunctions.cpp:39-43)
+                for c in range(S * nR + bucket * nA, S * nR + (bucket + 1) * nA):
+                    live[c] = True
+        return [g for g in range((len(live) + 15) // 16) if any(live[16 * g:16 * g + 16])]
+
     @torch.jit.export
     def set_check_interval(self, interval: int) -> None:
         """Extension: verify the neighbour-buffer capacities (one host round trip) only on every ``interval``-th call

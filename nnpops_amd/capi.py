@@ -486,13 +486,16 @@ MLP_MAX_KINDS = 8
 class _MlpKind(C.Structure):
     _fields_ = [("num_atoms", C.c_int), ("h1", C.c_int), ("h2", C.c_int), ("h3", C.c_int),
                 ("w0", C.c_void_p), ("w2", C.c_void_p), ("w4", C.c_void_p), ("w4t", C.c_void_p), ("w2t", C.c_void_p), ("w0t", C.c_void_p),
-                ("b0", C.c_void_p), ("b2", C.c_void_p), ("b4", C.c_void_p), ("w6", C.c_void_p), ("b6", C.c_void_p), ("d1", C.c_void_p)]
+                ("b0", C.c_void_p), ("b2", C.c_void_p), ("b4", C.c_void_p), ("w6", C.c_void_p), ("b6", C.c_void_p), ("d1", C.c_void_p),
+                ("w0tm", C.c_void_p)]
 
 
 class _MlpFrame(C.Structure):
     _fields_ = [("num_kinds", C.c_int), ("num_features", C.c_int), ("num_members", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int),
                 ("rows", C.c_void_p), ("energies", C.c_void_p), ("alpha", C.c_float), ("dx", C.c_void_p), ("lddx", C.c_int),
-                ("upstream", C.c_void_p), ("dx_scale", C.c_float), ("kinds", _MlpKind * MLP_MAX_KINDS)]
+                ("upstream", C.c_void_p), ("dx_scale", C.c_float), ("kinds", _MlpKind * MLP_MAX_KINDS),
+                ("x_groups", C.c_void_p), ("dead_groups", C.c_void_p), ("num_dead_groups", C.c_int), ("dx_partial", C.c_void_p),
+                ("mean_scale", C.c_float), ("mean_out", C.c_void_p), ("mean_shift", C.c_void_p), ("mean_out_shifted", C.c_void_p)]
 
 
 def mlp_pack(w, rows, cols, transpose=False, permute=False):
@@ -512,11 +515,24 @@ class FusedMLP:
     """The atomic networks of one frame (reference BatchedNN.py:37-122) on nnpops_mlp_forward / nnpops_mlp_input_grad.
     ``kinds``: one dict per species present, in the order the atoms are grouped: w0 [M,H1,F], b0 [M,H1], w2 [M,H2,H1], b2,
     w4 [M,H3,H2], b4, w6 [M,H3], b6 [M] (float32 device tensors, torch Linear layout) and ``atoms`` (int32 device tensor:
-    the rows of x that hold the atoms of the kind).  Widths are zero padded to multiples of 32 here."""
+    the rows of x that hold the atoms of the kind).  Widths are zero padded to multiples of 32 here.
 
-    def __init__(self, kinds, num_features, alpha=0.1):
+    ``live_groups`` (optional): the 16-column blocks of x that can be non-zero (the AEV blocks of the species the molecule
+    contains).  The first layer is then packed over those columns only (nnpops_hip.h: x_groups), the others are neither read nor
+    multiplied, and their gradient is written as zero; with at most 256 live columns the forward launch also forms the input
+    gradient member by member (dx_partial) and input_grad() only adds the members up."""
+
+    def __init__(self, kinds, num_features, alpha=0.1, live_groups=None):
         if not 1 <= len(kinds) <= MLP_MAX_KINDS:
             raise ValueError(f"1..{MLP_MAX_KINDS} kinds")
+        self.x_width = int(num_features)
+        self.live = None
+        if live_groups is not None:
+            assert self.x_width % 16 == 0, "column blocks of 16: the width of x must be a multiple of 16"
+            self.live = sorted(int(g) for g in live_groups)
+            cols = torch.tensor([16 * g + c for g in self.live for c in range(16)], dtype=torch.long)
+            kinds = [dict(kd, w0=kd["w0"][:, :, cols.to(kd["w0"].device)].contiguous()) for kd in kinds]
+            num_features = 16 * len(self.live)
         self.F, self.alpha = int(num_features), float(alpha)
         self.M = int(kinds[0]["w0"].shape[0])
         self._keep = []
@@ -546,6 +562,8 @@ class FusedMLP:
                 "w2t": torch.cat([mlp_pack(w2[m], h1, h2, transpose=True, permute=True) for m in range(M)]),
                 "w0t": mlp_pack(w0.reshape(M * h1, F), F, M * h1, transpose=True, permute=True),
             }
+            if self.live is not None and F <= 256:
+                planes["w0tm"] = torch.cat([mlp_pack(w0[m], F, h1, transpose=True, permute=True) for m in range(M)])
             n = int(kd["atoms"].numel())
             d1 = torch.empty((max(int(lib().nnpops_mlp_d1_halves(n, M, h1)), 1),), dtype=torch.float16, device=dev)
             self._keep += [planes, b0, b2, b4, w6, b6, d1]
@@ -559,6 +577,14 @@ class FusedMLP:
         self.frame.rows = self.rows.data_ptr()
         self.energies = torch.empty((self.rows.numel(), self.M), dtype=torch.float32, device=dev)
         self.frame.energies = self.energies.data_ptr()
+        if self.live is not None:
+            dead = [g for g in range(self.x_width // 16) if g not in set(self.live)]
+            self.x_groups = torch.tensor(self.live, dtype=torch.int32, device=dev)
+            self.dead_groups = torch.tensor(dead if dead else [0], dtype=torch.int32, device=dev)
+            self.frame.x_groups, self.frame.dead_groups, self.frame.num_dead_groups = self.x_groups.data_ptr(), self.dead_groups.data_ptr(), len(dead)
+            if self.F <= 256:
+                self.dx_partial = torch.empty((self.M, self.rows.numel(), self.F), dtype=torch.float32, device=dev)
+                self.frame.dx_partial = self.dx_partial.data_ptr()
 
     def forward(self, x, with_gradient=True):
         """x [atoms][>= F] float32 -> energies [grouped atoms][M] (every member's network output per atom)."""
@@ -586,7 +612,7 @@ class FusedMLP:
         """dE/dx of the summed energies of the last forward(with_gradient=True): [atoms][F] float32 (rows of atoms that
         belong to no kind are left as they are)."""
         if out is None:
-            out = torch.zeros((like.shape[0], self.F), dtype=torch.float32, device=like.device)
+            out = torch.zeros((like.shape[0], self.x_width), dtype=torch.float32, device=like.device)
         self.frame.dx, self.frame.lddx = out.data_ptr(), out.shape[1]
         self.frame.upstream = upstream.data_ptr() if upstream is not None else None
         self.frame.dx_scale = float(scale)

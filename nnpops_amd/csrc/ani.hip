@@ -70,8 +70,9 @@ struct nnpops_ani {
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
     int* d_status = nullptr;        // [kStatWords]
-    int* h_status = nullptr;        // pinned host copy of the overflow word (nnpops_ani_check_begin / _end)
-    hipEvent_t ev_check = nullptr;  // recorded behind that copy
+    int* h_status = nullptr;        // pinned, device-visible host words {stamp, overflow} (nnpops_ani_check_begin / _end)
+    int* h_status_dev = nullptr;    // the device's address of the same words
+    int check_stamp = 0;
     bool check_pending = false;
     // cell grid (celllist.h)
     CellGrid* d_grid = nullptr;
@@ -597,7 +598,6 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
         if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_check) (void)hipEventDestroy(h->ev_check);
     if (h->h_status) (void)hipHostFree(h->h_status);
     for (int k = 0; k < NNPOPS_ANI_NUM_KERNELS; k++) {
         for (hipEvent_t e : h->ev_start[k]) (void)hipEventDestroy(e);
@@ -810,21 +810,40 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     return NNPOPS_OK;
 }
 
-// The capacity check in two halves, so that its host round trip does not stop the device: _begin queues the 4-byte copy of the
-// builders' overflow word (into pinned memory) and an event behind the neighbour build; the caller goes on launching the work
-// that consumes the rows (consumers clamp their counts, an overflowed row is incomplete but harmless); _end waits for THAT
-// event only -- long past by then -- and, when the word is clean, that was all.  Otherwise it is nnpops_ani_check().
+// The capacity check in two halves, so that its host round trip does not stop the device: _begin queues ONE tiny launch
+// behind the neighbour build that publishes the builders' overflow word, and a stamp after it, into pinned host memory the
+// device can write (system-scope stores: no copy command, no event -- those cost the host ~35 us per step, more than the
+// launch of every other kernel of the step together); the caller goes on launching the work that consumes the rows
+// (consumers clamp their counts, an overflowed row is incomplete but harmless); _end polls the stamp -- long there by then
+// -- and, when the word is clean, that was all.  Otherwise it is nnpops_ani_check().
+}  // extern "C"
+namespace {
+__global__ void ani_publish_status(const int* __restrict__ status, int* __restrict__ host_words, int stamp) {
+    const int overflow = status[kStatOverflow];
+    __hip_atomic_store(&host_words[1], overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host_words[0], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+extern "C" {
+
 int nnpops_ani_check_begin(nnpops_ani_t h) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
     h->check_pending = false;
     if (!h->cap_fitted || h->backward_kernel == 0) return 0;          // the full check has decisions to make: not deferrable
     DeviceGuard guard(h->device);
     if (!guard.ok) return 0;
-    if (!h->h_status && hipHostMalloc((void**)&h->h_status, sizeof(int), hipHostMallocDefault) != hipSuccess) { h->h_status = nullptr; return 0; }
-    if (!h->ev_check && hipEventCreateWithFlags(&h->ev_check, hipEventDisableTiming) != hipSuccess) { h->ev_check = nullptr; return 0; }
-    if (hipMemcpyAsync(h->h_status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        hipEventRecord(h->ev_check, h->stream) != hipSuccess)
-        return 0;
+    if (!h->h_status) {
+        if (hipHostMalloc((void**)&h->h_status, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess) { h->h_status = nullptr; return 0; }
+        h->h_status[0] = 0; h->h_status[1] = 0;
+        if (hipHostGetDevicePointer((void**)&h->h_status_dev, h->h_status, 0) != hipSuccess) {
+            (void)hipHostFree(h->h_status);
+            h->h_status = nullptr;
+            return 0;
+        }
+    }
+    h->check_stamp = h->check_stamp == 0x7fffffff ? 1 : h->check_stamp + 1;
+    hipLaunchKernelGGL(ani_publish_status, dim3(1), dim3(1), 0, h->stream, h->d_status, h->h_status_dev, h->check_stamp);
+    if (hipGetLastError() != hipSuccess) return 0;
     h->check_pending = true;
     return 1;
 }
@@ -835,8 +854,15 @@ int nnpops_ani_check_end(nnpops_ani_t h) {
     h->check_pending = false;
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
-    NNPOPS_HIP_TRY(hipEventSynchronize(h->ev_check));
-    if (h->h_status[0] == 0) return NNPOPS_OK;
+    volatile int* words = h->h_status;
+    bool seen = false;
+    for (long spin = 0; spin < 2000000 && !(seen = __atomic_load_n(&h->h_status[0], __ATOMIC_ACQUIRE) == h->check_stamp); spin++)
+        __builtin_ia32_pause();
+    if (!seen) {                                                       // (a very slow device, or the store got lost: ask the stream)
+        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+        if (__atomic_load_n(&h->h_status[0], __ATOMIC_ACQUIRE) != h->check_stamp) return nnpops_ani_check(h, nullptr, nullptr);
+    }
+    if (words[1] == 0) return NNPOPS_OK;
     return nnpops_ani_check(h, nullptr, nullptr);                      // (statistics, growth, NNPOPS_ERR_CAPACITY)
 }
 

@@ -60,6 +60,7 @@ struct KindDesc {                           // one species: its atoms (a contigu
     int h1, h2, h3;                         // layer widths rounded up to 32 (zero padded)
     int tiles, block0;                      // 64-atom tiles, first workgroup of the kind
     const _Float16 *w0, *w2, *w4, *w4t, *w2t, *w0t;     // packed fragment planes, members one after the other
+    const _Float16* w0tm;                   // W0^T member by member ([M][F/16 row blocks][h1/32 steps]); only with dx_partial
     const float *b0, *b2, *b4, *w6, *b6;    // [M][h1] [M][h2] [M][h3] [M][h3] [M]
     _Float16* d1;                           // [tiles][M][h1/32][kCB][2][kFrag]: dE/dy1 in B-fragment planes
 };
@@ -73,6 +74,10 @@ struct MlpArgs {
     float* dx; int lddx;                    // input_grad only
     const float* upstream;                  // optional device scalar multiplying dx
     float dx_scale;                         // host scalar multiplying dx
+    const int* x_groups;                    // optional: feature block f lives in columns 16 x_groups[f] .. of x / dx (NULL: f)
+    const int* dead_groups; int num_dead;   // 16-column blocks of dx the gradient pass sets to zero
+    float* dx_partial; int n_grouped;       // optional [M][n_grouped][F]: every member's W0^T dE/dy1, formed by the forward launch
+    float mean_scale; float* mean_out; const double* mean_shift; double* mean_out_shifted;   // optional: the energy mean rides along (mlp_sum_members)
     KindDesc kinds[NNPOPS_MLP_MAX_KINDS];
 };
 
@@ -197,10 +202,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
     char* xstage = lds;                                     // 2 x 8 KiB: the AEV columns of a K step, split, fragment layout
     char* actA = lds + 2 * kStageBytes;                     // 64 KiB
     char* actB = actA + kActBytes;                          // 64 KiB
+    int* xgroup = reinterpret_cast<int*>(actB + kActBytes); // 64 ints: column block of x behind every 16-feature block
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const KindDesc& kd = kind_of_block(g, blockIdx.x);
     const int local = blockIdx.x - kd.block0;
     const int m = local % g.M, tile = local / g.M;
+    if (tid < 64) xgroup[tid] = 16 * tid < g.F ? (g.x_groups ? g.x_groups[tid] : tid) : 0;
+    __syncthreads();
     const int r0 = tile * kTile;                            // first atom of the tile inside the kind
     const int kgD = lane >> 4, a16 = lane & 15;
     const float inv_alpha = 1.0f / g.alpha;
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
         // staging role: thread -> (atom a = tid / 8, piece = tid % 8): four consecutive columns, one 8-byte half of a fragment slot
         const int sa = tid >> 3, piece = tid & 7;
         const int srow = g.rows[kd.first + min(r0 + sa, kd.n - 1)];
-        const float* xsrc = g.x + (size_t)srow * g.ldx + piece * 4;
+        const float* xsrc = g.x + (size_t)srow * g.ldx + (piece & 3) * 4;
         char* xdst = xstage + ((sa >> 4) * 2) * 1024 + ((sa & 15) + 16 * (piece >> 1)) * 16 + 8 * (piece & 1);
         // (the loaded columns are NOT touched before they are staged one step later: an instruction that consumes them right
         //  after the load makes the compiler wait for EVERY outstanding load there -- s_waitcnt vmcnt(0) after each barrier,
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
 #ifdef NNPOPS_PROTOTYPE_AEV_FROM_LDS      // tools/proto_fused_aev.py: what the kernel would cost if the AEV never came from memory
             xraw = make_float4(0.25f, 0.5f, 0.75f, 1.0f);
 #else
-            xraw = *reinterpret_cast<const float4*>(xsrc + (in ? 32 * s : -piece * 4));
+            xraw = *reinterpret_cast<const float4*>(xsrc + 16 * xgroup[in ? 2 * s + (piece >> 2) : 0]);
 #endif
             xscale = in ? kScale : 0.0f;
         };
@@ -351,6 +359,38 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
     });
     __syncthreads();
     layer_resident(kd.w2t + (size_t)m * nb1 * s2 * 2 * kFrag, s2, nb1, n1, w, lane, actB, acc1, acc2);
+    if (g.dx_partial) {
+        // Few input columns (the AEV blocks of the species the molecule has: x_groups): this member's share of dE/dx,
+        // W0_m^T d1, is one more small product on the spot -- d1 goes to region A like d2 went to region B -- instead of a
+        // round trip of d1 through memory and a launch that streams W0^T of every member past every tile.
+        for_blocks(n1, w, [&](int j, int rb) {
+#pragma unroll
+            for (int cb = 0; cb < kCB; cb++) {
+                f32x4 d;
+#pragma unroll
+                for (int q = 0; q < 4; q++) d[q] = fmaf(kLoInv, acc2[j][cb][q], acc1[j][cb][q]) * c1[j][cb][q];      // d1 / 16
+                put_fragment(actA, rb, cb, lane, d);
+            }
+        });
+        __syncthreads();
+        const int nbf = (g.F + 15) >> 4, nf = blocks_of_wave(nbf, w);
+        layer_resident(kd.w0tm + (size_t)m * nbf * s1 * 2 * kFrag, s1, nbf, nf, w, lane, actA, acc1, acc2);
+        float* pdst = g.dx_partial + ((size_t)m * g.n_grouped + kd.first + r0) * g.F;
+        for_blocks(nf, w, [&](int j, int rb) {
+            const int col = rb * 16 + kgD * 4;
+            if (col >= g.F) return;
+#pragma unroll
+            for (int cb = 0; cb < kCB; cb++) {
+                const int r = cb * 16 + a16;
+                if (r0 + r >= kd.n) continue;
+                float4 v;
+                v.x = fmaf(kLoInv, acc2[j][cb][0], acc1[j][cb][0]); v.y = fmaf(kLoInv, acc2[j][cb][1], acc1[j][cb][1]);
+                v.z = fmaf(kLoInv, acc2[j][cb][2], acc1[j][cb][2]); v.w = fmaf(kLoInv, acc2[j][cb][3], acc1[j][cb][3]);
+                *reinterpret_cast<float4*>(pdst + (size_t)r * g.F + col) = v;
+            }
+        });
+        return;
+    }
     _Float16* d1 = kd.d1 + ((size_t)(tile * g.M + m) * s1) * (kCB * 2 * kFrag);
     for_blocks(n1, w, [&](int j, int rb) {
 #pragma unroll
@@ -437,8 +477,17 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_input_grad(const MlpArgs g) {
     }
     const float up = (g.upstream ? *g.upstream : 1.0f) * g.dx_scale;
     const int kgD = lane >> 4, a16 = lane & 15;
-    const int col = rb * 16 + kgD * 4;
-    if (mine && col < g.F) {                                 // (F is a multiple of 4)
+    if (chunk == 0 && g.num_dead > 0) {                      // column blocks no network reads: their gradient is zero
+        const int per_row = g.num_dead * 4;
+        for (int q = tid; q < kTile * per_row; q += kThreads) {
+            const int r = r0 + q / per_row, e = q % per_row;
+            if (r < kd.n)
+                *reinterpret_cast<float4*>(g.dx + (size_t)g.rows[kd.first + r] * g.lddx + 16 * g.dead_groups[e >> 2] + 4 * (e & 3)) =
+                    make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const int col = 16 * (g.x_groups ? g.x_groups[min(rb, nbf - 1)] : rb) + kgD * 4;
+    if (mine && rb * 16 + kgD * 4 < g.F) {                   // (F is a multiple of 4)
 #pragma unroll
         for (int cb = 0; cb < kCB; cb++) {
             const int r = r0 + cb * 16 + a16;
@@ -449,6 +498,77 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_input_grad(const MlpArgs g) {
             v.z = (acc1[cb][2] + kLoInv * acc2[cb][2]) * kUnscale * up;
             v.w = (acc1[cb][3] + kLoInv * acc2[cb][3]) * kUnscale * up;
             *reinterpret_cast<float4*>(g.dx + (size_t)g.rows[kd.first + r] * g.lddx + col) = v;
+        }
+    }
+}
+
+// (value per thread: a sum over the elements i = tid, tid + 1024, ... whatever the width of the workgroup that calls it -- a
+//  narrower one walks several of those strides -- so the result does not depend on which kernel took the mean)
+template <int THREADS>
+__device__ __forceinline__ void energy_mean_block(const float* __restrict__ v, long n, float scale, float* __restrict__ out,
+                                                  const double* __restrict__ shift, double* __restrict__ out_shifted, double* red) {
+    static_assert(1024 % THREADS == 0 && THREADS % 64 == 0, "");
+    constexpr int SUBS = 1024 / THREADS, AHEAD = 8;
+    double acc[SUBS];
+#pragma unroll
+    for (int q = 0; q < SUBS; q++) acc[q] = 0.0;
+    for (long base = 0; base < n; base += 1024L * AHEAD) {             // (loads of a round issued together, added in index order)
+        float t[SUBS][AHEAD];
+#pragma unroll
+        for (int q = 0; q < SUBS; q++)
+#pragma unroll
+            for (int k = 0; k < AHEAD; k++) {
+                const long i = base + 1024L * k + q * THREADS + threadIdx.x;
+                const float x = v[min(i, n - 1)];                       // (a load behind a branch would be waited for on the spot)
+                t[q][k] = i < n ? x : 0.0f;
+            }
+#pragma unroll
+        for (int q = 0; q < SUBS; q++)
+#pragma unroll
+            for (int k = 0; k < AHEAD; k++) acc[q] += (double)t[q][k];
+    }
+#pragma unroll
+    for (int q = 0; q < SUBS; q++) {                                   // the 1024 strided partial sums, THREADS at a time
+        double a = acc[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+        const int sub = q * THREADS + threadIdx.x;
+        if ((sub & 63) == 0) red[sub >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int w = 0; w < 1024 / 64; w++) e += red[w];
+        const float mean = (float)(e * (double)scale);
+        if (shift) out_shifted[0] = (double)mean + shift[0];
+        else out[0] = mean;
+    }
+}
+
+// dx = scale * sum over the members of dx_partial (what mlp_forward left when the frame carries dx_partial), written to the
+// columns the feature blocks live in; dead column blocks are set to zero.  One thread per (grouped atom, four columns).
+__global__ __launch_bounds__(256) void mlp_sum_members(const MlpArgs g) {
+    __shared__ double red[1024 / 64];
+    if (blockIdx.x == 0 && (g.mean_out || g.mean_out_shifted))                  // (the energy mean rides along: one launch fewer)
+        energy_mean_block<256>(g.energies, (long)g.n_grouped * g.M, g.mean_scale, g.mean_out, g.mean_shift, g.mean_out_shifted, red);
+    const int quads = g.F >> 2, per_row = quads + g.num_dead * 4;
+    const long total = (long)g.n_grouped * per_row;
+    const float up = (g.upstream ? *g.upstream : 1.0f) * g.dx_scale * kUnscale;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int r = (int)(t / per_row), e = (int)(t % per_row);
+        float* row = g.dx + (size_t)g.rows[r] * g.lddx;
+        if (e < quads) {
+            const int c = 4 * e;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int m = 0; m < g.M; m++) {                  // fixed order: bitwise reproducible
+                const float4 v = *reinterpret_cast<const float4*>(g.dx_partial + ((size_t)m * g.n_grouped + r) * g.F + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            const int grp = g.x_groups ? g.x_groups[c >> 4] : (c >> 4);
+            *reinterpret_cast<float4*>(row + 16 * grp + (c & 15)) = make_float4(acc.x * up, acc.y * up, acc.z * up, acc.w * up);
+        } else {
+            const int d = e - quads;
+            *reinterpret_cast<float4*>(row + 16 * g.dead_groups[d >> 2] + 4 * (d & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
@@ -484,19 +604,7 @@ __global__ __launch_bounds__(256) void mlp_pack(int rows, int cols, const float*
 __global__ __launch_bounds__(1024) void mlp_energy_mean(const float* __restrict__ v, long n, float scale, float* __restrict__ out,
                                                         const double* __restrict__ shift, double* __restrict__ out_shifted) {
     __shared__ double red[1024 / 64];
-    double acc = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)v[i];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double e = 0.0;
-        for (int w = 0; w < 1024 / 64; w++) e += red[w];
-        const float mean = (float)(e * (double)scale);
-        if (shift) out_shifted[0] = (double)mean + shift[0];
-        else out[0] = mean;
-    }
+    energy_mean_block<1024>(v, n, scale, out, shift, out_shifted, red);
 }
 
 // out[i] = in[i] * (float)factor[0], the factor a device scalar of either precision (the chain-rule factor autograd hands to the
@@ -518,6 +626,15 @@ int check_and_fill(const nnpops_mlp_frame* fr, MlpArgs& g, bool grad, int blocks
     g.num_kinds = fr->num_kinds; g.F = fr->num_features; g.M = fr->num_members; g.ldx = fr->ldx;
     g.x = fr->x; g.rows = fr->rows; g.energies = fr->energies; g.alpha = fr->alpha;
     g.dx = fr->dx; g.lddx = fr->lddx; g.upstream = fr->upstream; g.dx_scale = fr->dx_scale == 0.f ? 1.0f : fr->dx_scale;
+    g.x_groups = fr->x_groups; g.dead_groups = fr->dead_groups; g.num_dead = fr->dead_groups ? fr->num_dead_groups : 0;
+    g.dx_partial = grad ? fr->dx_partial : nullptr;
+    g.mean_scale = fr->mean_scale; g.mean_out = fr->mean_out; g.mean_shift = fr->mean_shift; g.mean_out_shifted = fr->mean_out_shifted;
+    NNPOPS_REQUIRE(!(fr->mean_out && fr->mean_out_shifted) && (!fr->mean_out_shifted || fr->mean_shift), "one energy mean: float, or shifted double with its shift");
+    NNPOPS_REQUIRE(!fr->x_groups || fr->num_features % 16 == 0, "x_groups maps blocks of 16 features: the feature count must be a multiple of 16 (got %d)",
+                   fr->num_features);
+    NNPOPS_REQUIRE(fr->num_dead_groups >= 0 && (fr->num_dead_groups == 0 || fr->dead_groups), "dead_groups is NULL");
+    NNPOPS_REQUIRE(!g.dx_partial || (fr->num_features <= 256 && fr->num_features % 16 == 0),
+                   "dx_partial (the input gradient formed by the forward launch) takes at most 256 features in blocks of 16 (got %d)", fr->num_features);
     int blocks = 0, first = 0;
     for (int k = 0; k < fr->num_kinds; k++) {
         const nnpops_mlp_kind& s = fr->kinds[k];
@@ -526,17 +643,20 @@ int check_and_fill(const nnpops_mlp_frame* fr, MlpArgs& g, bool grad, int blocks
         for (int h : {s.h1, s.h2, s.h3})
             NNPOPS_REQUIRE(h >= 32 && h <= 256 && h % 32 == 0, "packed layer widths must be multiples of 32 in 32..256 (got %d)", h);
         NNPOPS_REQUIRE(s.w0 && s.w2 && s.w4 && s.b0 && s.b2 && s.b4 && s.w6 && s.b6, "NULL weight pointer (kind %d)", k);
-        NNPOPS_REQUIRE(!grad || (s.w4t && s.w2t && s.w0t && s.d1), "gradient pass needs the transposed planes and the d1 workspace (kind %d)", k);
+        NNPOPS_REQUIRE(!grad || (s.w4t && s.w2t && (fr->dx_partial || (s.w0t && s.d1))), "gradient pass needs the transposed planes and the d1 workspace (kind %d)", k);
         d.n = s.num_atoms; d.first = first; d.h1 = s.h1; d.h2 = s.h2; d.h3 = s.h3;
         d.tiles = (s.num_atoms + kTile - 1) / kTile;
         d.block0 = blocks;
         d.w0 = (const _Float16*)s.w0; d.w2 = (const _Float16*)s.w2; d.w4 = (const _Float16*)s.w4;
         d.w4t = (const _Float16*)s.w4t; d.w2t = (const _Float16*)s.w2t; d.w0t = (const _Float16*)s.w0t;
         d.b0 = s.b0; d.b2 = s.b2; d.b4 = s.b4; d.w6 = s.w6; d.b6 = s.b6; d.d1 = (_Float16*)s.d1;
+        d.w0tm = (const _Float16*)s.w0tm;
+        NNPOPS_REQUIRE(!g.dx_partial || s.w0tm, "dx_partial needs the member-by-member planes w0tm (kind %d)", k);
         blocks += d.tiles * blocks_per_tile_grad;
         first += s.num_atoms;
     }
     for (int k = fr->num_kinds; k < NNPOPS_MLP_MAX_KINDS; k++) g.kinds[k] = g.kinds[0];
+    g.n_grouped = first;
     *total_blocks = blocks;
     return NNPOPS_OK;
 }
@@ -569,7 +689,7 @@ int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gra
     int rc = check_and_fill(frame, g, with_gradient != 0, frame ? frame->num_members : 1, &blocks);
     if (rc != NNPOPS_OK) return rc;
     if (blocks == 0) return NNPOPS_OK;
-    const size_t lds = 2 * kStageBytes + 2 * kActBytes;      // 144 KiB: above the default limit of dynamic LDS, raised per device
+    const size_t lds = 2 * kStageBytes + 2 * kActBytes + 256;    // 144 KiB (+ the column-block table): above the default limit of dynamic LDS, raised per device
     if (with_gradient) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (with_gradient) hipLaunchKernelGGL(mlp_forward<true>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
@@ -615,6 +735,12 @@ int nnpops_mlp_input_grad(void* stream, const nnpops_mlp_frame* frame) {
     int rc = check_and_fill(frame, g, true, chunks, &blocks);
     if (rc != NNPOPS_OK) return rc;
     if (blocks == 0) return NNPOPS_OK;
+    if (g.dx_partial) {                                      // the forward launch has formed every member's share: add them up
+        const long total = (long)g.n_grouped * ((g.F >> 2) + g.num_dead * 4);
+        hipLaunchKernelGGL(mlp_sum_members, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, g);
+        NNPOPS_HIP_TRY(hipGetLastError());
+        return NNPOPS_OK;
+    }
     hipLaunchKernelGGL(mlp_input_grad, dim3(blocks), dim3(kThreads), 2 * kStageBytes, (hipStream_t)stream, g);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;

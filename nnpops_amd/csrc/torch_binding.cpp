@@ -64,7 +64,9 @@ bool stream_is_capturing(void* stream) {
 // The atomic networks of a frame on nnpops_mlp_forward / nnpops_mlp_input_grad (mlp_fused.hip).  The packed parameters
 // travel as two flat buffers (what nnpops_amd/BatchedNN.py::_FusedSpeciesNN registers): per kind, one after the other,
 //   planes (fp16): w0 (M members) | w2 (M) | w4 (M) | w4t (M) | w2t (M) | w0t          floats: b0 | b2 | b4 | w6 | b6
-// with the packed widths h1, h2, h3 of every kind in `widths` (multiples of 32).
+// with the packed widths h1, h2, h3 of every kind in `widths` (multiples of 32).  With x_blocks (the 16-column blocks of x
+// the networks are packed over, nnpops_hip.h: x_groups) the first layer's planes are that narrow, and when they hold at most
+// 256 columns every kind carries one more set, w0tm (M), behind w0t: the forward launch then forms the input gradient itself.
 // ---------------------------------------------------------------------------------------------
 struct MlpCall {
     nnpops_mlp_frame frame{};
@@ -75,10 +77,20 @@ struct MlpCall {
 int64_t mlp_halves(int64_t rows, int64_t cols) { return nnpops_mlp_packed_halves((int)rows, (int)cols); }
 
 MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64_t>& kind_atoms, const std::vector<int64_t>& widths,
-                    int64_t members, const Tensor& planes, const Tensor& floats, bool with_gradient) {
+                    int64_t members, const Tensor& planes, const Tensor& floats, bool with_gradient,
+                    const c10::optional<Tensor>& x_blocks = c10::nullopt, const c10::optional<Tensor>& dead_blocks = c10::nullopt) {
     TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.scalar_type() == torch::kFloat32 && x.is_contiguous(),
                 "the fused networks take a contiguous [atoms, features] float32 device tensor");
-    const int64_t kinds = (int64_t)kind_atoms.size(), F = x.size(1), atoms = x.size(0);
+    const bool narrow = x_blocks.has_value() && x_blocks->numel() > 0;
+    const int64_t kinds = (int64_t)kind_atoms.size(), atoms = x.size(0), F = narrow ? 16 * x_blocks->numel() : x.size(1);
+    if (narrow) {
+        TORCH_CHECK(x.size(1) % 16 == 0 && F <= x.size(1), "x_blocks: blocks of 16 columns of a [atoms, multiple of 16] array");
+        for (const Tensor* t : {&*x_blocks, dead_blocks.has_value() ? &*dead_blocks : &*x_blocks})
+            TORCH_CHECK(t->scalar_type() == torch::kInt32 && t->is_contiguous() && t->device() == x.device(), "column block lists must be int32 on the device of x");
+        TORCH_CHECK(dead_blocks.has_value() && x_blocks->numel() + dead_blocks->numel() == x.size(1) / 16,
+                    "x_blocks and dead_blocks together must list every 16-column block of x once");
+    }
+    const bool in_forward = narrow && with_gradient && F <= 256;
     TORCH_CHECK(kinds >= 1 && kinds <= NNPOPS_MLP_MAX_KINDS && (int64_t)widths.size() == 3 * kinds, "1..", NNPOPS_MLP_MAX_KINDS, " kinds, three widths each");
     TORCH_CHECK(rows.scalar_type() == torch::kInt32 && rows.is_contiguous() && rows.device() == x.device() && rows.numel() == atoms,
                 "rows must be an int32 permutation of the atoms on the device of x");
@@ -88,7 +100,17 @@ MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64
     MlpCall c;
     nnpops_mlp_frame& fr = c.frame;
     fr.num_kinds = (int)kinds; fr.num_features = (int)F; fr.num_members = (int)members;
-    fr.x = x.data_ptr<float>(); fr.ldx = (int)F; fr.rows = rows.data_ptr<int32_t>(); fr.alpha = 0.1f;       // BatchedNN.py:103
+    fr.x = x.data_ptr<float>(); fr.ldx = (int)x.size(1); fr.rows = rows.data_ptr<int32_t>(); fr.alpha = 0.1f;       // BatchedNN.py:103
+    if (narrow) {
+        fr.x_groups = x_blocks->data_ptr<int32_t>();
+        fr.dead_groups = dead_blocks->numel() ? dead_blocks->data_ptr<int32_t>() : nullptr;
+        fr.num_dead_groups = (int)dead_blocks->numel();
+    }
+    if (in_forward) {
+        Tensor partial = torch::empty({members, atoms, F}, x.options());
+        fr.dx_partial = partial.data_ptr<float>();
+        c.keep.push_back(partial);
+    }
     c.energies = torch::empty({atoms, members}, x.options());
     fr.energies = c.energies.data_ptr<float>();
     const at::Half* ph = planes.data_ptr<at::Half>();
@@ -105,12 +127,13 @@ MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64
         kd.w4t = ph + oh; oh += M * mlp_halves(h2, h3);
         kd.w2t = ph + oh; oh += M * mlp_halves(h1, h2);
         kd.w0t = ph + oh; oh += mlp_halves(F, M * h1);
+        if (narrow && F <= 256) { kd.w0tm = ph + oh; oh += M * mlp_halves(F, h1); }
         kd.b0 = pf + of; of += M * h1;
         kd.b2 = pf + of; of += M * h2;
         kd.b4 = pf + of; of += M * h3;
         kd.w6 = pf + of; of += M * h3;
         kd.b6 = pf + of; of += M;
-        if (with_gradient) {
+        if (with_gradient && !in_forward) {
             Tensor d1 = torch::empty({std::max<int64_t>(nnpops_mlp_d1_halves((int)kind_atoms[k], (int)M, (int)h1), 1)}, planes.options());
             kd.d1 = d1.data_ptr();
             c.keep.push_back(d1);
@@ -405,7 +428,8 @@ public:
     // (EnergyShifter.py:52); with it the energy comes back in double precision, promoted and shifted as the reference does it.
     static Tensor forward(AutogradContext* ctx, const HolderPtr& holder, const Tensor& frame, const c10::optional<Tensor>& cell,
                           const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
-                          const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift, bool need_gradient) {
+                          const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift,
+                          const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks, bool need_gradient) {
         TORCH_CHECK(frame.dim() == 2 || (frame.dim() == 3 && frame.size(0) == 1), "energy(): positions must be [atoms, 3] or [1, atoms, 3]");
         const Tensor positions = frame.dim() == 3 ? frame[0] : frame;
         // (The capacity check of the AEV holder -- one host round trip per call unless set_check_interval says otherwise -- is
@@ -419,21 +443,30 @@ public:
             const Tensor aev = holder->forwardImpl(positions, cell, true, /*defer_check=*/true)[0];
             c10::hip::HIPGuard guard(aev.device().index());
             void* stream = current_stream(aev.device());
-            MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient);
+            MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks);
             if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
-            int rc;
+            // the ensemble mean (BatchedNN.py:109), shifted by the self energy when the caller hands it over: its own small launch,
+            // or -- when the input gradient is only a sum over the members (dx_partial) -- a passenger of that launch
+            const bool mean_rides = need_gradient && call.frame.dx_partial != nullptr;
             if (shift.has_value()) {
                 TORCH_CHECK(shift->scalar_type() == torch::kFloat64 && shift->device() == aev.device() && shift->numel() == 1 && shift->is_contiguous(),
                             "energy(): the self-energy shift must be one float64 on the device of the positions");
                 energy = torch::empty({1}, aev.options().dtype(torch::kFloat64));
-                rc = nnpops_mlp_energy_mean_shifted(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,
-                                                    shift->data_ptr<double>(), energy.data_ptr<double>());
             } else {
                 energy = torch::empty({1}, aev.options());
-                rc = nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f / (float)members,     // BatchedNN.py:109
-                                            energy.data_ptr<float>());
             }
-            if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+            const float mean_scale = 1.0f / (float)members;
+            if (mean_rides) {
+                call.frame.mean_scale = mean_scale;
+                if (shift.has_value()) { call.frame.mean_shift = shift->data_ptr<double>(); call.frame.mean_out_shifted = energy.data_ptr<double>(); }
+                else call.frame.mean_out = energy.data_ptr<float>();
+            } else {
+                const int rc = shift.has_value()
+                    ? nnpops_mlp_energy_mean_shifted(stream, call.energies.data_ptr<float>(), call.energies.numel(), mean_scale,
+                                                     shift->data_ptr<double>(), energy.data_ptr<double>())
+                    : nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), mean_scale, energy.data_ptr<float>());
+                if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+            }
             if (need_gradient) {
                 Tensor daev = torch::empty_like(aev);
                 call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = 1.0f / (float)members;
@@ -464,15 +497,15 @@ public:
                                    g.scalar_type() == torch::kFloat64 ? 1 : 0, out.data_ptr<float>()) != NNPOPS_OK)
             raise_last("NNPOpsANISymmetryFunctions::energy (backward)");
         if (ctx->saved_data["lead"].toBool()) out = out.unsqueeze(0);
-        return {Tensor(), out, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {Tensor(), out, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
 Tensor energy(const c10::optional<HolderPtr>& holder, const Tensor& positions, const c10::optional<Tensor>& cell, const Tensor& rows,
               std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members, const Tensor& planes, const Tensor& floats,
-              const c10::optional<Tensor>& shift) {
+              const c10::optional<Tensor>& shift, const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks) {
     const bool need = torch::GradMode::is_enabled() && positions.requires_grad();
-    return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, shift, need);
+    return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks, dead_blocks, need);
 }
 
 TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
@@ -489,7 +522,7 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
     m.def("operation", operation);
     m.def("aev", aev);
     m.def("energy(__torch__.torch.classes.NNPOpsANISymmetryFunctions.Holder? holder, Tensor positions, Tensor? cell, Tensor rows, int[] kind_atoms, "
-          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None) -> Tensor", energy);
+          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None, Tensor? x_blocks=None, Tensor? dead_blocks=None) -> Tensor", energy);
 }
 
 }  // namespace ANISymmetryFunctions

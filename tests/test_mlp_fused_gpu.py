@@ -147,3 +147,47 @@ def test_shifted_energy_mean_and_scale_by_scalar():
     values = torch.randn(1001, 3, generator=gen).to(DEV)
     for factor in (torch.tensor([2.5000001], device=DEV), torch.tensor([-0.3333333333333], dtype=torch.float64, device=DEV)):
         assert torch.equal(capi.scale_by_scalar(values, factor), values * factor.float())
+
+
+@pytest.mark.parametrize("live", [[0, 3, 7, 10, 13, 40, 41, 62], [0, 1, 2, 5, 6, 9, 11, 12, 13, 20, 21, 30, 31, 33, 34, 50, 51, 60], list(range(63))])
+def test_networks_over_the_live_column_blocks_only(live):
+    """nnpops_mlp_frame::x_groups / dead_groups / dx_partial (include/nnpops_hip.h): with the AEV blocks of absent species zero, the
+    networks packed over the live 16-column blocks give the energies and the input gradient of the networks packed over all 1008
+    columns up to the ORDER of the fp32 additions (the live columns share K steps differently; the skipped terms are exact
+    zeros): 1e-6 of the largest value, far inside the bars against the float64 reference; the gradient is zero in the dead
+    columns.  With the gradient formed inside the forward launch (<= 256 live columns: 8 blocks), by the separate launch
+    (18 blocks = 288 columns), and with every block live (the identity map: then bit for bit)."""
+    from nnpops_amd.capi import FusedMLP
+    gen = torch.Generator().manual_seed(17)
+    F, n = 1008, 150
+    kinds_host = []
+    for s, (widths, atoms) in enumerate((((256, 192, 160), range(0, n, 3)), ((192, 160, 128), [a for a in range(n) if a % 3]))):
+        kd = _networks(widths, 3, F, seed=40 + s)
+        kd["atoms"] = torch.tensor(list(atoms), dtype=torch.int32)
+        kinds_host.append(kd)
+    x = torch.zeros(n, F)
+    for g in live:
+        x[:, 16 * g:16 * g + 16] = torch.rand(n, 16, generator=gen)
+    kinds_dev = [{k: v.to(DEV) for k, v in kd.items()} for kd in kinds_host]
+    full = FusedMLP(kinds_dev, F)
+    part = FusedMLP(kinds_dev, F, live_groups=live)
+    assert (getattr(part, "dx_partial", None) is not None) == (16 * len(live) <= 256)
+    xd = x.to(DEV)
+    e_full = full.forward(xd, with_gradient=True).clone()
+    dx_full = full.input_grad(xd, scale=0.5)
+    e_part = part.forward(xd, with_gradient=True).clone()
+    dx_part = part.input_grad(xd, out=torch.full((n, F), float("nan"), device=DEV), scale=0.5)
+    identity = len(live) == F // 16
+    assert torch.equal(e_full, e_part) if identity else float((e_full - e_part).abs().max()) <= 1e-6 * float(e_full.abs().max())
+    dead = [g for g in range(F // 16) if g not in live]
+    for g in dead:
+        assert bool((dx_part[:, 16 * g:16 * g + 16] == 0).all())
+    cols = torch.tensor([16 * g + c for g in live for c in range(16)], device=DEV)
+    ref = dx_full[:, cols]
+    if identity:
+        assert torch.equal(dx_part, dx_full)
+    assert float((dx_part[:, cols] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    e_ref, dx_ref = _host_reference(kinds_host, x)
+    assert float((dx_part.cpu().double() - 0.5 * dx_ref)[:, cols.cpu()].abs().max()) <= 1e-4 * float(dx_ref.abs().max())
+    assert torch.equal(part.forward(xd, with_gradient=False), e_part)
+    assert float((e_part.cpu().double() - e_ref).abs().max()) <= 1e-5 * float(e_ref.abs().max())
