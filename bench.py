@@ -711,6 +711,12 @@ def run_torchani(args, R):
     flops_fwd = 2.0 * 8 * sum(macs[int(s)] for s in species)
     nn_weight_bytes = sum(b.numel() * 4 for name, b in opt.neural_networks.named_buffers() if "layer" in name)
     tflops = 2 * flops_fwd / elapsed * steps / 1e12
+    # what is actually multiplied: inside the one-node step the networks run over the AEV column blocks this molecule's species
+    # can fill (water: H and O of the 7 species -> 128 of the 1008 columns; the others are identically zero), DESIGN.md s3.8c
+    nets0 = opt.neural_networks[0]
+    live_cols = 16 * int(nets0.x_blocks.numel()) if one_node and hasattr(nets0, "x_blocks") and nets0.x_blocks.numel() else 1008
+    macs_live = {s: live_cols * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}
+    tflops_issued = 3 * 2 * 2.0 * 8 * sum(macs_live[int(s)] for s in species) / elapsed * steps / 1e12
     split = args.nn_layout in ("fused", "gemm")
     kernel_name = {"fused": "mlp_forward + mlp_input_grad (mlp_fused.hip: a 64-atom tile of one species and one member through all "
                             "four layers in one workgroup, activations in LDS / registers)",
@@ -726,16 +732,20 @@ def run_torchani(args, R):
                                f"random weights, BatchedNN layout = {args.nn_layout}, "
                                + ("AEV + networks as one autograd node (8 launches per energy+forces step)" if one_node else "four-module composition")
                                + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
-                   "nn_weight_bytes": nn_weight_bytes, "nn_layout": args.nn_layout, "one_autograd_node": one_node},
+                   "nn_weight_bytes": nn_weight_bytes, "nn_layout": args.nn_layout, "one_autograd_node": one_node,
+                   "aev_columns": 1008, "aev_columns_multiplied": live_cols},
         "ms_per_step_without_capacity_check": (round(no_check_ms, 4) if no_check_ms is not None else None),
         "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",
                      "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,
-                     "issued": ({"instruction": "v_mfma_f32_16x16x32_f16, 3 products per fp32 product", "tflops": round(3 * tflops, 2),
-                                 "peak": F16_DENSE_PEAK, "frac": round(3 * tflops / F16_DENSE_PEAK, 5)} if split else None),
+                     "issued": ({"instruction": "v_mfma_f32_16x16x32_f16, 3 products per fp32 product, over the live AEV columns only",
+                                 "tflops": round(tflops_issued, 2), "peak": F16_DENSE_PEAK,
+                                 "frac": round(tflops_issued / F16_DENSE_PEAK, 5)} if split else None),
                      "note": "whole step time (neighbour search + AEV + networks, forward and backward) against the NETWORKS' algorithmic "
-                             "flops; `frac` is against the fp32 matrix peak the reference's arithmetic would be priced at, `issued` against "
-                             "the dense fp16 peak of the instruction actually issued"},
+                             "flops -- the reference's dense product over all 1008 AEV columns; `frac` is against the fp32 matrix peak that "
+                             "arithmetic would be priced at; `issued` counts what this implementation multiplies (the columns of absent "
+                             "species are structurally zero and skipped: config.aev_columns_multiplied) against the dense fp16 peak of the "
+                             "instruction actually issued"},
     }
     if not args.no_cpu_baseline:
         # the reference CPU AEV op (single thread) + BatchedLinear on the CPU.  The AEV leg is the
