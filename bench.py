@@ -649,15 +649,15 @@ def run_torchani(args, R):
         tpos.grad = None
         energy = opt((numbers, tpos), cell, pbc).energies
         energy.sum().backward()
-        return energy
+        return energy.detach()          # (not the autograd graph: one kept alive from an eager step breaks a later stream capture)
 
     steps, warm = min(args.steps, 200), min(args.warmup, 20)
     for _ in range(max(warm, 3)):
         step()
     torch.cuda.synchronize()
-    if args.graph:
-        # the whole energy+forces step as one HIP graph (the AEV holder skips its capacity check while capturing;
-        # capacities were calibrated by the warm-up steps above): removes the ~70 host launches per step
+    def replay_as_graph():
+        """the whole energy+forces step as one HIP graph (the AEV holder skips its capacity check while capturing; capacities were
+        calibrated by the warm-up steps above): removes the host's ~10 launches and its interpreter / autograd time per step"""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -670,7 +670,7 @@ def run_torchani(args, R):
             g_energy = opt((numbers, tpos), cell, pbc).energies
             g_forces = torch.autograd.grad(g_energy.sum(), tpos)[0]
         torch.cuda.synchronize()
-        eager_e = step().detach().clone()
+        eager_e = step().clone()
         eager_g = tpos.grad.detach().clone()
         graph.replay()
         torch.cuda.synchronize()
@@ -679,9 +679,12 @@ def run_torchani(args, R):
         for _ in range(steps):
             graph.replay()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        energy = g_energy
-        tpos.grad = g_forces
+        return time.perf_counter() - t0, g_energy, g_forces
+
+    graph_ms = None
+    if args.graph:
+        elapsed, energy, forces = replay_as_graph()
+        tpos.grad = forces
     else:
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -705,6 +708,10 @@ def run_torchani(args, R):
         (opt if one_node else opt.aev_computer).set_check_interval(1)
         step()                                               # (raises if a neighbour buffer had overflowed)
         torch.cuda.synchronize()
+        try:                                                 # ... and the same step replayed as a HIP graph (device time, no host in the loop)
+            graph_ms = 1e3 * replay_as_graph()[0] / steps
+        except Exception as exc:                             # noqa: BLE001 -- a figure beside the line, not the line
+            print(f"bench: graph replay of the torchani step failed: {exc!r}", file=sys.stderr)
     # NN flops: 2 * models * sum over atoms of the MACs of its network; backward to the
     # inputs costs the same again
     macs = {s: 1008 * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}
@@ -735,6 +742,7 @@ def run_torchani(args, R):
                    "nn_weight_bytes": nn_weight_bytes, "nn_layout": args.nn_layout, "one_autograd_node": one_node,
                    "aev_columns": 1008, "aev_columns_multiplied": live_cols},
         "ms_per_step_without_capacity_check": (round(no_check_ms, 4) if no_check_ms is not None else None),
+        "ms_per_step_as_hip_graph": (round(graph_ms, 4) if graph_ms is not None else None),
         "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",
                      "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,
