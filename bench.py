@@ -681,7 +681,7 @@ def run_torchani(args, R):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, g_energy, g_forces
 
-    graph_ms = None
+    graph_ms = dense_graph_ms = None
     if args.graph:
         elapsed, energy, forces = replay_as_graph()
         tpos.grad = forces
@@ -712,6 +712,21 @@ def run_torchani(args, R):
             graph_ms = 1e3 * replay_as_graph()[0] / steps
         except Exception as exc:                             # noqa: BLE001 -- a figure beside the line, not the line
             print(f"bench: graph replay of the torchani step failed: {exc!r}", file=sys.stderr)
+        # ... and what the step costs when the networks multiply ALL 1008 AEV columns, the identically-zero blocks of absent species
+        # included, as the reference's dense BatchedLinear does (OptimizedTorchANI(live_columns=False))
+        nets_live = opt.neural_networks[0]
+        if one_node and graph_ms is not None and hasattr(nets_live, "x_blocks") and nets_live.x_blocks.numel():
+            live_opt = opt
+            try:
+                opt = OptimizedTorchANI(model, numbers.cpu(), nn_layout=args.nn_layout, live_columns=False).to(dev)
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                dense_graph_ms = 1e3 * replay_as_graph()[0] / steps
+            except Exception as exc:                         # noqa: BLE001
+                print(f"bench: dense-networks variant of the torchani step failed: {exc!r}", file=sys.stderr)
+            finally:
+                opt = live_opt
     # NN flops: 2 * models * sum over atoms of the MACs of its network; backward to the
     # inputs costs the same again
     macs = {s: 1008 * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}
@@ -743,6 +758,7 @@ def run_torchani(args, R):
                    "aev_columns": 1008, "aev_columns_multiplied": live_cols},
         "ms_per_step_without_capacity_check": (round(no_check_ms, 4) if no_check_ms is not None else None),
         "ms_per_step_as_hip_graph": (round(graph_ms, 4) if graph_ms is not None else None),
+        "ms_per_step_as_hip_graph_with_dense_networks": (round(dense_graph_ms, 4) if dense_graph_ms is not None else None),
         "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",
                      "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,
