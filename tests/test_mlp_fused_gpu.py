@@ -149,7 +149,8 @@ def test_shifted_energy_mean_and_scale_by_scalar():
         assert torch.equal(capi.scale_by_scalar(values, factor), values * factor.float())
 
 
-@pytest.mark.parametrize("live", [[0, 3, 7, 10, 13, 40, 41, 62], [0, 1, 2, 5, 6, 9, 11, 12, 13, 20, 21, 30, 31, 33, 34, 50, 51, 60], list(range(63))])
+@pytest.mark.parametrize("live", [[0, 3, 7, 10, 13, 40, 41, 62], [0, 1, 2, 5, 6, 9, 11, 12, 13, 20, 21, 30, 31, 33, 34, 50, 51, 60], list(range(63)),
+                                  [5], [62, 0, 31], list(range(1, 63, 4)), list(range(0, 63, 3)) + [61]])
 def test_networks_over_the_live_column_blocks_only(live):
     """nnpops_mlp_frame::x_groups / dead_groups / dx_partial (include/nnpops_hip.h): with the AEV blocks of absent species zero, the
     networks packed over the live 16-column blocks give the energies and the input gradient of the networks packed over all 1008
