@@ -690,8 +690,17 @@ int nnpops_mlp_forward(void* stream, const nnpops_mlp_frame* frame, int with_gra
     if (rc != NNPOPS_OK) return rc;
     if (blocks == 0) return NNPOPS_OK;
     const size_t lds = 2 * kStageBytes + 2 * kActBytes + 256;    // 144 KiB (+ the column-block table): above the default limit of dynamic LDS, raised per device
-    if (with_gradient) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {   // (once per device and kernel: the attribute is sticky, and the call is not free on the launch path)
+        static bool raised[2][64] = {};
+        int dev = 0;
+        NNPOPS_HIP_TRY(hipGetDevice(&dev));
+        bool& done = raised[with_gradient ? 1 : 0][dev & 63];
+        if (!done || dev >= 64) {
+            if (with_gradient) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            else NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+    }
     if (with_gradient) hipLaunchKernelGGL(mlp_forward<true>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(mlp_forward<false>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, g);
     NNPOPS_HIP_TRY(hipGetLastError());
