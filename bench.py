@@ -681,7 +681,7 @@ def run_torchani(args, R):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, g_energy, g_forces
 
-    graph_ms = dense_graph_ms = None
+    graph_ms = dense_graph_ms = call_ms = None
     if args.graph:
         elapsed, energy, forces = replay_as_graph()
         tpos.grad = forces
@@ -712,6 +712,19 @@ def run_torchani(args, R):
             graph_ms = 1e3 * replay_as_graph()[0] / steps
         except Exception as exc:                             # noqa: BLE001 -- a figure beside the line, not the line
             print(f"bench: graph replay of the torchani step failed: {exc!r}", file=sys.stderr)
+        # ... and as ONE call outside autograd (FusedOptimizedTorchANI.energy_and_forces: what an MD driver that takes the forces as
+        # a model output runs -- no .sum() / backward(), no autograd engine)
+        if one_node:
+            tp = tpos.detach()
+            for _ in range(3):
+                opt.energy_and_forces((numbers, tp), cell, pbc)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                e_call, f_call = opt.energy_and_forces((numbers, tp), cell, pbc)
+            torch.cuda.synchronize()
+            call_ms = 1e3 * (time.perf_counter() - t1) / steps
+            assert bool(torch.isfinite(e_call).all()) and bool(torch.isfinite(f_call).all())
         # ... and what the step costs when the networks multiply ALL 1008 AEV columns, the identically-zero blocks of absent species
         # included, as the reference's dense BatchedLinear does (OptimizedTorchANI(live_columns=False))
         nets_live = opt.neural_networks[0]
@@ -758,6 +771,7 @@ def run_torchani(args, R):
                    "aev_columns": 1008, "aev_columns_multiplied": live_cols},
         "ms_per_step_without_capacity_check": (round(no_check_ms, 4) if no_check_ms is not None else None),
         "ms_per_step_as_hip_graph": (round(graph_ms, 4) if graph_ms is not None else None),
+        "ms_per_energy_and_forces_call": (round(call_ms, 4) if call_ms is not None else None),
         "ms_per_step_as_hip_graph_with_dense_networks": (round(dense_graph_ms, 4) if dense_graph_ms is not None else None),
         "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",

@@ -319,6 +319,15 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
                                                            self.num_models, self.mlp_planes, self.mlp_floats, shift, None, None)
 
+    def fused_energy_forces(self, positions: Tensor, cell: Optional[Tensor], shift: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """The same step outside autograd: (energy [1], forces = -dE/dpositions in the shape of ``positions``) from one call."""
+        if self.x_blocks.numel() > 0:
+            return torch.ops.NNPOpsANISymmetryFunctions.energy_forces(self.holder, positions, cell, self.atom_order32, self.group_sizes,
+                                                                      self.widths, self.num_models, self.live_planes, self.mlp_floats, shift,
+                                                                      self.x_blocks, self.dead_blocks)
+        return torch.ops.NNPOpsANISymmetryFunctions.energy_forces(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
+                                                                  self.num_models, self.mlp_planes, self.mlp_floats, shift, None, None)
+
 
 class _SplitGemmSpeciesNN(_SpeciesGroupedNN):
     """(Round-1/2 default, kept as ``layout='gemm'`` for comparison and for widths the fused kernels do not take.)  The
@@ -412,6 +421,9 @@ class TorchANIBatchedNN(nn.ModuleList):
 
     def fused_energy(self, positions: Tensor, cell: Optional[Tensor], shift: Optional[Tensor] = None) -> Tensor:
         return self[0].fused_energy(positions, cell, shift)
+
+    def fused_energy_forces(self, positions: Tensor, cell: Optional[Tensor], shift: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        return self[0].fused_energy_forces(positions, cell, shift)
 
     def set_check_interval(self, interval: int) -> None:
         self[0].set_check_interval(interval)

@@ -53,6 +53,22 @@ class FusedOptimizedTorchANI(OptimizedTorchANI):
         self.aev_computer.set_check_interval(interval)
         self.neural_networks.set_check_interval(interval)
 
+    @torch.jit.export
+    def energy_and_forces(self, species_coordinates: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
+                          pbc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """Extension: (energies [1], forces [1, N, 3] = -dE/dpositions) from ONE call, outside autograd -- for MD drivers that take
+        the forces as a model output instead of differentiating the energy (no autograd node, no ``.sum()`` / ``backward()``
+        around the step: the same kernels as ``forward`` + ``backward``, three small launches and the autograd engine's host time
+        fewer).  Same arguments, checks and energies as ``forward``."""
+        converted = self.species_converter(species_coordinates)
+        species, positions = converted.species, converted.coordinates
+        self.aev_computer.check_arguments(species, cell, pbc)
+        shift = self.energy_shifter.self_energies
+        if shift.dtype == torch.float64 and shift.numel() == 1 and shift.device == positions.device:
+            return self.neural_networks.fused_energy_forces(positions, cell, shift)
+        energy, forces = self.neural_networks.fused_energy_forces(positions, cell)
+        return energy + self.energy_shifter.self_energies, forces
+
     def forward(self, species_coordinates: Tuple[Tensor, Tensor], cell: Optional[Tensor] = None,
                 pbc: Optional[Tensor] = None) -> SpeciesEnergies:
         converted = self.species_converter(species_coordinates)

@@ -421,6 +421,60 @@ Tensor aev(const c10::optional<HolderPtr>& holder, const Tensor& positions, cons
 // records, no [N, 1008] gradient held by autograd between the passes.  (The reference's PME op keeps its derivatives
 // the same way, pmeCPU.cpp:161-171.)
 // ---------------------------------------------------------------------------------------------
+// One energy (+ gradient) evaluation of the frame: AEV forward, networks, and -- with a gradient -- the networks' input gradient and
+// the AEV backward.  Returns {energy [1], dE/dpositions * gradient_sign [N, 3] or undefined}.  (The capacity check of the AEV
+// holder -- one host round trip per call unless set_check_interval says otherwise -- is taken in two halves: its word is published
+// right behind the AEV forward, read after everything else has been launched.  A buffer that did overflow is grown there and the
+// step issued again.  Before: the host waited for the AEV forward, then launched the networks into an idle device; waiting at the
+// END of the step for the whole stream was worse still, 0.22 -> 0.28 ms.)
+std::pair<Tensor, Tensor> energy_step(const HolderPtr& holder, const Tensor& frame, const c10::optional<Tensor>& cell, const Tensor& rows,
+                                      const std::vector<int64_t>& kind_atoms, const std::vector<int64_t>& widths, int64_t members,
+                                      const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift,
+                                      const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks, bool need_gradient,
+                                      float gradient_sign) {
+    TORCH_CHECK(frame.dim() == 2 || (frame.dim() == 3 && frame.size(0) == 1), "energy(): positions must be [atoms, 3] or [1, atoms, 3]");
+    const Tensor positions = frame.dim() == 3 ? frame[0] : frame;
+    Tensor energy, kept;
+    for (int attempt = 0;; attempt++) {
+        TORCH_CHECK(attempt <= 8, "NNPOpsANISymmetryFunctions::energy: neighbour buffers kept overflowing");
+        const Tensor aev = holder->forwardImpl(positions, cell, true, /*defer_check=*/true)[0];
+        c10::hip::HIPGuard guard(aev.device().index());
+        void* stream = current_stream(aev.device());
+        MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks);
+        if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+        // the ensemble mean (BatchedNN.py:109), shifted by the self energy when the caller hands it over: its own small launch,
+        // or -- when the input gradient is only a sum over the members (dx_partial) -- a passenger of that launch
+        const bool mean_rides = need_gradient && call.frame.dx_partial != nullptr;
+        if (shift.has_value()) {
+            TORCH_CHECK(shift->scalar_type() == torch::kFloat64 && shift->device() == aev.device() && shift->numel() == 1 && shift->is_contiguous(),
+                        "energy(): the self-energy shift must be one float64 on the device of the positions");
+            energy = torch::empty({1}, aev.options().dtype(torch::kFloat64));
+        } else {
+            energy = torch::empty({1}, aev.options());
+        }
+        const float mean_scale = 1.0f / (float)members;
+        if (mean_rides) {
+            call.frame.mean_scale = mean_scale;
+            if (shift.has_value()) { call.frame.mean_shift = shift->data_ptr<double>(); call.frame.mean_out_shifted = energy.data_ptr<double>(); }
+            else call.frame.mean_out = energy.data_ptr<float>();
+        } else {
+            const int rc = shift.has_value()
+                ? nnpops_mlp_energy_mean_shifted(stream, call.energies.data_ptr<float>(), call.energies.numel(), mean_scale,
+                                                 shift->data_ptr<double>(), energy.data_ptr<double>())
+                : nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), mean_scale, energy.data_ptr<float>());
+            if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+        }
+        if (need_gradient) {
+            Tensor daev = torch::empty_like(aev);
+            call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = gradient_sign / (float)members;
+            if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
+            kept = holder->backwardFused(daev)[1];
+        }
+        if (!holder->finishDeferredCheck()) break;
+    }
+    return {energy, kept};
+}
+
 class EnergyFunction : public torch::autograd::Function<EnergyFunction> {
 public:
     // `frame`: positions [N, 3], or [1, N, 3] as the torchani modules pass them (the gradient comes back in the same shape: no
@@ -430,51 +484,9 @@ public:
                           const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
                           const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift,
                           const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks, bool need_gradient) {
-        TORCH_CHECK(frame.dim() == 2 || (frame.dim() == 3 && frame.size(0) == 1), "energy(): positions must be [atoms, 3] or [1, atoms, 3]");
-        const Tensor positions = frame.dim() == 3 ? frame[0] : frame;
-        // (The capacity check of the AEV holder -- one host round trip per call unless set_check_interval says otherwise -- is
-        //  taken in two halves: its copy is queued right behind the AEV forward, its answer is read after everything else has been
-        //  launched.  A buffer that did overflow is grown there and the step issued again.  Before: the host waited for the AEV
-        //  forward, then launched the networks into an idle device; waiting at the END of the step for the whole stream was
-        //  worse still, 0.22 -> 0.28 ms.)
         Tensor energy, kept;
-        for (int attempt = 0;; attempt++) {
-            TORCH_CHECK(attempt <= 8, "NNPOpsANISymmetryFunctions::energy: neighbour buffers kept overflowing");
-            const Tensor aev = holder->forwardImpl(positions, cell, true, /*defer_check=*/true)[0];
-            c10::hip::HIPGuard guard(aev.device().index());
-            void* stream = current_stream(aev.device());
-            MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks);
-            if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
-            // the ensemble mean (BatchedNN.py:109), shifted by the self energy when the caller hands it over: its own small launch,
-            // or -- when the input gradient is only a sum over the members (dx_partial) -- a passenger of that launch
-            const bool mean_rides = need_gradient && call.frame.dx_partial != nullptr;
-            if (shift.has_value()) {
-                TORCH_CHECK(shift->scalar_type() == torch::kFloat64 && shift->device() == aev.device() && shift->numel() == 1 && shift->is_contiguous(),
-                            "energy(): the self-energy shift must be one float64 on the device of the positions");
-                energy = torch::empty({1}, aev.options().dtype(torch::kFloat64));
-            } else {
-                energy = torch::empty({1}, aev.options());
-            }
-            const float mean_scale = 1.0f / (float)members;
-            if (mean_rides) {
-                call.frame.mean_scale = mean_scale;
-                if (shift.has_value()) { call.frame.mean_shift = shift->data_ptr<double>(); call.frame.mean_out_shifted = energy.data_ptr<double>(); }
-                else call.frame.mean_out = energy.data_ptr<float>();
-            } else {
-                const int rc = shift.has_value()
-                    ? nnpops_mlp_energy_mean_shifted(stream, call.energies.data_ptr<float>(), call.energies.numel(), mean_scale,
-                                                     shift->data_ptr<double>(), energy.data_ptr<double>())
-                    : nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), mean_scale, energy.data_ptr<float>());
-                if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
-            }
-            if (need_gradient) {
-                Tensor daev = torch::empty_like(aev);
-                call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = 1.0f / (float)members;
-                if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
-                kept = holder->backwardFused(daev)[1];
-            }
-            if (!holder->finishDeferredCheck()) break;
-        }
+        std::tie(energy, kept) = energy_step(holder, frame, cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks, dead_blocks,
+                                             need_gradient, 1.0f);
         if (need_gradient) {
             ctx->save_for_backward({kept});
             ctx->saved_data["lead"] = frame.dim() == 3;
@@ -508,6 +520,21 @@ Tensor energy(const c10::optional<HolderPtr>& holder, const Tensor& positions, c
     return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks, dead_blocks, need);
 }
 
+// Additive: energy AND forces (-dE/dpositions) of the frame from one call, outside autograd -- what an MD driver asks a model for
+// when it takes the forces as an output instead of differentiating the energy (the step is the one of energy() with a gradient:
+// the same launches; no autograd node, no sum / ones / scale kernels around it).
+std::tuple<Tensor, Tensor> energy_forces(const c10::optional<HolderPtr>& holder, const Tensor& positions, const c10::optional<Tensor>& cell,
+                                         const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
+                                         const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift,
+                                         const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks) {
+    torch::NoGradGuard no_grad;
+    Tensor energy, forces;
+    std::tie(energy, forces) = energy_step(*holder, positions.detach(), cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks,
+                                           dead_blocks, true, -1.0f);
+    if (positions.dim() == 3) forces = forces.unsqueeze(0);
+    return std::make_tuple(energy, forces);
+}
+
 TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
     m.class_<Holder>("Holder")
         .def(torch::init<int64_t, double, double, const std::vector<double>&, const std::vector<double>&,
@@ -523,6 +550,9 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
     m.def("aev", aev);
     m.def("energy(__torch__.torch.classes.NNPOpsANISymmetryFunctions.Holder? holder, Tensor positions, Tensor? cell, Tensor rows, int[] kind_atoms, "
           "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None, Tensor? x_blocks=None, Tensor? dead_blocks=None) -> Tensor", energy);
+    m.def("energy_forces(__torch__.torch.classes.NNPOpsANISymmetryFunctions.Holder? holder, Tensor positions, Tensor? cell, Tensor rows, int[] kind_atoms, "
+          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None, Tensor? x_blocks=None, Tensor? dead_blocks=None) -> (Tensor, Tensor)",
+          energy_forces);
 }
 
 }  // namespace ANISymmetryFunctions

@@ -573,3 +573,29 @@ def test_fused_step_regrows_its_neighbour_buffers_behind_the_deferred_check():
     torch.testing.assert_close(f1, f2, rtol=1e-4, atol=2e-5 * float(f2.abs().max()))
     e3, f3 = run(fused, 0.72)                              # and once more, now without growth: bitwise the same
     assert torch.equal(e1, e3) and torch.equal(f1, f3)
+
+
+def test_energy_and_forces_in_one_call_equals_forward_plus_backward():
+    """FusedOptimizedTorchANI.energy_and_forces (additive): the energy of forward() to the bit and the forces -dE/dpositions to the
+    bit (the same launches with the sign folded into the networks' input gradient), no autograd graph recorded; also through
+    the scripted module, and for a frame whose live AEV columns exceed 256 (five species: the separate gradient launch)."""
+    from NNPOps import OptimizedTorchANI
+    for seed, swaps in ((3, {}), (5, {4: 1, 9: 2, 33: 4})):
+        model = workloads.torchani_like_model(n_models=3, seed=seed, self_energies=[-0.5, -38.0, -54.7, -75.2, -398.1, -99.8, -460.1])
+        pos, species, box = workloads.water_box(110, seed=seed)
+        species = species.copy()
+        for at, sp in swaps.items():
+            species[at] = sp
+        numbers = _numbers(species)
+        module = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+        cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True], device=DEV)
+        p = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+        e = module((numbers, p), cell, pbc).energies
+        e.sum().backward()
+        e2, f2 = module.energy_and_forces((numbers, p.detach()), cell, pbc)
+        assert e2.grad_fn is None and f2.grad_fn is None and f2.shape == p.shape and e2.dtype == torch.float64
+        assert torch.equal(e2, e.detach()) and torch.equal(f2, -p.grad)
+        e3, f3 = torch.jit.script(module).energy_and_forces((numbers, p.detach()), cell, pbc)
+        assert torch.equal(e3, e2) and torch.equal(f3, f2)
+        with pytest.raises(ValueError, match='"pbc" has to be defined'):
+            module.energy_and_forces((numbers, p.detach()), cell, None)
