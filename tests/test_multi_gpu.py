@@ -197,3 +197,25 @@ def test_default_bench_line_carries_measured_counters():
         assert 0.05 < k["valu"]["frac"] <= 1.0 and k["valu"]["valu_per_atom"] > 100, (name, k)
     four = sum(k["traffic"] for k in roof["per_kernel"].values())            # (the step also counts the two cell-grid kernels)
     assert four <= roof["step"]["traffic"] <= four + 16 * 2 ** 20
+
+
+def test_torchani_side_line_carries_its_variants():
+    """`python bench.py --workload torchani` (shortened): config 2's line names the AEV columns the networks multiply, and
+    carries the step as an eager forward + backward, without the capacity check, replayed as a HIP graph (live and dense
+    networks) and as ONE energy_and_forces call -- the roofline line about the kernel with the most bytes, the longest one
+    named beside it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "torchani", "--steps", "30", "--warmup", "5",
+                          "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert cfg["one_autograd_node"] and cfg["aev_columns"] == 1008 and cfg["aev_columns_multiplied"] == 128      # water: H and O of 7 species
+    eager, nocheck, graph = line["ms_per_step"], line["ms_per_step_without_capacity_check"], line["ms_per_step_as_hip_graph"]
+    dense, call = line["ms_per_step_as_hip_graph_with_dense_networks"], line["ms_per_energy_and_forces_call"]
+    assert all(isinstance(v, float) and 0.02 < v < 2.0 for v in (eager, nocheck, graph, dense, call)), line
+    assert graph < dense                                     # skipping the dead columns pays on the device
+    assert line["roofline"]["issued"]["tflops"] < 3 * line["roofline"]["achieved"]      # issued flops count the live columns only
