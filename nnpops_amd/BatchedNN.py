@@ -289,7 +289,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         for w in (w4, w2):
             back = (w.abs().sum(-2).amax() * back).reshape(1)
         self.fused_ok = (bool(torch.isfinite(bound).all()) and float(bound) < 1.0e6 and bool(torch.isfinite(back).all()) and float(back) < 1.0e6
-                         and F % 8 == 0 and max(widths) <= 256 and kinds <= 8 and int(w6.shape[2]) == 1)
+                         and F % 8 == 0 and F <= 1024 and max(widths) <= 256 and kinds <= 8 and int(w6.shape[2]) == 1)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
@@ -312,6 +312,9 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         """AEV + networks of the whole frame as one autograd node (only inside OptimizedTorchANI, which hands over the AEV
         holder): positions [N, 3] or [1, N, 3] -> ensemble-mean energy [1]; with ``shift`` (the molecule's self energy, one
         float64 on the device) the energy comes back in float64, shifted as the reference's EnergyShifter does it."""
+        if not self.fused_ok:        # (a state dict loaded since construction: the weights no longer bound the fp16 operands)
+            raise RuntimeError("the loaded weights exceed the activation bound of the fused network kernels (BatchedNN.py: fused_ok); "
+                               "build the model with OptimizedTorchANI(..., fused_step=False) or nn_layout='grouped'")
         if self.x_blocks.numel() > 0:
             return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
                                                                self.num_models, self.live_planes, self.mlp_floats, shift, self.x_blocks,
@@ -321,6 +324,9 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
 
     def fused_energy_forces(self, positions: Tensor, cell: Optional[Tensor], shift: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """The same step outside autograd: (energy [1], forces = -dE/dpositions in the shape of ``positions``) from one call."""
+        if not self.fused_ok:        # (a state dict loaded since construction: the weights no longer bound the fp16 operands)
+            raise RuntimeError("the loaded weights exceed the activation bound of the fused network kernels (BatchedNN.py: fused_ok); "
+                               "build the model with OptimizedTorchANI(..., fused_step=False) or nn_layout='grouped'")
         if self.x_blocks.numel() > 0:
             return torch.ops.NNPOpsANISymmetryFunctions.energy_forces(self.holder, positions, cell, self.atom_order32, self.group_sizes,
                                                                       self.widths, self.num_models, self.live_planes, self.mlp_floats, shift,

@@ -21,7 +21,6 @@ using namespace nnpops;
 
 struct nnpops_ani {
     AniParams hp{};                 // host copy of the parameter block
-    AngularConsts ac{};             // what the angular backward kernel needs of it, passed by value (ani_kernels.h)
     AniParams* d_params = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -273,7 +272,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (!vec_ok && (mode == 1 || mode == 3)) mode++;
         const bool glds = mode == 2 || mode == 4;
         const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, glds) + 15) & ~(size_t)15;
-        void (*k)(const AniParams*, const AngularConsts, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
+        void (*k)(const AniParams*, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
                   float4*, float4*, int, int, int, const int*, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
                          : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, true>
@@ -285,7 +284,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
-        hipLaunchKernelGGL(k, dim3(div_up(N, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+        hipLaunchKernelGGL(k, dim3(div_up(N, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
                            sp.ang_order, sp.w0, sp.nw);
     } else {
@@ -303,14 +302,12 @@ template <bool TA>
 int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out, const Span& sp) {
     const int key = h->nfrp * 100 + h->nfzp;
     switch (key) {
-        case 804:  return launch_angular<TA, 8, 4>(h, forward, g, out, sp);
-#ifndef NNPOPS_ONLY_ANI2X_SHAPE      // (a development build instantiates the ANI-1x / 2x factor shape only: a quarter of the compile time)
         case 404:  return launch_angular<TA, 4, 4>(h, forward, g, out, sp);
         case 408:  return launch_angular<TA, 4, 8>(h, forward, g, out, sp);
+        case 804:  return launch_angular<TA, 8, 4>(h, forward, g, out, sp);
         case 808:  return launch_angular<TA, 8, 8>(h, forward, g, out, sp);
         case 1604: return launch_angular<TA, 16, 4>(h, forward, g, out, sp);
         case 1608: return launch_angular<TA, 16, 8>(h, forward, g, out, sp);
-#endif
         default:
             return fail(NNPOPS_ERR_UNSUPPORTED, "no angular kernel for %d x %d factors", h->hp.nFR, h->hp.nFZ);
     }
@@ -329,7 +326,7 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, cons
         if (lb > 160 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "generic angular backward needs %zu bytes of LDS (cap_angular %d)", lb, h->cap_angular);
         auto k = ani_angular_backward_pair<TA, 4, 4, 4, 1, false, true>;
         if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, h->hp.NB, (int)lb, nullptr, 0, N);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
@@ -576,19 +573,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         const int want = std::atoi(e);
         if (want == 2 && h->mfma_ok) h->forward_kernel = 2;
         else if (want != 2) { h->chunked_forward = hp.NB < 64 && want != 0; h->forward_kernel = h->chunked_forward ? 1 : 0; }
-    }
-    {   // the angular backward kernel's constants, by value: every factor slot behind the real ones holds its neutral value
-        AngularConsts& c = h->ac;
-        c.N = hp.N; c.nA = hp.nA;
-        for (int a = 0; a < kMaxFactor; a++) {
-            const bool live = !h->generic && a < hp.nFR;
-            c.fr_c[a] = live ? hp.fr_c[a] : 0.f; c.fr_rs[a] = live ? hp.fr_rs[a] : 0.f; c.fr_negeta[a] = live ? -hp.fr_eta[a] : 0.f;
-        }
-        for (int z = 0; z < 8; z++) {
-            const bool live = !h->generic && z < hp.nFZ;
-            c.fz_zeta[z] = live ? hp.fz_zeta[z] : 1.f; c.fz_cos[z] = live ? hp.fz_cos[z] : 0.f;
-            c.fz_sin[z] = live ? hp.fz_sin[z] : 0.f; c.fz_bias[z] = live ? hp.fz_bias[z] : 0.f;
-        }
     }
     if (hipMemcpy(h->d_params, &hp, sizeof(AniParams), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||

@@ -87,18 +87,6 @@ struct AniParams {
     int fwd_zero_shift;              // log2 of the lanes that zero one absent block (16 bytes each), <= 6
 };
 
-// What the angular BACKWARD kernel needs of the parameter block, passed BY VALUE in the kernel arguments.  Read through the AniParams
-// pointer, the factor constants cost every workgroup a chain of dependent scalar loads before its first useful instruction (kernel
-// argument -> pointer -> counts -> the conditionally loaded constants).  The arrays are padded on the host with the neutral value of
-// every factor slot, so the loads are unconditional and leave with the kernel arguments' own request: 15.9 -> 15.4 us at 10 000 atoms
-// (round 4, interleaved A/B against the round-3 library).  The FORWARD kernel keeps the pointer: with these 60 values as kernel
-// arguments it parks even more scalars in vector lanes and measured 17.7 -> 18.5 us.
-struct AngularConsts {
-    int N, nA;
-    float fr_c[kMaxFactor], fr_rs[kMaxFactor], fr_negeta[kMaxFactor];       // -eta log2(e), Rs, -eta; 0 behind nFR
-    float fz_zeta[8], fz_cos[8], fz_sin[8], fz_bias[8];                     // zeta (1 behind nFZ), cos / sin(thetas), 1 - zeta
-};
-
 // status words reported by nnpops_ani_check
 enum { kStatOverflow = 0, kStatMaxRow = 1, kStatMaxAngular = 2, kStatWords = 4 };
 
@@ -316,10 +304,6 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
         store_wt(tri + at, word);
         if (tri_l) tri_l[at] = word;
     }
-    // (Round 4: assembling the list in LDS -- the row mirror is dead by then -- and writing it out as ~10 wave-wide 16-byte stores
-    //  instead of 153 scattered 4-byte ones was built and measured: 19.6 -> 19.8 us, interleaved.  The 3 us this list costs the
-    //  builder (profiles/r04a_probe_10k.json) are its decode / place arithmetic and its six dependent LDS lookups per pair, not
-    //  its stores.)
 }
 
 // LDS of one builder wave: the row mirror [cap] float4 | radial scratch r, fc, species [3][cap] | radial bins

@@ -3,6 +3,7 @@
 must be measured side by side).  Every variant is a set of environment variables read at handle creation.
 
     python tools/ab.py "NNPOPS_ANI_FWD_CHUNK=128" "NNPOPS_ANI_FWD_CHUNK=192" [--atoms 10000] [--rounds 9] [--steps 40] [--species 7]
+    python tools/ab.py "LIB=tools/_ref/libnnpops_hip.so" ""      # another BUILD of the library against the current one
 """
 import argparse
 import os
@@ -33,13 +34,26 @@ def main():
     rf, af = workloads.ani2x_functions()
     tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
     handles = []
+    from nnpops_amd import capi
+    product = capi.lib()
     for v in args.variants:
         saved = dict(os.environ)
+        capi._lib = product
         for kv in v.split():
             if "=" in kv:
                 k, val = kv.split("=", 1)
-                os.environ[k] = val
+                if k == "LIB":                                 # another build of the library (an older one: no source-hash check)
+                    import ctypes as C
+                    other = C.CDLL(os.path.abspath(val))
+                    for name, (restype, argtypes) in capi.SIGNATURES.items():
+                        if hasattr(other, name):
+                            fn = getattr(other, name)
+                            fn.restype, fn.argtypes = restype, argtypes
+                    capi._lib = other
+                else:
+                    os.environ[k] = val
         sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+        capi._lib = product
         os.environ.clear(); os.environ.update(saved)
         radial = torch.empty((n, sym.radial_width), device=dev)
         angular = torch.empty((n, sym.angular_width), device=dev)

@@ -2,7 +2,8 @@
 """Upper bound on what fusion (A) of SURVEY s8f rank 1 -- AEV tiles handed to the first network layer through LDS, never
 through HBM -- could gain on BASELINE config 2 ("keep the prototype's numbers in profiles/").
 
-Builds a second copy of libnnpops_hip.so under /tmp with -DNNPOPS_PROTOTYPE_AEV_FROM_LDS: the angular forward assembles its
+Builds a second copy of libnnpops_hip.so under /tmp from a PATCHED copy of the kernel sources (PATCHES below; the product
+sources carry no prototype code): the angular forward assembles its
 rows in LDS as always but does not store them, and the fused networks take their layer-0 operand from registers instead of
 reading the [N, 1008] array.  Both kernels then do ALL of their arithmetic, LDS traffic and weight streaming and NONE of the
 AEV round trip; the difference to the product library is everything fusion (A) could remove (it would still have to pay for
@@ -22,15 +23,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+# The prototype is a PATCH applied to a temporary copy of the kernel sources (round 4: the product kernels carry no
+# prototype #ifdef any more): (anchor in the product source, replacement).  An anchor that no longer matches stops the tool.
+PATCHES = {
+    "ani_angular_mfma.h": [(
+        "                store_row16(out + 4 * q, mfma_f4{v.x, v.y, v.z, v.w}, (vec_ok >> 1) & 3);\n",
+        # the AEV rows stay in LDS (one token store per atom, never taken, keeps the work alive)
+        "                if (q == 0 && v.x == 12345.678f) store_row16(out, mfma_f4{v.x, v.y, v.z, v.w}, 0);\n")],
+    "mlp_fused.hip": [(
+        "            xraw = *reinterpret_cast<const float4*>(xsrc + 16 * xgroup[in ? 2 * s + (piece >> 2) : 0]);\n",
+        # what the kernel would cost if the AEV never came from memory: the layer-0 operand from registers
+        "            xraw = make_float4(0.25f, 0.5f, 0.75f, 1.0f);\n")],
+}
+
+
 def build_variant(workdir):
+    import shutil
     from nnpops_amd import build as hb
+    src_dir = os.path.join(workdir, "nnpops_amd", "csrc")      # (host_common.h includes ../../include/nnpops_hip.h)
+    shutil.copytree(hb.CSRC, src_dir, ignore=shutil.ignore_patterns("_obj"))
+    os.makedirs(os.path.join(workdir, "include"), exist_ok=True)
+    shutil.copy(os.path.join(ROOT, "include", "nnpops_hip.h"), os.path.join(workdir, "include", "nnpops_hip.h"))
+    for name, edits in PATCHES.items():
+        path = os.path.join(src_dir, name)
+        text = open(path).read()
+        for anchor, replacement in edits:
+            assert text.count(anchor) == 1, f"prototype patch: anchor not found exactly once in {name}"
+            text = text.replace(anchor, replacement)
+        open(path, "w").write(text)
     objs = []
     procs = []
-    for src in hb._sources():
-        obj = os.path.join(workdir, os.path.basename(src) + ".o")
+    for unit in hb.UNITS:
+        src = os.path.join(src_dir, unit)
+        obj = os.path.join(workdir, unit + ".o")
         objs.append(obj)
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                                       f'-DNNPOPS_SOURCE_HASH="{hb.source_hash()}"', "-DNNPOPS_PROTOTYPE_AEV_FROM_LDS=1", "-c", src, "-o", obj]))
+                                       f'-DNNPOPS_SOURCE_HASH="{hb.source_hash()}"', "-c", src, "-o", obj]))
     for p in procs:
         assert p.wait() == 0
     lib = os.path.join(workdir, "libnnpops_hip.so")
@@ -38,7 +66,7 @@ def build_variant(workdir):
     return lib
 
 
-def measure(lib_path):
+def measure(lib_path, frame="water"):
     """AEV forward (kernel event times) and the fused networks (HIP events) of config 2 with the given library."""
     code = r'''
 import json, sys
@@ -48,7 +76,11 @@ from nnpops_amd import capi, workloads
 capi.LIB_PATH = %r
 from nnpops_amd.capi import AniSymmetryFunctions, FusedMLP
 sys.path.insert(0, %r)
-pos, species, box = workloads.water_box(667, seed=1)
+frame = %r
+if frame == "water":
+    pos, species, box = workloads.water_box(667, seed=1)          # BASELINE config 2: 2 of the 7 species, 128 of 1008 columns live
+else:
+    pos, species, box = workloads.random_box(2000, density=0.1, seed=1, n_species=7)    # all 7 species: every AEV column live
 rf, af = workloads.ani2x_functions()
 dev = torch.device("cuda:0")
 sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
@@ -75,27 +107,44 @@ def nets(w, s):
                 b4=r(8, h3, fan=100), w6=r(8, h3, fan=h3), b6=r(8, fan=100))
 sp = torch.tensor(species)
 kinds = []
-for s, w in ((0, (256, 192, 160)), (3, (192, 160, 128))):
+widths = {0: (256, 192, 160), 1: (224, 192, 160), 2: (192, 160, 128), 3: (192, 160, 128), 4: (160, 128, 96), 5: (160, 128, 96), 6: (160, 128, 96)}
+for s in sorted(set(int(x) for x in species)):
+    w = widths[s]
     kd = nets(w, s); kd["atoms"] = torch.nonzero(sp == s).flatten().to(torch.int32).cuda(); kinds.append(kd)
 mlp = FusedMLP(kinds, 1008)
 aev_forward()
 out = {"aev_forward_us": t(aev_forward), "networks_forward_us": t(lambda: mlp.forward(aev, with_gradient=True))}
 print(json.dumps(out))
-''' % (ROOT, lib_path, ROOT)
+''' % (ROOT, lib_path, ROOT, frame)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build-only", default=None, help="build the prototype library into this directory (hipcc, no GPU needed) and stop")
+    ap.add_argument("--lib", default=None, help="a prototype library built earlier with --build-only")
+    args = ap.parse_args()
+    if args.build_only:
+        os.makedirs(args.build_only, exist_ok=True)
+        print(build_variant(args.build_only))
+        return
     from nnpops_amd import capi
-    product = measure(capi.LIB_PATH)
+    out = {}
     with tempfile.TemporaryDirectory(prefix="nnpops_proto_") as wd:
-        proto = measure(build_variant(wd))
-    saved = {k: round(product[k] - proto[k], 2) for k in product}
-    print(json.dumps({"workload": "BASELINE config 2: 2001-atom water box, AEV forward (fused build + forward) and the fused networks' forward launch",
-                      "product_us": {k: round(v, 2) for k, v in product.items()}, "aev_never_in_memory_us": {k: round(v, 2) for k, v in proto.items()},
-                      "upper_bound_of_fusion_A_us": saved, "total_upper_bound_us": round(sum(saved.values()), 2)}))
+        proto_lib = os.path.abspath(args.lib) if args.lib else build_variant(wd)
+        for frame, label in (("water", "BASELINE config 2: 2001-atom water box (2 species, 128 live AEV columns)"),
+                             ("seven", "2000 atoms, 7 species uniform (all 1008 AEV columns live: the networks read 8x what they read for water)")):
+            product = measure(capi.LIB_PATH, frame)
+            proto = measure(proto_lib, frame)
+            saved = {k: round(product[k] - proto[k], 2) for k in product}
+            out[frame] = {"workload": label + "; AEV forward (fused build + forward) and the fused networks' forward launch",
+                          "product_us": {k: round(v, 2) for k, v in product.items()},
+                          "aev_never_in_memory_us": {k: round(v, 2) for k, v in proto.items()},
+                          "upper_bound_of_fusion_A_us": saved, "total_upper_bound_us": round(sum(saved.values()), 2)}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
