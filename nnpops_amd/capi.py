@@ -79,6 +79,9 @@ SIGNATURES = {
                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_backward": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_neighbor_pairs_backward_workspace_bytes": (C.c_int64, [C.c_int]),
+    "nnpops_neighbor_pairs_backward_ws": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -312,10 +315,11 @@ def neighbor_pairs_backward(num_atoms, neighbors, deltas, distances, grad_deltas
     dev, dt = deltas.device, deltas.dtype
     grad_positions = torch.empty((num_atoms, 3), dtype=dt, device=dev)
     with torch.cuda.device(dev):
-        _check(lib().nnpops_neighbor_pairs_backward(_DTYPE_CODE[dt], num_atoms, distances.numel(), _ptr(neighbors),
-                                                    _ptr(deltas.contiguous()), _ptr(distances.contiguous()),
-                                                    _ptr(grad_deltas.contiguous()), _ptr(grad_distances.contiguous()),
-                                                    _ptr(grad_positions), _stream_ptr(dev)))
+        ws = torch.empty((int(lib().nnpops_neighbor_pairs_backward_workspace_bytes(num_atoms)) // 8,), dtype=torch.int64, device=dev)
+        _check(lib().nnpops_neighbor_pairs_backward_ws(_DTYPE_CODE[dt], num_atoms, distances.numel(), _ptr(neighbors),
+                                                       _ptr(deltas.contiguous()), _ptr(distances.contiguous()),
+                                                       _ptr(grad_deltas.contiguous()), _ptr(grad_distances.contiguous()),
+                                                       _ptr(grad_positions), _ptr(ws), _stream_ptr(dev)))
     return grad_positions
 
 

@@ -43,7 +43,8 @@ struct nnpops_ani {
     bool generic = false;           // the angular functions do not factor (or have too many factors): generic kernels
     bool mfma_ok = false;           // at most 32 species pairs can occur in this system
     bool fwd_identity = false;      // angular function m sits at canonical slot m: 16-byte stores of the row
-    int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel
+    int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel (large systems; forward_chunk())
+    bool fwd_chunk_forced = false;  // $NNPOPS_ANI_FWD_CHUNK given
     int fwd_waves_per_atom = 2;     // 2: a 128-lane workgroup per atom (half the LDS per wave), 1: a wave per atom
     // Atoms are evaluated in `nstreams` spans on as many HIP streams (fork after the cell grid, join before the caller's
     // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
@@ -151,6 +152,22 @@ int waves_per_group(size_t lds_wave) {
     return best;
 }
 
+// Triples staged per chunk of the matrix-core forward.  192 is the optimum of the 10 000-atom liquid, where LDS per atom is
+// occupancy (128 -> 20.9 us, 192 -> 19.0, 256 -> 20.2).  A system small enough for ALL its atoms to be resident at once has no
+// occupancy to lose: there the chunk is as large as the whole triple list of the busiest atom the records allow (one phase 1, one
+// phase 2, two barriers instead of six for a 300-triple atom): the 50-atom molecule of BASELINE config 1 36.3 -> 31.1 us per
+// forward+backward evaluation at 512 (round 4).  fixed_lds_bytes: what the workgroup needs besides the staged factors.
+int forward_chunk(const nnpops_ani* h, size_t fixed_lds_bytes, size_t bytes_per_triple) {
+    if (h->fwd_chunk_forced) return h->fwd_chunk;
+    const int want = std::min(512, (triples_capacity(h->cap_angular) + 15) & ~15);
+    for (int ch : {want, 384, 256}) {
+        if (ch > want || ch <= h->fwd_chunk) continue;
+        const size_t lds = fixed_lds_bytes + (size_t)(ch + 1) * bytes_per_triple;
+        if (lds <= 160 * 1024 && h->hp.N <= 256L * (long)(160 * 1024 / lds)) return ch;
+    }
+    return h->fwd_chunk;
+}
+
 int pad_pow2(int n, int lo) {
     int p = lo;
     while (p < n) p <<= 1;
@@ -232,7 +249,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
     const size_t lds_group = (size_t)lds_wave * wpg;
     const dim3 grid(div_up(N, wpg)), block(64 * wpg);
     if (forward && h->forward_kernel == 2) {
-        const int CH = h->fwd_chunk;
+        const int CH = forward_chunk(h, (size_t)h->cap_angular * 2 * sizeof(float4), (size_t)(NFRP + NFZP) * sizeof(float));
         const size_t lds2 = ang_fwd_mfma_lds_bytes<NFRP, NFZP>(h->cap_angular, CH);
         const int lw = (int)((lds2 + 15) & ~(size_t)15);
         int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)out & 15) == 0;
@@ -343,23 +360,29 @@ int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out, co
 }
 
 // The fused neighbour build + angular forward (ani_build_forward.h): the ANI-1x / ANI-2x factor shape, two waves per atom.
+// (fused kernel: records + the triple list in LDS besides the staged factors; the builder's scratch shares the staging area)
+int fused_chunk(const nnpops_ani* h) {
+    return forward_chunk(h, (size_t)h->cap_angular * 2 * sizeof(float4) + (size_t)triples_capacity(h->cap_angular) * sizeof(int) + 64, 12 * sizeof(float));
+}
+
 bool build_forward_fused(const nnpops_ani* h, const float* angular) {
     constexpr int kFuseAtoms = 4096;
     const bool want = h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0;
     return want && !h->generic && h->forward_kernel == 2 && h->fwd_waves_per_atom == 2 && h->nfrp == 8 && h->nfzp == 4 &&
            h->nstreams == 1 && h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)angular & 15) == 0 &&
-           build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk) <= 160 * 1024;
+           build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, fused_chunk(h)) <= 160 * 1024;
 }
 
 template <bool TA>
 int launch_build_forward(nnpops_ani* h, const BuildInputs& in, const BuildOutputs& out, float* angular, const Span& sp) {
     int tri_offset = 0;
-    const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk, &tri_offset) + 15) & ~(size_t)15;
+    const int CH = fused_chunk(h);
+    const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, CH, &tri_offset) + 15) & ~(size_t)15;
     const int vec_ok = 1 | (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);
     const bool uni = h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4;
     auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6> : uni ? ani_build_forward<TA, 8, 4, 7, true> : ani_build_forward<TA, 8, 4, 7>;
     if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, h->fwd_chunk, angular,
+    hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, CH, angular,
                        h->ld_angular, vec_ok, tri_offset, sp.w0, sp.nw);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
@@ -500,7 +523,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         while ((4 << hp.fwd_zero_shift) < num_angular && hp.fwd_zero_shift < 6) hp.fwd_zero_shift++;
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
-        if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) { h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16)); h->fwd_chunk_forced = true; }
         if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("NNPOPS_ANI_LPT")) h->lpt = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_CELL_ATOMS")) h->cell_atoms = std::max(1, std::atoi(e));

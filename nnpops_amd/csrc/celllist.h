@@ -279,6 +279,7 @@ static __global__ void order_cells(int N, const float* __restrict__ pos, const C
 // A bin that overflows clears grid.ok; the owner grows the bins in its check() and rebuilds.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBinnedAtoms = 65536;
+constexpr int kPairsBinnedAtoms = 200000, kPairsBinCap = 128;    // the stateless getNeighborPairs op: <= 8 192 cells x 128 ids (4 MiB of workspace)
 constexpr int kBinnedCells = 8192;
 constexpr int kBinnedThreads = 256;
 
@@ -632,7 +633,9 @@ struct CellBuffers {
 };
 
 static inline bool cell_build_is_binned(int N, bool periodic, const CellBuffers& b) {
-    return periodic && b.hist != nullptr && b.bins != nullptr && N <= kBinnedAtoms;
+    // (callers hand over hist / bins only for systems their bins are sized for: the stateful handles up to kBinnedAtoms atoms, with
+    //  bins that grow in check(); getNeighborPairs up to kPairsBinnedAtoms with a fixed bin of 128 ids per cell)
+    return periodic && b.hist != nullptr && b.bins != nullptr;
 }
 
 static inline void launch_cell_build(hipStream_t stream, int N, const float* pos, const float* box, bool periodic, float cutoff,

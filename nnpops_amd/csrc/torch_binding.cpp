@@ -866,9 +866,11 @@ public:
         Tensor grad_positions = torch::empty({num_atoms, 3}, deltas.options());
         const int dtype = deltas.scalar_type() == torch::kFloat64 ? 1 : 0;
         c10::hip::HIPGuard guard(deltas.device().index());
-        if (nnpops_neighbor_pairs_backward(dtype, (int)num_atoms, distances.size(0), neighbors.data_ptr<int32_t>(), deltas.data_ptr(),
-                                           distances.data_ptr(), grad_deltas.data_ptr(), grad_distances.data_ptr(),
-                                           grad_positions.data_ptr(), current_stream(deltas.device())) != NNPOPS_OK)
+        // (scratch for the order-independent fixed-point sums of the backward pass: no float atomics, nnpops_hip.h)
+        Tensor workspace = torch::empty({nnpops_neighbor_pairs_backward_workspace_bytes((int)num_atoms) / 8}, deltas.options().dtype(torch::kInt64));
+        if (nnpops_neighbor_pairs_backward_ws(dtype, (int)num_atoms, distances.size(0), neighbors.data_ptr<int32_t>(), deltas.data_ptr(),
+                                              distances.data_ptr(), grad_deltas.data_ptr(), grad_distances.data_ptr(),
+                                              grad_positions.data_ptr(), workspace.data_ptr(), current_stream(deltas.device())) != NNPOPS_OK)
             raise_last("neighbors::getNeighborPairs backward");
         return {grad_positions, Tensor(), Tensor(), Tensor(), Tensor()};
     }

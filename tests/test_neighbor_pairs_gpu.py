@@ -92,6 +92,33 @@ def test_backward(dtype, num_atoms, grad):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_backward_bitwise_reproducible(dtype):
+    """The backward pass adds the pair forces as fixed-point integers (no float atomics, nnpops_hip.h): the same inputs give the
+    same bits every time -- also with the pair list in another order -- where the reference's atomicAdd scatter
+    (getNeighborPairsCUDA.cu:96-100) gives a different rounding from run to run."""
+    from nnpops_amd.capi import neighbor_pairs_backward, neighbor_pairs_forward
+    rng = np.random.default_rng(5)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    n = 3000
+    pos = (12 * rng.random((n, 3))).astype(npdt)
+    tp = torch.tensor(pos, device=DEV)
+    nb, dl, ds, cnt = neighbor_pairs_forward(tp, 3.0, 400000)
+    assert 0 < int(cnt) < 400000
+    gd = torch.tensor(rng.standard_normal(tuple(dl.shape)).astype(npdt), device=DEV)
+    gs = torch.tensor(rng.standard_normal(tuple(ds.shape)).astype(npdt), device=DEV)
+    first = neighbor_pairs_backward(n, nb, dl, ds, gd, gs)
+    for _ in range(5):
+        assert torch.equal(neighbor_pairs_backward(n, nb, dl, ds, gd, gs), first)
+    perm = torch.randperm(nb.shape[1], device=DEV)                       # the same pairs, shuffled
+    again = neighbor_pairs_backward(n, nb[:, perm].contiguous(), dl[perm].contiguous(), ds[perm].contiguous(), gd[perm].contiguous(),
+                                    gs[perm].contiguous())
+    assert torch.equal(again, first)
+    ref = neighbor_pairs_backward_oracle(n, nb.cpu().numpy(), dl.cpu().numpy(), ds.cpu().numpy(), gd.cpu().numpy(), gs.cpu().numpy())
+    tol = 1e-4 if npdt == np.float32 else 1e-10
+    np.testing.assert_allclose(first.cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("box", [[[10, 0, 0], [0, 10, 0], [0, 0, 10]], [[10, 0, 0], [2, 12, 0], [0, 1, 11]],
                                  [[10, 0, 0], [-2, 12, 0], [0, -1, 11]]])
 @pytest.mark.parametrize("all_pairs", [True, False])
