@@ -60,6 +60,8 @@ struct nnpops_ani {
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
     int fwd_occ = 7;                // A/B: register budget of the forward kernel (waves per SIMD)
+    bool fwd_dynamic = false;       // quads dealt out per atom from its bucket sizes (ani_angular_mfma.h: DYN): set at create from the
+                                    // composition (forward_dynamic_pays), $NNPOPS_ANI_FWD_DYN=0 / 1 forces
     int nstreams = 1;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -258,7 +260,10 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             int groups = N;
             if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
             const bool uni = h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP;      // one eta, one zeta, no padded factor slots
+            // balanced phase 2 (per-atom quad table, ani_angular_mfma.h: DYN): needs the row assembled in LDS and a lane per bucket
+            const bool dyn = h->fwd_dynamic && (vec_ok & 8) && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * (NFRP + NFZP);
             auto k = h->fwd_occ == 6 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 6> : h->fwd_occ == 8 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 8>
+                   : dyn ? (uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, false, true>)
                    : uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
             hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
@@ -380,7 +385,10 @@ int launch_build_forward(nnpops_ani* h, const BuildInputs& in, const BuildOutput
     const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, CH, &tri_offset) + 15) & ~(size_t)15;
     const int vec_ok = 1 | (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);
     const bool uni = h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4;
-    auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6> : uni ? ani_build_forward<TA, 8, 4, 7, true> : ani_build_forward<TA, 8, 4, 7>;
+    const bool dyn = h->fwd_dynamic && h->fwd_row_via_lds && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * 12;
+    auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6>
+           : dyn ? (uni ? ani_build_forward<TA, 8, 4, 7, true, true> : ani_build_forward<TA, 8, 4, 7, false, true>)
+           : uni ? ani_build_forward<TA, 8, 4, 7, true> : ani_build_forward<TA, 8, 4, 7>;
     if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, CH, angular,
                        h->ld_angular, vec_ok, tri_offset, sp.w0, sp.nw);
@@ -531,6 +539,19 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_OCC")) h->fwd_occ = std::atoi(e);
+        {   // Does the per-atom quad table pay?  With one quad set per species pair the step loop of phase 2 runs max_b n_b / K times,
+            // balanced it runs ~T / 32 times; the table costs ~150-250 instructions per atom (two waves).  From the composition:
+            // the largest bucket's expected share of the triples, f = p_a p_b (x 2 for a != b), against 1 / 32 per quad and the K
+            // quads it already has.  Seven equally likely species 1.3, water 1.8 (measured there: 17.6 -> 21.1 us and 16.1 -> 22.9 us
+            // with the table: it loses); H/C/N/O molecules 4.8 (64 steps against 14 for a 400-triple atom: it wins).
+            std::vector<double> frac(num_species, 0.0);
+            for (int i = 0; i < num_atoms; i++) frac[atom_species[i]] += 1.0 / num_atoms;
+            double fmax = 0;
+            for (int a = 0; a < num_species; a++)
+                for (int b = a; b < num_species; b++) fmax = std::max(fmax, frac[a] * frac[b] * (a == b ? 1.0 : 2.0));
+            h->fwd_dynamic = h->mfma_ok && 32.0 * fmax / hp.fwd_split > 3.0;
+        }
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_DYN")) h->fwd_dynamic = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_STREAMS")) h->nstreams = std::max(1, std::min(4, std::atoi(e)));
         if (const char* e = std::getenv("NNPOPS_ANI_BWD_APG")) h->bwd_atoms_per_group = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_STORE")) h->store_mode = std::atoi(e) & 3;
