@@ -105,6 +105,12 @@ struct nnpops_ani {
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
     int* d_work_order = nullptr;    // [N] atoms by DECREASING number of angular neighbours (check() builds it): the schedule of the
     bool work_order_valid = false;  //     angular kernels -- heaviest atoms first, the light ones fill the tail
+    unsigned char* d_class_tile = nullptr;   // [N] pair-matrix edge of the backward launch every atom belongs to (255: no limit)
+    struct BwdClass { int tile, w0, nw; bool two_waves; };
+    std::vector<BwdClass> bwd_classes;       // stretches of d_work_order, by decreasing tile (check() builds them with the order)
+    bool bwd_by_class = true;                // $NNPOPS_ANI_BWD_CLASSES=0: one launch with the full-size pair matrix
+    bool bwd_two_waves = false;              // the atoms average 200 triples or more (check()): two waves per atom in the backward kernel
+    int bwd_class_min = 512;                 // smallest class launched on its own ($NNPOPS_ANI_BWD_CLASS_MIN)
     int cell_atoms = 1800;          // systems of at least this many atoms search their neighbours through the cell grid ($NNPOPS_ANI_CELL_ATOMS)
     int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
@@ -287,15 +293,27 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         // backward_kernel: 1 = one wave per atom, every triple reads its gradient block through the L1 (needs the 16-byte
         // layout); 2 = one wave, gradient row staged in LDS; 3 / 4 = the same two with two waves per atom (A/B only)
         const int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)grad_or_null & 15) == 0;
+        // One launch per class of atoms (by their number of angular neighbours, nnpops_ani_check), each with the pair matrix its
+        // atoms need; without classes -- no work order yet, several spans, $NNPOPS_ANI_BWD_CLASSES=0 -- one launch at full size.
+        nnpops_ani::BwdClass whole{h->cap_angular, sp.w0, sp.nw, h->bwd_two_waves};
+        const bool by_class = h->bwd_by_class && !h->bwd_classes.empty() && sp.ang_order == h->d_work_order && sp.w0 == 0 && sp.nw == h->hp.N;
+        const nnpops_ani::BwdClass* classes = by_class ? h->bwd_classes.data() : &whole;
+        const int nclasses = by_class ? (int)h->bwd_classes.size() : 1;
+        for (int c = 0; c < nclasses; c++) {
+        const int tile = std::min(classes[c].tile, h->cap_angular), cw0 = classes[c].w0, cnw = classes[c].nw;
+        if (cnw <= 0) continue;
         int mode = h->backward_kernel;
         // Dense systems (64 or more record slots): the pair matrix is 27 KB per atom and only 6 atoms fit a CU -- six waves
         // where twenty could run.  Two waves per atom double the waves on the same LDS (1 024 conformers: 1.03 -> 0.97 ms per
         // batch); with the usual 32 slots one wave per atom wins (section 3.5 of DESIGN.md).
-        if (mode == 1 && !h->backward_forced && ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, false) > 16 * 1024) mode = 3;
+        // (round 4: what decides is the work per atom, not the LDS -- with the classes above every class of the conformer batch, the
+        //  32-slot one included, is faster with two waves per atom: 304 us in one launch, 275 by class with this rule on LDS, 246
+        //  with two waves everywhere; the 153-triple atoms of a liquid stay with one wave, 15.8 against 25 us)
+        if (mode == 1 && !h->backward_forced && (classes[c].two_waves || ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, false) > 16 * 1024)) mode = 3;
         if (!vec_ok && (mode == 1 || mode == 3)) mode++;
         const bool glds = mode == 2 || mode == 4;
-        const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, glds) + 15) & ~(size_t)15;
-        void (*k)(const AniParams*, const AngularConsts, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
+        const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, glds) + 15) & ~(size_t)15;
+        void (*k)(const AniParams*, const AngularConsts, int, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
                   float4*, float4*, int, int, int, const int*, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
                          : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, true>
@@ -307,9 +325,10 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
-        hipLaunchKernelGGL(k, dim3(div_up(N, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+        hipLaunchKernelGGL(k, dim3(div_up(cnw, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, tile, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
-                           sp.ang_order, sp.w0, sp.nw);
+                           sp.ang_order, cw0, cnw);
+        }
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
@@ -351,7 +370,7 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, cons
         if (lb > 160 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "generic angular backward needs %zu bytes of LDS (cap_angular %d)", lb, h->cap_angular);
         auto k = ani_angular_backward_pair<TA, 4, 4, 4, 1, false, true>;
         if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, h->hp.NB, (int)lb, nullptr, 0, N);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
@@ -591,6 +610,11 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_tile_total, (size_t)h->max_cells / kScanTile + 2))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_work_order, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_class_tile, (size_t)num_atoms))) return cleanup(rc);
+    if (hipMemset(h->d_class_tile, 255, (size_t)num_atoms) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
+    hp.class_tile = h->d_class_tile;
+    if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASSES")) h->bwd_by_class = std::atoi(e) != 0;
+    if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_MIN")) h->bwd_class_min = std::max(0, std::atoi(e));
     if ((rc = dev_alloc(&h->d_unsorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_bucket_offsets, (size_t)num_atoms * (hp.NB + 1)))) return cleanup(rc);
@@ -652,7 +676,7 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     dev_free(h->d_ids); dev_free(h->d_leg_force); dev_free(h->d_centre_force); dev_free(h->d_bucket_offsets);
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
-    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_tile_total); dev_free(h->d_sorted_atom); dev_free(h->d_work_order); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
+    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_tile_total); dev_free(h->d_sorted_atom); dev_free(h->d_work_order); dev_free(h->d_class_tile); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
     for (int q = 0; q < 3; q++) {
         if (h->side[q]) (void)hipStreamDestroy(h->side[q]);
         if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
@@ -963,7 +987,37 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         for (size_t a = 0; a < perm.size(); a++) perm[a] = (int)a;
         std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return counts[a] > counts[b]; });
         NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_work_order, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, h->stream));
-        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));      // (perm is a local)
+        // The angular backward is launched class by class along this order (launch_angular): atoms with more than 44 angular
+        // neighbours with the full pair matrix, up to 44 with a 48-slot one, up to 28 with a 32-slot one -- four slots of room for
+        // the frames until the next check(); an atom that outgrows its class is flagged by the builder (kStatOverflow bit 3) and
+        // the classes are rebuilt here.  Records of 32 slots: one class.
+        std::vector<unsigned char> tile_of(perm.size(), 255);
+        h->bwd_classes.clear();
+        {
+            double triples = 0;
+            for (int cnt : counts) triples += 0.5 * cnt * (cnt - 1);
+            h->bwd_two_waves = triples / std::max<size_t>(counts.size(), 1) >= 200.0;
+        }
+        if (h->cap_angular > 48 && h->bwd_by_class) {          // (record capacities are 32, 64, 128, ...)
+            const int tiles[3] = {h->cap_angular, 48, 32}, above[3] = {44, 28, -1};      // class c: atoms with more than above[c] neighbours
+            // (a class of a few hundred atoms is a launch that cannot fill the chip: it takes the next class with it -- at the
+            //  larger pair matrix -- until it has bwd_class_min atoms)
+            int start = 0, pending = 0;
+            for (int c = 0; c < 3; c++) {
+                int end = start;
+                while (end < (int)perm.size() && counts[perm[end]] > above[c]) end++;
+                if (c < 2 && end - start < h->bwd_class_min) continue;     // (start stays: the next class begins where this one would have)
+                double triples = 0;
+                for (int q = start; q < end; q++) triples += 0.5 * counts[perm[q]] * (counts[perm[q]] - 1);
+                const int tile = tiles[pending];               // (the largest matrix of the classes merged into this launch)
+                h->bwd_classes.push_back({tile, start, end - start, end > start && triples / (end - start) >= 200.0});
+                for (int q = start; q < end; q++) tile_of[perm[q]] = (unsigned char)std::min(255, tile);
+                start = end;
+                pending = c + 1;
+            }
+        }
+        NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_class_tile, tile_of.data(), tile_of.size(), hipMemcpyHostToDevice, h->stream));
+        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));      // (perm and tile_of are locals)
         h->work_order_valid = true;
     }
     // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
@@ -974,6 +1028,13 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
                      h->tile * (h->tile + 1) + h->tile * (h->tile - 1) / 2 >= h->cap_angular * 4 + 12;
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
+    if (st[kStatOverflow] == 8) {         // nothing overflowed, but an atom outgrew its backward class: regrouped above
+        h->computed = false;
+        if (!want_order)                   // (no order was built: lift every limit)
+            NNPOPS_HIP_TRY(hipMemset(h->d_class_tile, 255, (size_t)h->hp.N));
+        if (!want_order) h->bwd_classes.clear();
+        return fail(NNPOPS_ERR_CAPACITY, "an atom outgrew the pair-matrix class of its backward launch; classes rebuilt, call compute() again");
+    }
     if (st[kStatOverflow] & 4) {          // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins
         const int old_bin = h->bin_cap;
         h->bin_cap *= 2;
@@ -996,6 +1057,10 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         const int old_cap = h->cap, old_ca = h->cap_angular;
         while (h->cap < st[kStatMaxRow]) h->cap *= 2;
         while (h->cap_angular < st[kStatMaxAngular]) h->cap_angular *= 2;
+        if (h->cap_angular != old_ca) {    // (the classes above were cut for the old capacity)
+            h->bwd_classes.clear();
+            NNPOPS_HIP_TRY(hipMemset(h->d_class_tile, 255, (size_t)h->hp.N));
+        }
         if (h->cap_angular > kMaxAngularCap)
             return fail(NNPOPS_ERR_UNSUPPORTED, "an atom has %d neighbours inside the angular cutoff (limit %d)",
                         st[kStatMaxAngular], kMaxAngularCap);

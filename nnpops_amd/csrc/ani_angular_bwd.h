@@ -110,7 +110,7 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 // 20 fewer wave-uniform constants in scalar registers.
 template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, bool UNI = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
-    const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, const float4* __restrict__ recA_g,
+    const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, int tile, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
     const float* __restrict__ angular_grad, int ld_angular, float4* __restrict__ leg_force, float4* __restrict__ centre_force,
     int vec_ok, int NB, int lds_per_atom, const int* __restrict__ order, int w0, int nw) {     // positions [w0, w0 + nw) of `order`
@@ -124,15 +124,19 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     const int atoms_per_group = WPA == 2 ? 1 : (int)(blockDim.x >> 6);
     const int slot_in_group = WPA == 2 ? 0 : wig;
     const int nA = C.nA;
-    const int tile = capA, tstride = capA + 1;
+    // tile: edge of the LDS pair matrix and number of record slots of THIS launch (<= capA, the stride of the global arrays): check()
+    // groups the atoms by their number of angular neighbours and the groups are launched one after the other, each with the
+    // LDS its atoms need -- 7 KB for up to 32 neighbours, 15 KB for 48, 27 KB for 64: in a batch of compact molecules (BASELINE
+    // config 4) two thirds of the atoms have at most 32 and ran six to a CU because 1 % have more than 48.
+    const int tstride = tile + 1;
     auto sync = [&]() {
         if constexpr (WPA == 2) __syncthreads();
         else wave_fence();
     };
 
     char* cursor = lds_raw + (size_t)slot_in_group * lds_per_atom;
-    float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
-    float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float4* recA = (float4*)cursor;       cursor += (size_t)tile * sizeof(float4);
+    float4* recB = (float4*)cursor;       cursor += (size_t)tile * sizeof(float4);
     float* grow = (float*)cursor;         if (GLDS) cursor += (size_t)NB * BLK * sizeof(float);   // upstream gradient row, canonical [bucket][a][z]
     float* Ma = (float*)cursor;           // alpha[tile][tile + 1]: Ma[e][x] = coefficient of A_e in the force of triple {e, x} on e
     float* Mb = Ma + tile * tstride;      // beta, once per unordered pair (p < q), triangular
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         }
         int n, nro;
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+        n = min(n, tile);                                      // (an atom that outgrew its class was flagged by the builder; stay inside the LDS)
         if (n < 2) {                                           // no triples (uniform for the workgroup): a lone leg carries no force
             if (n == 1 && role == 0 && lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
@@ -196,10 +201,10 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         if constexpr (WPA == 2) {
             const float4* src = (role == 0 ? recA_g : recB_g) + (size_t)i * capA;
             float4* dst = role == 0 ? recA : recB;
-            if (lane < capA) dst[lane] = recA_first;           // (not "< n": the compiler would sink the load behind the counts)
+            if (lane < tile) dst[lane] = recA_first;           // (not "< n": the compiler would sink the load behind the counts)
             for (int e = lane + 64; e < n; e += 64) dst[e] = src[e];
         } else {
-            if (lane < capA) { recA[lane] = recA_first; recB[lane] = recB_first; }
+            if (lane < tile) { recA[lane] = recA_first; recB[lane] = recB_first; }
             for (int e = lane + 64; e < n; e += 64) { recA[e] = recA_g[(size_t)i * capA + e]; recB[e] = recB_g[(size_t)i * capA + e]; }
         }
         sync();
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         for (int base = role * 64; base < T; base += NT) {
             const int t = base + lane;
             const int next_word = (t + NT < T) ? tri[t + NT] : 0;
-            if (t < T) {
+            if (t < T && ((word >> 8) & 0xff) < tile) {        // (the second test only fails for an atom that outgrew its class: its list is laid out for more slots)
                 const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;
                 float ap, aq, bt;
                 if constexpr (GENERIC) {

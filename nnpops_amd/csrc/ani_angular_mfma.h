@@ -101,7 +101,7 @@ struct MfmaForward {
     int* qtab;                            // [32][2], LDS (DYN): quad slot -> {first triple | count << 16, bucket | part << 8 | parts << 16}
     int dpart, dparts;                    // DYN: this quad's part of its bucket, and how many quads share the bucket
     int lane, role, quad, nn;
-    int NB, nA, K, logK, nabsent, zero_shift;
+    int NB, nA, K, logK;
     int fac_addr, zdelta, zero_addr;      // (LDS addresses of phase 2 are kept as 32-bit byte offsets: one register per quad stream)
     int sbk[NS], spart[NS];
     float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];   // constants of the two factor families (wave-uniform)
@@ -119,7 +119,6 @@ struct MfmaForward {
         lane = lane_id();
         NB = P->NB; nA = P->nA;
         const int nFR = P->nFR, nFZ = P->nFZ;
-        nabsent = P->fwd_nabsent; zero_shift = P->fwd_zero_shift;
         K = P->fwd_split; logK = 31 - __builtin_clz(K);
         recA = (float4*)lds;
         recB = recA + capA;
@@ -151,12 +150,10 @@ struct MfmaForward {
 
     // One atom with n angular neighbours.  tri_at(t): word of triple t; boff_at(b): first triple of bucket b;
     // stage_records(): called once, before the first barrier -- the records of the atom must be in recA / recB after it.
-    // first_word: the word of triple role * 64 + lane, requested by the caller BEFORE the atom's counts were known (whatever the list
-    // holds behind the last triple is masked here): one dependent round trip to memory less per atom.
     template <class TriAt, class BoffAt, class StageRecords>
-    __device__ __forceinline__ void atom(int i, int n, int first_word, TriAt&& tri_at, BoffAt&& boff_at, StageRecords&& stage_records) {
+    __device__ __forceinline__ void atom(int i, int n, TriAt&& tri_at, BoffAt&& boff_at, StageRecords&& stage_records) {
         const int T = (n * (n - 1)) / 2;
-        int word = role * 64 + lane < T ? first_word : 0;                      // my first batch of triple words
+        int word = role * 64 + lane < T ? tri_at(role * 64 + lane) : 0;        // my first batch of triple words, in flight early
         int sstart[NS], send[NS];
         if constexpr (DYN) {
             if (role == 0) {
@@ -340,7 +337,7 @@ struct MfmaForward {
             float* rowbuf = fac;
             constexpr int NT = 64 * WPA;
             const int tid = role * 64 + lane, pieces = (NB * nA) >> 2;
-            const int nabs = nabsent;
+            const int nabs = P->fwd_nabsent;
             sync();                                            // every wave is done with the staged factors
             if (DYN || nabs > 0) {                             // blocks nobody owns are zero (DYN: species pairs without triples have no quad)
                 for (int q = tid; q < pieces; q += NT) reinterpret_cast<float4*>(rowbuf)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -385,10 +382,10 @@ struct MfmaForward {
                     }
             }
             // species pairs that cannot occur in this system have no quad: their blocks are zero
-            const int nabs = nabsent;
+            const int nabs = P->fwd_nabsent;
             if (nabs > 0 && role == 0) {
                 if (vec_ok) {                                      // 2^fwd_zero_shift lanes per block, one 16-byte piece each
-                    const int sh = zero_shift, piece = lane & ((1 << sh) - 1), per_pass = 64 >> sh;
+                    const int sh = P->fwd_zero_shift, piece = lane & ((1 << sh) - 1), per_pass = 64 >> sh;
                     for (int a0 = 0; a0 < nabs; a0 += per_pass) {
                         const int a = a0 + (lane >> sh);
                         if (a < nabs && piece * 4 < nA)
@@ -424,27 +421,19 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     for (int w = blockIdx.x * natoms_group + slot_in_group; w < nw; w += stride_atoms) {
         int i = order ? order[w0 + w] : w0 + w;
         if ((unsigned)i >= (unsigned)P->N) i = w0 + w;         // (a void grid build leaves no valid order: stay in bounds)
-        // Everything that only needs the atom's index is requested before its counts are known -- the first batch of triple words
-        // and (two waves per atom: one array each) the first 64 records; what lies behind the atom's last triple / record is
-        // allocated and ignored.  The chain per atom is index -> {counts, words, offsets, records} instead of
-        // index -> counts -> {...}: the kernel with NO arithmetic at all takes 11.6 of its 20.5 us (profiles/r04a_probe_10k.json),
-        // it is made of these round trips.
-        const int capT = triples_capacity(capA);
-        const int* tri = tri_g + (size_t)i * capT;
-        const int t_first = F.role * 64 + lane;
-        const int first_word = t_first < capT ? tri[t_first] : 0;
-        const float4* rec_src = (F.role == 0 ? recA_g : recB_g) + (size_t)i * capA;
-        float4 rec_first = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (WPA == 2) rec_first = rec_src[min(lane, capA - 1)];
-        const int* boff_g = P->bucket_offsets + (size_t)i * (NB + 1);
         int n, nro;
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
-        F.atom(i, n, first_word, [&](int t) { return tri[t]; }, [&](int b) { return boff_g[b]; },
+        const int* tri = tri_g + (size_t)i * triples_capacity(capA);
+        const int* boff_g = P->bucket_offsets + (size_t)i * (NB + 1);
+        // (Requesting the first triple words and records BEFORE the counts are known -- one dependent round trip less per atom --
+        //  was built and measured in round 4: no gain, and the values it keeps alive cost this kernel, which sits exactly at the
+        //  72 registers of seven waves per SIMD, 20 bytes of scratch: 17.5 -> 18.7 us.  The backward kernel keeps that form.)
+        F.atom(i, n, [&](int t) { return tri[t]; }, [&](int b) { return boff_g[b]; },
                [&]() {
                    if constexpr (WPA == 2) {                   // one array each
+                       const float4* src = (F.role == 0 ? recA_g : recB_g) + (size_t)i * capA;
                        float4* dst = F.role == 0 ? F.recA : F.recB;
-                       if (lane < capA) dst[lane] = rec_first;  // (not "< n": the compiler would sink the load behind the counts)
-                       for (int e = lane + 64; e < n; e += 64) dst[e] = rec_src[e];
+                       for (int e = lane; e < n; e += 64) dst[e] = src[e];
                    } else {
                        load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, F.recA, F.recB);
                    }

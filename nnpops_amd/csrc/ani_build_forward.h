@@ -141,6 +141,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
                 out.cnt_a[i] = na; out.cnt_ro[i] = nro;
                 shared[0] = na; shared[1] = nro;
                 if (na > capA || na + nro > cap) atomicOr(&out.status[kStatOverflow], 1);      // (ani_kernels.h: builders flag their own overflow)
+                else if (na > (int)P->class_tile[i]) atomicOr(&out.status[kStatOverflow], 8);
             }
         }
         __syncthreads();
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
         //  build has no room for)
         MfmaForward<TORCHANI, NFRP, NFZP, 2, UNI, DYN> F;
         F.init(P, capA, CH, vec_ok, angular, ld_angular, lds_raw, role);
-        F.atom(i, n, role * 64 + lane < triples_capacity(capA) ? tri_l[role * 64 + lane] : 0, [&](int t) { return tri_l[t]; }, [&](int bk) { return G.boff[bk]; }, [&]() { F.write_zero_record(); });
+        F.atom(i, n, [&](int t) { return tri_l[t]; }, [&](int bk) { return G.boff[bk]; }, [&]() { F.write_zero_record(); });
     }
 }
 

@@ -78,6 +78,8 @@ struct AniParams {
     float af_cos[kMaxAngularFns];    // cos(thetas_m)
     float af_sin[kMaxAngularFns];    // sin(thetas_m)
     int* bucket_offsets;             // [N][NB + 1] device array the builders fill: offsets of the buckets in an atom's triple list
+    const unsigned char* class_tile; // [N] pair-matrix edge of the backward launch this atom was put in by check() (255: no limit);
+                                     //     a builder that finds more angular neighbours than that flags kStatOverflow bit 3
     // matrix-core forward kernel (ani_angular_mfma.h)
     int m_of_c[kMaxAngularFns];      // canonical slot a*NFZP+z -> function m, -1 for padding slots
     int fwd_split;                   // K: every species pair that can occur is shared by K quads (1, 2, 4 or 8)
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
+        else if (na > (int)P->class_tile[i]) atomicOr(&status[kStatOverflow], 8);     // outgrew its backward class: check() regroups
     }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
@@ -515,6 +518,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
+        else if (na > (int)P->class_tile[i]) atomicOr(&status[kStatOverflow], 8);     // outgrew its backward class: check() regroups
     }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);

@@ -218,4 +218,9 @@ def test_torchani_side_line_carries_its_variants():
     dense, call = line["ms_per_step_as_hip_graph_with_dense_networks"], line["ms_per_energy_and_forces_call"]
     assert all(isinstance(v, float) and 0.02 < v < 2.0 for v in (eager, nocheck, graph, dense, call)), line
     assert graph < dense                                     # skipping the dead columns pays on the device
-    assert line["roofline"]["issued"]["tflops"] < 3 * line["roofline"]["achieved"]      # issued flops count the live columns only
+    # `achieved` / `frac` price the EXECUTED flops (live columns only); the split-fp16 path issues three products per fp32 product;
+    # the reference's dense formulation (all 1008 columns) is a separate figure and the only one that may exceed the peak
+    roof = line["roofline"]
+    assert abs(roof["issued"]["tflops"] - 3 * roof["achieved"]) <= 0.02 * roof["issued"]["tflops"]
+    assert 0 < roof["frac"] < 1 and 0 < roof["issued"]["frac"] < 1
+    assert roof["vs_reference_formulation"]["tflops"] > roof["achieved"]
