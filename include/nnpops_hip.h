@@ -98,6 +98,15 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
  * slack: a row that outgrows it is clamped (the builders raise a device-side flag that only check() reads), so call
  * check() every few hundred replays, or after anything that can change the density. */
 int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors);
+/* The device-side flag itself: *word receives the DEVICE address of one int32 that the neighbour builders OR into whenever a
+ * compute() overflows a capacity (bit 0 rows / records, bit 1 box too small for the cell stencil, bit 2 cell bins, bit 3 an
+ * atom outgrew the class of its backward launch) and that only nnpops_ani_check() clears.  It is STICKY: a captured graph
+ * that is replayed without any check leaves its overflows there, so a caller can (a) put its own 4-byte asynchronous copy of
+ * the word into the graph, or read it every N replays, without calling into this library, and (b) rely on the next eager
+ * check() -- any later compute() followed by check() -- to report NNPOPS_ERR_CAPACITY for what happened during the replays:
+ * a non-zero word found there means that every evaluation since the previous check may have been incomplete.  The address is
+ * valid for the life of the handle. */
+int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word);
 /* The same check in two halves for callers that have more work to queue behind compute(): _begin (right after compute) queues
  * one single-thread launch that publishes the overflow word and a stamp into pinned host memory and returns 1 -- or 0 when the check cannot be deferred (first calls, while
  * capacities are still being fitted): call nnpops_ani_check() then.  _end (after the consumers of this build have been launched;

@@ -75,6 +75,14 @@ class TorchANISymmetryFunctions(torch.nn.Module):
         captured graph -- for production loops at known density (cf. ``check_errors`` of ``getNeighborPairs``)."""
         self.holder.set_check_interval(interval)
 
+    @torch.jit.export
+    def overflow_flag(self) -> Tensor:
+        """Extension: int32[1] device tensor, non-zero when a forward since the last capacity check overflowed a neighbour buffer
+        (a view of the word the kernels set: no copy, no synchronisation).  Inside a captured graph no check can run and an
+        overflow leaves the AEV of the affected atoms incomplete; the flag is sticky, so ``bool(module.overflow_flag())`` after
+        any number of replays -- or the next eager ``forward``, whose check then re-fits the buffers -- tells."""
+        return self.holder.overflow_flag()
+
     @torch.jit.unused
     def forward_batch(self, species_positions: Tuple[Tensor, Tensor]) -> Tuple[Tensor, Tensor]:
         """Extension (the reference rejects batches, SymmetryFunctions.py:110): B conformers of THE molecule this module was

@@ -44,6 +44,7 @@ SIGNATURES = {
     "nnpops_ani_set_timing_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nnpops_ani_timing_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "nnpops_ani_overflow_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
     "nnpops_cfconv_neighbors_destroy": (C.c_int, [C.c_void_p]),
     "nnpops_cfconv_neighbors_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

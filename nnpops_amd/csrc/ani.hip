@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ani_kernels.h"
+#include "ani_fallback_kernels.h"
 #include "ani_angular_mfma.h"
 #include "ani_angular_bwd.h"
 #include "ani_angular_generic.h"
@@ -1089,6 +1090,12 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
                         st[kStatMaxRow], old_cap, h->cap);
         }
     }
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word) {
+    NNPOPS_REQUIRE(h != nullptr && word != nullptr, "NULL argument");
+    *word = reinterpret_cast<const int32_t*>(h->d_status + kStatOverflow);
     return NNPOPS_OK;
 }
 

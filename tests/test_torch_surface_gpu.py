@@ -430,6 +430,48 @@ def test_optimized_torchani_step_replays_as_one_graph():
         torch.testing.assert_close(g_f, f_ref, rtol=1e-4, atol=1e-5 * float(f_ref.abs().max()))
 
 
+def test_overflow_inside_a_replayed_graph_is_observable():
+    """No capacity check can run inside a captured graph.  The builders' overflow word is sticky and exposed as a device tensor
+    (``overflow_flag()``, nnpops_hip.h: nnpops_ani_overflow_word): a replay on a frame that outgrows the fitted neighbour rows
+    sets it -- readable at any time, no call into the library -- and the next eager forward reports and repairs the capacity."""
+    from NNPOps.SymmetryFunctions import TorchANISymmetryFunctions
+    pos, species, box = workloads.water_box(400, seed=9)              # 1 200 atoms, rows fitted to liquid density
+    module = TorchANISymmetryFunctions(FakeConverter(), fake_aev_computer(), _numbers(species).cpu()).to(DEV)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True])
+    static_pos = torch.tensor(pos, device=DEV).unsqueeze(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            module((sp, static_pos), cell, pbc)
+    torch.cuda.current_stream().wait_stream(side)
+    flag = module.overflow_flag()
+    assert flag.dtype == torch.int32 and flag.is_cuda and int(flag) == 0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_aev = module((sp, static_pos), cell, pbc)[1]
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(flag) == 0                                              # the frame the capacities were fitted to
+    # the same atoms pulled into an eighth of the volume around the centre of the box: rows several times longer than fitted
+    centre = 0.5 * np.diag(box).astype(np.float32)
+    dense = (centre + 0.5 * (pos - centre)).astype(np.float32)
+    with torch.no_grad():
+        static_pos.copy_(torch.tensor(dense, device=DEV).unsqueeze(0))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(flag) != 0                                              # set by the replay, nobody asked the library
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(flag) != 0                                              # sticky
+    eager = module((sp, static_pos), cell, pbc)[1]                     # the eager call checks, grows the buffers and evaluates again
+    assert int(flag) == 0 and bool(torch.isfinite(eager).all())
+    oracle = AniOracle(7, 5.1, 3.5, species, *workloads.ani2x_functions(), periodic=True, torchani=True)
+    r_ref, a_ref = oracle.forward(dense, box)
+    np.testing.assert_allclose(eager[0].cpu().numpy(), np.concatenate([r_ref, a_ref], axis=1), rtol=2e-5, atol=2e-6)
+
+
 def test_capacity_check_interval_knob():
     """set_check_interval(k): results are unchanged (the check only verifies), scripted modules expose it, a negative
     interval is refused."""

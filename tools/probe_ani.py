@@ -45,14 +45,14 @@ PATCHES = {
          f"                if (!({PM} & 256)) store_row16(out + 4 * q, mfma_f4{{v.x, v.y, v.z, v.w}}, (vec_ok >> 1) & 3);\n", 1),
     ],
     "ani_angular_mfma.h#2": [
-        ("        F.atom(i, n, first_word,", f"        if (!({PM} & 8192)) F.atom(i, n, first_word,", 1),
-        ("        sync();\n\n        for (int c0 = 0; c0 < T; c0 += CH) {\n", f"        sync();\n        if ({PM} & 16384) return;\n\n        for (int c0 = 0; c0 < T; c0 += CH) {{\n", 1),
-        ("        // the K quads of a bucket hold partial blocks: add them up (all end with the total)\n",
-         f"        if ({PM} & 32768) return;\n", 1),
+        ("        F.atom(i, n, [&](int t) { return tri[t]; },", f"        if (!({PM} & 8192)) F.atom(i, n, [&](int t) {{ return tri[t]; }},", 1),
+        ("        }\n\n        for (int c0 = 0; c0 < T; c0 += CH) {\n", f"        }}\n        if ({PM} & 16384) return;\n\n        for (int c0 = 0; c0 < T; c0 += CH) {{\n", 1),
+        ("        if constexpr (DYN) {\n            // the quads of a bucket are consecutive and inside one wave",
+         f"        if ({PM} & 32768) return;\n        if constexpr (DYN) {{\n            // the quads of a bucket are consecutive and inside one wave", 1),
     ],
     "ani_angular_bwd.h": [
-        ("            if (t < T) {\n                const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;\n",
-         f"            if (t < T && !({PM} & 512)) {{\n                const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;\n", 1),
+        ("            if (t < T && ((word >> 8) & 0xff) < tile) {",
+         f"            if (t < T && ((word >> 8) & 0xff) < tile && !({PM} & 512)) {{", 1),
         ("        if (role == 0) {\n            float cx = 0.f, cy = 0.f, cz = 0.f;\n",
          f"        if (role == 0 && !({PM} & 1024)) {{\n            float cx = 0.f, cy = 0.f, cz = 0.f;\n", 1),
     ],
