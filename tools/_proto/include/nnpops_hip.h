@@ -98,6 +98,15 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
  * slack: a row that outgrows it is clamped (the builders raise a device-side flag that only check() reads), so call
  * check() every few hundred replays, or after anything that can change the density. */
 int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular_neighbors);
+/* The device-side flag itself: *word receives the DEVICE address of one int32 that the neighbour builders OR into whenever a
+ * compute() overflows a capacity (bit 0 rows / records, bit 1 box too small for the cell stencil, bit 2 cell bins, bit 3 an
+ * atom outgrew the class of its backward launch) and that only nnpops_ani_check() clears.  It is STICKY: a captured graph
+ * that is replayed without any check leaves its overflows there, so a caller can (a) put its own 4-byte asynchronous copy of
+ * the word into the graph, or read it every N replays, without calling into this library, and (b) rely on the next eager
+ * check() -- any later compute() followed by check() -- to report NNPOPS_ERR_CAPACITY for what happened during the replays:
+ * a non-zero word found there means that every evaluation since the previous check may have been incomplete.  The address is
+ * valid for the life of the handle. */
+int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word);
 /* The same check in two halves for callers that have more work to queue behind compute(): _begin (right after compute) queues
  * one single-thread launch that publishes the overflow word and a stamp into pinned host memory and returns 1 -- or 0 when the check cannot be deferred (first calls, while
  * capacities are still being fitted): call nnpops_ani_check() then.  _end (after the consumers of this build have been launched;
@@ -207,6 +216,15 @@ int nnpops_neighbor_pairs_forward(int dtype, int num_atoms, const void* position
 int nnpops_neighbor_pairs_backward(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors,
                                    const void* deltas, const void* distances, const void* grad_deltas,
                                    const void* grad_distances, void* grad_positions, void* stream);
+/* The same with caller-provided scratch (device, 8-byte aligned, nnpops_neighbor_pairs_backward_workspace_bytes(num_atoms) bytes;
+ * the entry point above takes it from the stream-ordered allocator).  Where the reference adds six floating-point atomics per pair
+ * (getNeighborPairsCUDA.cu:96-100), the contributions are added as 64-bit fixed-point numbers on one scale for the call: the
+ * result does not depend on the order of the additions -- bitwise reproducible -- and is within 2^-40 of the largest contribution
+ * per term of the exact sum.  A NaN / infinite contribution makes every output NaN. */
+int64_t nnpops_neighbor_pairs_backward_workspace_bytes(int num_atoms);
+int nnpops_neighbor_pairs_backward_ws(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors,
+                                      const void* deltas, const void* distances, const void* grad_deltas,
+                                      const void* grad_distances, void* grad_positions, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * PME, direct-space part (replaces computeDirect: src/pytorch/pme/pmeCUDA.cu:30-100, pmeCPU.cpp:75-163) -- the immediate

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ani_kernels.h"
+#include "ani_fallback_kernels.h"
 #include "ani_angular_mfma.h"
 #include "ani_angular_bwd.h"
 #include "ani_angular_generic.h"
@@ -21,6 +22,7 @@ using namespace nnpops;
 
 struct nnpops_ani {
     AniParams hp{};                 // host copy of the parameter block
+    AngularConsts ac{};             // what the angular backward kernel needs of it, passed by value (ani_kernels.h)
     AniParams* d_params = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -42,7 +44,8 @@ struct nnpops_ani {
     bool generic = false;           // the angular functions do not factor (or have too many factors): generic kernels
     bool mfma_ok = false;           // at most 32 species pairs can occur in this system
     bool fwd_identity = false;      // angular function m sits at canonical slot m: 16-byte stores of the row
-    int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel
+    int fwd_chunk = 192;            // triples staged in LDS per chunk of the matrix-core forward kernel (large systems; forward_chunk())
+    bool fwd_chunk_forced = false;  // $NNPOPS_ANI_FWD_CHUNK given
     int fwd_waves_per_atom = 2;     // 2: a 128-lane workgroup per atom (half the LDS per wave), 1: a wave per atom
     // Atoms are evaluated in `nstreams` spans on as many HIP streams (fork after the cell grid, join before the caller's
     // stream continues): the per-atom kernels of a span only depend on the same span of the kernel before, so the ramp and
@@ -58,6 +61,8 @@ struct nnpops_ani {
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
     int fwd_occ = 7;                // A/B: register budget of the forward kernel (waves per SIMD)
+    bool fwd_dynamic = false;       // quads dealt out per atom from its bucket sizes (ani_angular_mfma.h: DYN): set at create from the
+                                    // composition (forward_dynamic_pays), $NNPOPS_ANI_FWD_DYN=0 / 1 forces
     int nstreams = 1;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -101,6 +106,12 @@ struct nnpops_ani {
     bool last_used_cells = false;   // the last compute() built a cell grid (d_sorted_atom is a permutation in cell order)
     int* d_work_order = nullptr;    // [N] atoms by DECREASING number of angular neighbours (check() builds it): the schedule of the
     bool work_order_valid = false;  //     angular kernels -- heaviest atoms first, the light ones fill the tail
+    unsigned char* d_class_tile = nullptr;   // [N] pair-matrix edge of the backward launch every atom belongs to (255: no limit)
+    struct BwdClass { int tile, w0, nw; bool two_waves; };
+    std::vector<BwdClass> bwd_classes;       // stretches of d_work_order, by decreasing tile (check() builds them with the order)
+    bool bwd_by_class = true;                // $NNPOPS_ANI_BWD_CLASSES=0: one launch with the full-size pair matrix
+    bool bwd_two_waves = false;              // the atoms average 200 triples or more (check()): two waves per atom in the backward kernel
+    int bwd_class_min = 512;                 // smallest class launched on its own ($NNPOPS_ANI_BWD_CLASS_MIN)
     int cell_atoms = 1800;          // systems of at least this many atoms search their neighbours through the cell grid ($NNPOPS_ANI_CELL_ATOMS)
     int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
@@ -148,6 +159,22 @@ int waves_per_group(size_t lds_wave) {
     for (int wpg : {2, 4})
         if (resident(wpg) >= resident(best)) best = wpg;
     return best;
+}
+
+// Triples staged per chunk of the matrix-core forward.  192 is the optimum of the 10 000-atom liquid, where LDS per atom is
+// occupancy (128 -> 20.9 us, 192 -> 19.0, 256 -> 20.2).  A system small enough for ALL its atoms to be resident at once has no
+// occupancy to lose: there the chunk is as large as the whole triple list of the busiest atom the records allow (one phase 1, one
+// phase 2, two barriers instead of six for a 300-triple atom): the 50-atom molecule of BASELINE config 1 36.3 -> 31.1 us per
+// forward+backward evaluation at 512 (round 4).  fixed_lds_bytes: what the workgroup needs besides the staged factors.
+int forward_chunk(const nnpops_ani* h, size_t fixed_lds_bytes, size_t bytes_per_triple) {
+    if (h->fwd_chunk_forced) return h->fwd_chunk;
+    const int want = std::min(512, (triples_capacity(h->cap_angular) + 15) & ~15);
+    for (int ch : {want, 384, 256}) {
+        if (ch > want || ch <= h->fwd_chunk) continue;
+        const size_t lds = fixed_lds_bytes + (size_t)(ch + 1) * bytes_per_triple;
+        if (lds <= 160 * 1024 && h->hp.N <= 256L * (long)(160 * 1024 / lds)) return ch;
+    }
+    return h->fwd_chunk;
 }
 
 int pad_pow2(int n, int lo) {
@@ -231,7 +258,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
     const size_t lds_group = (size_t)lds_wave * wpg;
     const dim3 grid(div_up(N, wpg)), block(64 * wpg);
     if (forward && h->forward_kernel == 2) {
-        const int CH = h->fwd_chunk;
+        const int CH = forward_chunk(h, (size_t)h->cap_angular * 2 * sizeof(float4), (size_t)(NFRP + NFZP) * sizeof(float));
         const size_t lds2 = ang_fwd_mfma_lds_bytes<NFRP, NFZP>(h->cap_angular, CH);
         const int lw = (int)((lds2 + 15) & ~(size_t)15);
         int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)out & 15) == 0;
@@ -240,7 +267,10 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             int groups = N;
             if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
             const bool uni = h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP;      // one eta, one zeta, no padded factor slots
+            // balanced phase 2 (per-atom quad table, ani_angular_mfma.h: DYN): needs the row assembled in LDS and a lane per bucket
+            const bool dyn = h->fwd_dynamic && (vec_ok & 8) && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * (NFRP + NFZP);
             auto k = h->fwd_occ == 6 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 6> : h->fwd_occ == 8 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 8>
+                   : dyn ? (uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, false, true>)
                    : uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
             hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
@@ -264,15 +294,27 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         // backward_kernel: 1 = one wave per atom, every triple reads its gradient block through the L1 (needs the 16-byte
         // layout); 2 = one wave, gradient row staged in LDS; 3 / 4 = the same two with two waves per atom (A/B only)
         const int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)grad_or_null & 15) == 0;
+        // One launch per class of atoms (by their number of angular neighbours, nnpops_ani_check), each with the pair matrix its
+        // atoms need; without classes -- no work order yet, several spans, $NNPOPS_ANI_BWD_CLASSES=0 -- one launch at full size.
+        nnpops_ani::BwdClass whole{h->cap_angular, sp.w0, sp.nw, h->bwd_two_waves};
+        const bool by_class = h->bwd_by_class && !h->bwd_classes.empty() && sp.ang_order == h->d_work_order && sp.w0 == 0 && sp.nw == h->hp.N;
+        const nnpops_ani::BwdClass* classes = by_class ? h->bwd_classes.data() : &whole;
+        const int nclasses = by_class ? (int)h->bwd_classes.size() : 1;
+        for (int c = 0; c < nclasses; c++) {
+        const int tile = std::min(classes[c].tile, h->cap_angular), cw0 = classes[c].w0, cnw = classes[c].nw;
+        if (cnw <= 0) continue;
         int mode = h->backward_kernel;
         // Dense systems (64 or more record slots): the pair matrix is 27 KB per atom and only 6 atoms fit a CU -- six waves
         // where twenty could run.  Two waves per atom double the waves on the same LDS (1 024 conformers: 1.03 -> 0.97 ms per
         // batch); with the usual 32 slots one wave per atom wins (section 3.5 of DESIGN.md).
-        if (mode == 1 && !h->backward_forced && ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, false) > 16 * 1024) mode = 3;
+        // (round 4: what decides is the work per atom, not the LDS -- with the classes above every class of the conformer batch, the
+        //  32-slot one included, is faster with two waves per atom: 304 us in one launch, 275 by class with this rule on LDS, 246
+        //  with two waves everywhere; the 153-triple atoms of a liquid stay with one wave, 15.8 against 25 us)
+        if (mode == 1 && !h->backward_forced && (classes[c].two_waves || ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, false) > 16 * 1024)) mode = 3;
         if (!vec_ok && (mode == 1 || mode == 3)) mode++;
         const bool glds = mode == 2 || mode == 4;
-        const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(h->cap_angular, h->hp.NB, glds) + 15) & ~(size_t)15;
-        void (*k)(const AniParams*, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
+        const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, glds) + 15) & ~(size_t)15;
+        void (*k)(const AniParams*, const AngularConsts, int, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
                   float4*, float4*, int, int, int, const int*, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
                          : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, true>
@@ -284,9 +326,10 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
-        hipLaunchKernelGGL(k, dim3(div_up(N, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+        hipLaunchKernelGGL(k, dim3(div_up(cnw, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, tile, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
-                           sp.ang_order, sp.w0, sp.nw);
+                           sp.ang_order, cw0, cnw);
+        }
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
         if (lds_group > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_group));
@@ -302,12 +345,14 @@ template <bool TA>
 int dispatch_factors(nnpops_ani* h, bool forward, const float* g, float* out, const Span& sp) {
     const int key = h->nfrp * 100 + h->nfzp;
     switch (key) {
+        case 804:  return launch_angular<TA, 8, 4>(h, forward, g, out, sp);
+#ifndef NNPOPS_ONLY_ANI2X_SHAPE      // (a development build instantiates the ANI-1x / 2x factor shape only: a quarter of the compile time)
         case 404:  return launch_angular<TA, 4, 4>(h, forward, g, out, sp);
         case 408:  return launch_angular<TA, 4, 8>(h, forward, g, out, sp);
-        case 804:  return launch_angular<TA, 8, 4>(h, forward, g, out, sp);
         case 808:  return launch_angular<TA, 8, 8>(h, forward, g, out, sp);
         case 1604: return launch_angular<TA, 16, 4>(h, forward, g, out, sp);
         case 1608: return launch_angular<TA, 16, 8>(h, forward, g, out, sp);
+#endif
         default:
             return fail(NNPOPS_ERR_UNSUPPORTED, "no angular kernel for %d x %d factors", h->hp.nFR, h->hp.nFZ);
     }
@@ -326,7 +371,7 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, cons
         if (lb > 160 * 1024) return fail(NNPOPS_ERR_UNSUPPORTED, "generic angular backward needs %zu bytes of LDS (cap_angular %d)", lb, h->cap_angular);
         auto k = ani_angular_backward_pair<TA, 4, 4, 4, 1, false, true>;
         if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
+        hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, h->hp.NB, (int)lb, nullptr, 0, N);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
@@ -340,23 +385,32 @@ int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out, co
 }
 
 // The fused neighbour build + angular forward (ani_build_forward.h): the ANI-1x / ANI-2x factor shape, two waves per atom.
+// (fused kernel: records + the triple list in LDS besides the staged factors; the builder's scratch shares the staging area)
+int fused_chunk(const nnpops_ani* h) {
+    return forward_chunk(h, (size_t)h->cap_angular * 2 * sizeof(float4) + (size_t)triples_capacity(h->cap_angular) * sizeof(int) + 64, 12 * sizeof(float));
+}
+
 bool build_forward_fused(const nnpops_ani* h, const float* angular) {
     constexpr int kFuseAtoms = 4096;
     const bool want = h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0;
     return want && !h->generic && h->forward_kernel == 2 && h->fwd_waves_per_atom == 2 && h->nfrp == 8 && h->nfzp == 4 &&
            h->nstreams == 1 && h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)angular & 15) == 0 &&
-           build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk) <= 160 * 1024;
+           build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, fused_chunk(h)) <= 160 * 1024;
 }
 
 template <bool TA>
 int launch_build_forward(nnpops_ani* h, const BuildInputs& in, const BuildOutputs& out, float* angular, const Span& sp) {
     int tri_offset = 0;
-    const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, h->fwd_chunk, &tri_offset) + 15) & ~(size_t)15;
+    const int CH = fused_chunk(h);
+    const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, CH, &tri_offset) + 15) & ~(size_t)15;
     const int vec_ok = 1 | (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);
     const bool uni = h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4;
-    auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6> : uni ? ani_build_forward<TA, 8, 4, 7, true> : ani_build_forward<TA, 8, 4, 7>;
+    const bool dyn = h->fwd_dynamic && h->fwd_row_via_lds && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * 12;
+    auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6>
+           : dyn ? (uni ? ani_build_forward<TA, 8, 4, 7, true, true> : ani_build_forward<TA, 8, 4, 7, false, true>)
+           : uni ? ani_build_forward<TA, 8, 4, 7, true> : ani_build_forward<TA, 8, 4, 7>;
     if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, h->fwd_chunk, angular,
+    hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, CH, angular,
                        h->ld_angular, vec_ok, tri_offset, sp.w0, sp.nw);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
@@ -497,7 +551,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         while ((4 << hp.fwd_zero_shift) < num_angular && hp.fwd_zero_shift < 6) hp.fwd_zero_shift++;
         h->fwd_identity = h->fwd_identity && num_angular <= 256;
         h->forward_kernel = h->mfma_ok ? 2 : -1;
-        if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16));
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_CHUNK")) { h->fwd_chunk = std::min(512, std::max(64, (std::atoi(e) + 15) / 16 * 16)); h->fwd_chunk_forced = true; }
         if (const char* e = std::getenv("NNPOPS_ANI_FUSE")) h->fuse_forward = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("NNPOPS_ANI_LPT")) h->lpt = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_CELL_ATOMS")) h->cell_atoms = std::max(1, std::atoi(e));
@@ -505,6 +559,19 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_OCC")) h->fwd_occ = std::atoi(e);
+        {   // Does the per-atom quad table pay?  With one quad set per species pair the step loop of phase 2 runs max_b n_b / K times,
+            // balanced it runs ~T / 32 times; the table costs ~150-250 instructions per atom (two waves).  From the composition:
+            // the largest bucket's expected share of the triples, f = p_a p_b (x 2 for a != b), against 1 / 32 per quad and the K
+            // quads it already has.  Seven equally likely species 1.3, water 1.8 (measured there: 17.6 -> 21.1 us and 16.1 -> 22.9 us
+            // with the table: it loses); H/C/N/O molecules 4.8 (64 steps against 14 for a 400-triple atom: it wins).
+            std::vector<double> frac(num_species, 0.0);
+            for (int i = 0; i < num_atoms; i++) frac[atom_species[i]] += 1.0 / num_atoms;
+            double fmax = 0;
+            for (int a = 0; a < num_species; a++)
+                for (int b = a; b < num_species; b++) fmax = std::max(fmax, frac[a] * frac[b] * (a == b ? 1.0 : 2.0));
+            h->fwd_dynamic = h->mfma_ok && 32.0 * fmax / hp.fwd_split > 3.0;
+        }
+        if (const char* e = std::getenv("NNPOPS_ANI_FWD_DYN")) h->fwd_dynamic = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_STREAMS")) h->nstreams = std::max(1, std::min(4, std::atoi(e)));
         if (const char* e = std::getenv("NNPOPS_ANI_BWD_APG")) h->bwd_atoms_per_group = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_STORE")) h->store_mode = std::atoi(e) & 3;
@@ -544,6 +611,11 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_tile_total, (size_t)h->max_cells / kScanTile + 2))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_work_order, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_class_tile, (size_t)num_atoms))) return cleanup(rc);
+    if (hipMemset(h->d_class_tile, 255, (size_t)num_atoms) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
+    hp.class_tile = h->d_class_tile;
+    if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASSES")) h->bwd_by_class = std::atoi(e) != 0;
+    if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_MIN")) h->bwd_class_min = std::max(0, std::atoi(e));
     if ((rc = dev_alloc(&h->d_unsorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_bucket_offsets, (size_t)num_atoms * (hp.NB + 1)))) return cleanup(rc);
@@ -574,6 +646,19 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (want == 2 && h->mfma_ok) h->forward_kernel = 2;
         else if (want != 2) { h->chunked_forward = hp.NB < 64 && want != 0; h->forward_kernel = h->chunked_forward ? 1 : 0; }
     }
+    {   // the angular backward kernel's constants, by value: every factor slot behind the real ones holds its neutral value
+        AngularConsts& c = h->ac;
+        c.N = hp.N; c.nA = hp.nA;
+        for (int a = 0; a < kMaxFactor; a++) {
+            const bool live = !h->generic && a < hp.nFR;
+            c.fr_c[a] = live ? hp.fr_c[a] : 0.f; c.fr_rs[a] = live ? hp.fr_rs[a] : 0.f; c.fr_negeta[a] = live ? -hp.fr_eta[a] : 0.f;
+        }
+        for (int z = 0; z < 8; z++) {
+            const bool live = !h->generic && z < hp.nFZ;
+            c.fz_zeta[z] = live ? hp.fz_zeta[z] : 1.f; c.fz_cos[z] = live ? hp.fz_cos[z] : 0.f;
+            c.fz_sin[z] = live ? hp.fz_sin[z] : 0.f; c.fz_bias[z] = live ? hp.fz_bias[z] : 0.f;
+        }
+    }
     if (hipMemcpy(h->d_params, &hp, sizeof(AniParams), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess ||
@@ -592,7 +677,7 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     dev_free(h->d_ids); dev_free(h->d_leg_force); dev_free(h->d_centre_force); dev_free(h->d_bucket_offsets);
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
-    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_tile_total); dev_free(h->d_sorted_atom); dev_free(h->d_work_order); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
+    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_tile_total); dev_free(h->d_sorted_atom); dev_free(h->d_work_order); dev_free(h->d_class_tile); dev_free(h->d_unsorted_atom); dev_free(h->d_sorted_pos);
     for (int q = 0; q < 3; q++) {
         if (h->side[q]) (void)hipStreamDestroy(h->side[q]);
         if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
@@ -903,7 +988,37 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         for (size_t a = 0; a < perm.size(); a++) perm[a] = (int)a;
         std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return counts[a] > counts[b]; });
         NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_work_order, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, h->stream));
-        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));      // (perm is a local)
+        // The angular backward is launched class by class along this order (launch_angular): atoms with more than 44 angular
+        // neighbours with the full pair matrix, up to 44 with a 48-slot one, up to 28 with a 32-slot one -- four slots of room for
+        // the frames until the next check(); an atom that outgrows its class is flagged by the builder (kStatOverflow bit 3) and
+        // the classes are rebuilt here.  Records of 32 slots: one class.
+        std::vector<unsigned char> tile_of(perm.size(), 255);
+        h->bwd_classes.clear();
+        {
+            double triples = 0;
+            for (int cnt : counts) triples += 0.5 * cnt * (cnt - 1);
+            h->bwd_two_waves = triples / std::max<size_t>(counts.size(), 1) >= 200.0;
+        }
+        if (h->cap_angular > 48 && h->bwd_by_class) {          // (record capacities are 32, 64, 128, ...)
+            const int tiles[3] = {h->cap_angular, 48, 32}, above[3] = {44, 28, -1};      // class c: atoms with more than above[c] neighbours
+            // (a class of a few hundred atoms is a launch that cannot fill the chip: it takes the next class with it -- at the
+            //  larger pair matrix -- until it has bwd_class_min atoms)
+            int start = 0, pending = 0;
+            for (int c = 0; c < 3; c++) {
+                int end = start;
+                while (end < (int)perm.size() && counts[perm[end]] > above[c]) end++;
+                if (c < 2 && end - start < h->bwd_class_min) continue;     // (start stays: the next class begins where this one would have)
+                double triples = 0;
+                for (int q = start; q < end; q++) triples += 0.5 * counts[perm[q]] * (counts[perm[q]] - 1);
+                const int tile = tiles[pending];               // (the largest matrix of the classes merged into this launch)
+                h->bwd_classes.push_back({tile, start, end - start, end > start && triples / (end - start) >= 200.0});
+                for (int q = start; q < end; q++) tile_of[perm[q]] = (unsigned char)std::min(255, tile);
+                start = end;
+                pending = c + 1;
+            }
+        }
+        NNPOPS_HIP_TRY(hipMemcpyAsync(h->d_class_tile, tile_of.data(), tile_of.size(), hipMemcpyHostToDevice, h->stream));
+        NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));      // (perm and tile_of are locals)
         h->work_order_valid = true;
     }
     // the backward pair matrix only needs to cover the busiest atom (larger atoms still work, tile by tile)
@@ -914,6 +1029,13 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
                      h->tile * (h->tile + 1) + h->tile * (h->tile - 1) / 2 >= h->cap_angular * 4 + 12;
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
+    if (st[kStatOverflow] == 8) {         // nothing overflowed, but an atom outgrew its backward class: regrouped above
+        h->computed = false;
+        if (!want_order)                   // (no order was built: lift every limit)
+            NNPOPS_HIP_TRY(hipMemset(h->d_class_tile, 255, (size_t)h->hp.N));
+        if (!want_order) h->bwd_classes.clear();
+        return fail(NNPOPS_ERR_CAPACITY, "an atom outgrew the pair-matrix class of its backward launch; classes rebuilt, call compute() again");
+    }
     if (st[kStatOverflow] & 4) {          // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins
         const int old_bin = h->bin_cap;
         h->bin_cap *= 2;
@@ -936,6 +1058,10 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         const int old_cap = h->cap, old_ca = h->cap_angular;
         while (h->cap < st[kStatMaxRow]) h->cap *= 2;
         while (h->cap_angular < st[kStatMaxAngular]) h->cap_angular *= 2;
+        if (h->cap_angular != old_ca) {    // (the classes above were cut for the old capacity)
+            h->bwd_classes.clear();
+            NNPOPS_HIP_TRY(hipMemset(h->d_class_tile, 255, (size_t)h->hp.N));
+        }
         if (h->cap_angular > kMaxAngularCap)
             return fail(NNPOPS_ERR_UNSUPPORTED, "an atom has %d neighbours inside the angular cutoff (limit %d)",
                         st[kStatMaxAngular], kMaxAngularCap);
@@ -964,6 +1090,12 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
                         st[kStatMaxRow], old_cap, h->cap);
         }
     }
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word) {
+    NNPOPS_REQUIRE(h != nullptr && word != nullptr, "NULL argument");
+    *word = reinterpret_cast<const int32_t*>(h->d_status + kStatOverflow);
     return NNPOPS_OK;
 }
 

@@ -110,8 +110,8 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 // 20 fewer wave-uniform constants in scalar registers.
 template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, bool UNI = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
-    const AniParams* __restrict__ P, int cap, int capA, const float4* __restrict__ recA_g, const float4* __restrict__ recB_g,
-    const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
+    const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, int tile, const float4* __restrict__ recA_g,
+    const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
     const float* __restrict__ angular_grad, int ld_angular, float4* __restrict__ leg_force, float4* __restrict__ centre_force,
     int vec_ok, int NB, int lds_per_atom, const int* __restrict__ order, int w0, int nw) {     // positions [w0, w0 + nw) of `order`
     constexpr int BLK = NFRP * NFZP;
@@ -123,50 +123,67 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     // one wave per atom: a workgroup holds blockDim / 64 independent atoms (fewer, larger dispatches), each with its own LDS slice
     const int atoms_per_group = WPA == 2 ? 1 : (int)(blockDim.x >> 6);
     const int slot_in_group = WPA == 2 ? 0 : wig;
-    const int nA = P->nA, nFR = P->nFR, nFZ = P->nFZ;
-    const int tile = capA, tstride = capA + 1;
+    const int nA = C.nA;
+    // tile: edge of the LDS pair matrix and number of record slots of THIS launch (<= capA, the stride of the global arrays): check()
+    // groups the atoms by their number of angular neighbours and the groups are launched one after the other, each with the
+    // LDS its atoms need -- 7 KB for up to 32 neighbours, 15 KB for 48, 27 KB for 64: in a batch of compact molecules (BASELINE
+    // config 4) two thirds of the atoms have at most 32 and ran six to a CU because 1 % have more than 48.
+    const int tstride = tile + 1;
     auto sync = [&]() {
         if constexpr (WPA == 2) __syncthreads();
         else wave_fence();
     };
 
     char* cursor = lds_raw + (size_t)slot_in_group * lds_per_atom;
-    float4* recA = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
-    float4* recB = (float4*)cursor;       cursor += (size_t)capA * sizeof(float4);
+    float4* recA = (float4*)cursor;       cursor += (size_t)tile * sizeof(float4);
+    float4* recB = (float4*)cursor;       cursor += (size_t)tile * sizeof(float4);
     float* grow = (float*)cursor;         if (GLDS) cursor += (size_t)NB * BLK * sizeof(float);   // upstream gradient row, canonical [bucket][a][z]
     float* Ma = (float*)cursor;           // alpha[tile][tile + 1]: Ma[e][x] = coefficient of A_e in the force of triple {e, x} on e
     float* Mb = Ma + tile * tstride;      // beta, once per unordered pair (p < q), triangular
 
     static_assert(!(GENERIC && GLDS), "generic function lists read their gradients from global memory");
+    // (constants from the by-value block, padded on the host: no dependent scalar loads in the workgroup's prologue, ani_kernels.h)
     float frc[NFRP], frs[NFRP], fren[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];
 #pragma unroll
     for (int a = 0; a < NFRP; a++) {
-        frc[a] = UNI ? P->fr_c[0] : (a < nFR ? P->fr_c[a] : 0.f);
-        frs[a] = a < nFR ? P->fr_rs[a] : 0.f;
-        fren[a] = UNI ? -P->fr_eta[0] : (a < nFR ? -P->fr_eta[a] : 0.f);
+        frc[a] = C.fr_c[UNI ? 0 : a];
+        frs[a] = C.fr_rs[a];
+        fren[a] = C.fr_negeta[UNI ? 0 : a];
     }
 #pragma unroll
     for (int z = 0; z < NFZP; z++) {
-        zz[z] = UNI ? P->fz_zeta[0] : (z < nFZ ? P->fz_zeta[z] : 1.f);
-        zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
-        zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
-        zb[z] = UNI ? P->fz_bias[0] : (z < nFZ ? P->fz_bias[z] : 0.f);
+        zz[z] = C.fz_zeta[UNI ? 0 : z];
+        zc[z] = C.fz_cos[z];
+        zs[z] = C.fz_sin[z];
+        zb[z] = C.fz_bias[UNI ? 0 : z];
     }
 
     const int stride_atoms = gridDim.x * atoms_per_group;
     for (int w = blockIdx.x * atoms_per_group + slot_in_group; w < nw; w += stride_atoms) {
         int i = order ? order[w0 + w] : w0 + w;
-        if ((unsigned)i >= (unsigned)P->N) i = w0 + w;         // (a void grid build leaves no valid order: stay in bounds)
+        if ((unsigned)i >= (unsigned)C.N) i = w0 + w;          // (a void grid build leaves no valid order: stay in bounds)
+        // (the first batch of triple words and the first 64 records are requested before the counts are known: what lies behind
+        //  the atom's last triple / record is allocated and ignored -- one dependent round trip less per atom, ani_angular_mfma.h)
+        const int tid = role * 64 + lane;
+        const int capT = triples_capacity(capA);
+        const int* tri = tri_g + (size_t)i * capT;
+        int word = tid < capT ? tri[tid] : 0;
+        float4 recA_first = make_float4(0.f, 0.f, 0.f, 0.f), recB_first = recA_first;
+        if constexpr (WPA == 2) {
+            recA_first = (role == 0 ? recA_g : recB_g)[(size_t)i * capA + min(lane, capA - 1)];
+        } else {
+            recA_first = recA_g[(size_t)i * capA + min(lane, capA - 1)];
+            recB_first = recB_g[(size_t)i * capA + min(lane, capA - 1)];
+        }
         int n, nro;
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
+        n = min(n, tile);                                      // (an atom that outgrew its class was flagged by the builder; stay inside the LDS)
         if (n < 2) {                                           // no triples (uniform for the workgroup): a lone leg carries no force
             if (n == 1 && role == 0 && lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
         }
         const int T = (n * (n - 1)) / 2;
-        const int tid = role * 64 + lane;
-        const int* tri = tri_g + (size_t)i * triples_capacity(capA);
-        int word = tid < T ? tri[tid] : 0;
+        if (tid >= T) word = 0;
         const float* g = angular_grad + (size_t)i * ld_angular;
 
         // upstream gradient row -> LDS in canonical [bucket][a][z] order (a copy: no scaling, see triple_forces_pk)
@@ -184,9 +201,11 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         if constexpr (WPA == 2) {
             const float4* src = (role == 0 ? recA_g : recB_g) + (size_t)i * capA;
             float4* dst = role == 0 ? recA : recB;
-            for (int e = lane; e < n; e += 64) dst[e] = src[e];
+            if (lane < tile) dst[lane] = recA_first;           // (not "< n": the compiler would sink the load behind the counts)
+            for (int e = lane + 64; e < n; e += 64) dst[e] = src[e];
         } else {
-            load_angular_records(recA_g + (size_t)i * capA, recB_g + (size_t)i * capA, n, recA, recB);
+            if (lane < tile) { recA[lane] = recA_first; recB[lane] = recB_first; }
+            for (int e = lane + 64; e < n; e += 64) { recA[e] = recA_g[(size_t)i * capA + e]; recB[e] = recB_g[(size_t)i * capA + e]; }
         }
         sync();
 
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         for (int base = role * 64; base < T; base += NT) {
             const int t = base + lane;
             const int next_word = (t + NT < T) ? tri[t + NT] : 0;
-            if (t < T) {
+            if (t < T && ((word >> 8) & 0xff) < tile) {        // (the second test only fails for an atom that outgrew its class: its list is laid out for more slots)
                 const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;
                 float ap, aq, bt;
                 if constexpr (GENERIC) {

@@ -36,7 +36,8 @@ constexpr int kFwdSlots = 32;          // 2 sets x 16 quads
 
 template <int NFRP, int NFZP>
 __host__ __device__ inline size_t ang_fwd_mfma_lds_bytes(int capA, int CH) {
-    return (size_t)capA * 2 * sizeof(float4) + (size_t)(CH + 1) * (NFRP + NFZP) * sizeof(float);
+    // records | staged factors (+ the zero record) | 32 x 2 ints: the per-atom quad table of the balanced phase 2 (DYN)
+    return (size_t)capA * 2 * sizeof(float4) + (size_t)(CH + 1) * (NFRP + NFZP) * sizeof(float) + 64 * sizeof(int);
 }
 
 template <int W>
@@ -79,8 +80,16 @@ __device__ __forceinline__ const float* lds_ptr(int byte_address) {
 // UNI: every radial factor has the same eta and every angular factor the same zeta (ANI-1x / 1ccx / 2x: one EtaA, one Zeta)
 // and no factor slot is padding: 13 fewer wave-uniform constants to hold in scalar registers through phase 1 -- the kernel
 // parks scalars in vector lanes when they run out (one vector instruction to park, one to fetch back).
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, bool UNI = false>
+// DYN (two waves per atom, row assembled in LDS, at most 63 buckets): the quads are dealt out PER ATOM.  With a fixed quad per species
+// pair the step loop runs max_b n_b times -- 14 where the mean is 5.4 for seven equally likely species -- and the other quads
+// multiply zeros.  Here the first wave finds, from the atom's bucket sizes, the smallest piece length L for which
+// sum_b ceil(n_b / L) <= 32 quads, and writes a table {bucket, first triple, count, part, parts} per quad; a bucket larger than L is
+// shared by consecutive quads of ONE wave (never across the two), whose partial blocks are added with a segmented shuffle before
+// the row is assembled; species pairs without triples get no quad at all (the row is zero-filled first).  Steps: 14 -> ~9 for the
+// 7-species liquid, 9 -> 5 for water.
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, bool UNI = false, bool DYN = false>
 struct MfmaForward {
+    static_assert(!DYN || WPA == 2, "the per-atom quad table is built by the first of two waves");
     static constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
     static constexpr int NS = 2 / WPA;                         // quad sets run by this wave
 
@@ -89,6 +98,8 @@ struct MfmaForward {
     float* angular;
     float4 *recA, *recB;                  // [capA] each, LDS
     float* fac;                           // [CH + 1][REC], LDS; the last record stays zero
+    int* qtab;                            // [32][2], LDS (DYN): quad slot -> {first triple | count << 16, bucket | part << 8 | parts << 16}
+    int dpart, dparts;                    // DYN: this quad's part of its bucket, and how many quads share the bucket
     int lane, role, quad, nn;
     int NB, nA, K, logK;
     int fac_addr, zdelta, zero_addr;      // (LDS addresses of phase 2 are kept as 32-bit byte offsets: one register per quad stream)
@@ -112,6 +123,7 @@ struct MfmaForward {
         recA = (float4*)lds;
         recB = recA + capA;
         fac = (float*)(recB + capA);
+        qtab = (int*)(fac + (size_t)(CH + 1) * REC);
         fac_addr = (int)(uintptr_t)fac + (lane & 3) * (NR4 * 4);                   // this lane's R pieces in record 0
         zdelta = NFRP * 4 + (lane & 3) * (NZ4 * 4) - (lane & 3) * (NR4 * 4);       // from the R pieces to the Z pieces
         zero_addr = fac_addr + CH * (REC * 4);
@@ -143,12 +155,43 @@ struct MfmaForward {
         const int T = (n * (n - 1)) / 2;
         int word = role * 64 + lane < T ? tri_at(role * 64 + lane) : 0;        // my first batch of triple words, in flight early
         int sstart[NS], send[NS];
+        if constexpr (DYN) {
+            if (role == 0) {
+                // lane b = bucket b: its size from two neighbouring offsets (one coalesced load of the atom's NB + 1 offsets)
+                const int off = lane <= NB ? boff_at(lane) : 0;
+                const int off1 = __shfl_down(off, 1, 64);
+                const int nb = (lane < NB && T > 0) ? off1 - off : 0;
+                if (lane < 32) { qtab[2 * lane] = 0; qtab[2 * lane + 1] = 0; }
+                // piece length: the estimate T / (32 - nonempty / 2) (half a piece is lost per bucket to rounding), then up until it fits
+                const int nz = __popcll(__ballot(nb > 0));
+                int L = max(1, (2 * T + (63 - nz)) / max(1, 64 - nz));
+                int k, q0, shift;
+                for (;;) {
+                    k = (int)(((float)(nb + L - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)L));     // ceil(nb / L), exact for these sizes
+                    const int incl = wave_prefix_sum(k);
+                    q0 = incl - k;
+                    // a bucket's quads must sit in ONE wave (slots 0-15 / 16-31): the one that would straddle starts at 16
+                    shift = wave_max_nonneg((q0 < 16 && q0 + k > 16) ? 16 - q0 : 0);
+                    if (__builtin_amdgcn_readlane(incl, 63) + shift <= 32) break;
+                    L++;
+                }
+                if (q0 + k > 16) q0 += shift;
+                const int kmax = wave_max_nonneg(k);
+                wave_fence();                                  // (the zeros above)
+                for (int j = 0; j < kmax; j++)
+                    if (j < k) {
+                        qtab[2 * (q0 + j)] = (off + j * L) | (min(L, nb - j * L) << 16);
+                        qtab[2 * (q0 + j) + 1] = lane | (j << 8) | (k << 16);
+                    }
+            }
+        } else {
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const int b = max(sbk[s], 0);
-            const int lo = boff_at(b), hi = boff_at(b + 1);
-            sstart[s] = (sbk[s] >= 0 && T > 0) ? lo : 0;
-            send[s] = (sbk[s] >= 0 && T > 0) ? hi : 0;
+            for (int s = 0; s < NS; s++) {
+                const int b = max(sbk[s], 0);
+                const int lo = boff_at(b), hi = boff_at(b + 1);
+                sstart[s] = (sbk[s] >= 0 && T > 0) ? lo : 0;
+                send[s] = (sbk[s] >= 0 && T > 0) ? hi : 0;
+            }
         }
         stage_records();
 
@@ -160,6 +203,14 @@ struct MfmaForward {
 #pragma unroll
                 for (int rh = 0; rh < NR4; rh++) acc[s][zh][rh] = mfma_f4{0.f, 0.f, 0.f, 0.f};
         sync();
+        if constexpr (DYN) {                                   // my quad's entry of the table
+            const int2 e = *reinterpret_cast<const int2*>(qtab + 2 * (role * 16 + quad));
+            dparts = e.y >> 16; dpart = (e.y >> 8) & 0xff;
+            sbk[0] = dparts > 0 ? (e.y & 0xff) : -1;
+            spart[0] = dpart;
+            sstart[0] = e.x & 0xffff;
+            send[0] = sstart[0] + (e.x >> 16);
+        }
 
         for (int c0 = 0; c0 < T; c0 += CH) {
             const int c1 = min(c0 + CH, T);
@@ -203,13 +254,18 @@ struct MfmaForward {
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const int lo = max(sstart[s], c0), hi = min(send[s], c1);
-                const int first = lo + ((spart[s] - (lo - sstart[s])) & (K - 1));     // triples of a bucket are dealt round-robin
-                cnt[s] = max(0, (hi - first + K - 1) >> logK);
-                ra[s] = fac_addr + (first - c0) * (REC * 4);
+                if constexpr (DYN) {                           // a quad's piece is a run of consecutive triples
+                    cnt[s] = max(0, hi - lo);
+                    ra[s] = fac_addr + (lo - c0) * (REC * 4);
+                } else {
+                    const int first = lo + ((spart[s] - (lo - sstart[s])) & (K - 1));     // triples of a bucket are dealt round-robin
+                    cnt[s] = max(0, (hi - first + K - 1) >> logK);
+                    ra[s] = fac_addr + (first - c0) * (REC * 4);
+                }
                 cmax = max(cmax, cnt[s]);
             }
             const int steps = wave_max_nonneg(cmax);             // wave-uniform trip count
-            const int stride = K * REC * 4;
+            const int stride = (DYN ? 1 : K) * REC * 4;
             float ar[NS][NR4], az[NS][NZ4], br[NS][NR4], bz[NS][NZ4];      // operand registers, ping-pong
             auto fetch = [&](int k, float (&r)[NS][NR4], float (&z)[NS][NZ4]) {
 #pragma unroll
@@ -241,6 +297,22 @@ struct MfmaForward {
             if (c1 < T) sync();                                // (the staging area is about to be overwritten)
         }
 
+        if constexpr (DYN) {
+            // the quads of a bucket are consecutive and inside one wave: segmented suffix sum, part 0 ends with the total
+            const int kw = wave_max_nonneg(dparts);
+            for (int d = 1; d < kw; d <<= 1) {
+                const bool take = dpart + d < dparts;
+#pragma unroll
+                for (int zh = 0; zh < NZ4; zh++)
+#pragma unroll
+                    for (int rh = 0; rh < NR4; rh++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float o = __shfl_down(acc[0][zh][rh][r], 4 * d, 64);
+                            acc[0][zh][rh][r] += take ? o : 0.f;
+                        }
+            }
+        } else {
         // the K quads of a bucket hold partial blocks: add them up (all end with the total)
         for (int off = 4; off < 4 * K; off <<= 1) {
 #pragma unroll
@@ -251,6 +323,7 @@ struct MfmaForward {
                     for (int rh = 0; rh < NR4; rh++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) acc[s][zh][rh][r] += __shfl_xor(acc[s][zh][rh][r], off, 64);
+        }
         }
 
         // ---------------- epilogue: registers -> the atom's output row ----------------
@@ -266,7 +339,7 @@ struct MfmaForward {
             const int tid = role * 64 + lane, pieces = (NB * nA) >> 2;
             const int nabs = P->fwd_nabsent;
             sync();                                            // every wave is done with the staged factors
-            if (nabs > 0) {                                    // blocks nobody owns are zero
+            if (DYN || nabs > 0) {                             // blocks nobody owns are zero (DYN: species pairs without triples have no quad)
                 for (int q = tid; q < pieces; q += NT) reinterpret_cast<float4*>(rowbuf)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 sync();
             }
@@ -329,7 +402,7 @@ struct MfmaForward {
     }
 };
 
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC, bool UNI = false>
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC, bool UNI = false, bool DYN = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
     const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
@@ -338,7 +411,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());        // wave-uniform: keeps per-atom addressing scalar
     const int slot_in_group = WPA == 2 ? 0 : wig;               // which atom of the workgroup
-    MfmaForward<TORCHANI, NFRP, NFZP, WPA, UNI> F;
+    MfmaForward<TORCHANI, NFRP, NFZP, WPA, UNI, DYN> F;
     F.init(P, capA, CH, vec_ok, angular, ld_angular, lds_raw + (size_t)slot_in_group * lds_per_atom, WPA == 2 ? wig : 0);
     F.write_zero_record();
     const int lane = F.lane, NB = F.NB;
@@ -352,6 +425,9 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
         const int* tri = tri_g + (size_t)i * triples_capacity(capA);
         const int* boff_g = P->bucket_offsets + (size_t)i * (NB + 1);
+        // (Requesting the first triple words and records BEFORE the counts are known -- one dependent round trip less per atom --
+        //  was built and measured in round 4: no gain, and the values it keeps alive cost this kernel, which sits exactly at the
+        //  72 registers of seven waves per SIMD, 20 bytes of scratch: 17.5 -> 18.7 us.  The backward kernel keeps that form.)
         F.atom(i, n, [&](int t) { return tri[t]; }, [&](int b) { return boff_g[b]; },
                [&]() {
                    if constexpr (WPA == 2) {                   // one array each

@@ -22,7 +22,7 @@ namespace nnpops {
 template <int NFRP, int NFZP>
 __host__ __device__ inline size_t build_forward_lds_bytes(int cap, int capA, int S, int NB, int CH, int* tri_offset = nullptr) {
     const size_t recs = (size_t)capA * 2 * sizeof(float4);
-    const size_t staging = (size_t)(CH + 1) * (NFRP + NFZP) * sizeof(float);
+    const size_t staging = (size_t)(CH + 1) * (NFRP + NFZP) * sizeof(float) + 64 * sizeof(int);      // (+ the quad table of the balanced phase 2)
     const size_t builder = ((builder_lds_bytes(cap, S, NB) + 15) & ~(size_t)15) + 32;
     const size_t mid = ((staging > builder ? staging : builder) + 15) & ~(size_t)15;
     if (tri_offset) *tri_offset = (int)(recs + mid);
@@ -52,7 +52,7 @@ struct BuildOutputs {
     int ld_radial;
 };
 
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, bool UNI = false>
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, bool UNI = false, bool DYN = false>
 __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* __restrict__ P, BuildInputs in, BuildOutputs out, int cap,
                                                               int capA, int CH, float* __restrict__ angular, int ld_angular,
                                                               int vec_ok, int tri_offset, int w0, int nw) {
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
                 out.cnt_a[i] = na; out.cnt_ro[i] = nro;
                 shared[0] = na; shared[1] = nro;
                 if (na > capA || na + nro > cap) atomicOr(&out.status[kStatOverflow], 1);      // (ani_kernels.h: builders flag their own overflow)
+                else if (na > (int)P->class_tile[i]) atomicOr(&out.status[kStatOverflow], 8);
             }
         }
         __syncthreads();
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
         __syncthreads();
         // (the forward's constants are set up here, not before the build: they would be live across it -- 32 scalars the
         //  build has no room for)
-        MfmaForward<TORCHANI, NFRP, NFZP, 2, UNI> F;
+        MfmaForward<TORCHANI, NFRP, NFZP, 2, UNI, DYN> F;
         F.init(P, capA, CH, vec_ok, angular, ld_angular, lds_raw, role);
         F.atom(i, n, [&](int t) { return tri_l[t]; }, [&](int bk) { return G.boff[bk]; }, [&]() { F.write_zero_record(); });
     }

@@ -279,6 +279,7 @@ static __global__ void order_cells(int N, const float* __restrict__ pos, const C
 // A bin that overflows clears grid.ok; the owner grows the bins in its check() and rebuilds.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBinnedAtoms = 65536;
+constexpr int kPairsBinnedAtoms = 200000, kPairsBinCap = 128;    // the stateless getNeighborPairs op: <= 8 192 cells x 128 ids (4 MiB of workspace)
 constexpr int kBinnedCells = 8192;
 constexpr int kBinnedThreads = 256;
 
@@ -365,7 +366,12 @@ static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const 
     if (c >= 0) atom_cell[i] = c;
 }
 
-static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, const float* __restrict__ pos,
+// (T threads per block.  Every block scans the whole histogram -- 23 cells per thread at 256 threads for the 5 832-cell grid of
+//  the 10 000-atom frame -- but blocks of 1 024 threads, whose scan is four times shorter, measured SLOWER: the two grid kernels
+//  together 8.9 -> 10.9 us (round 4, interleaved A/B): with 10 blocks instead of 40 the ranking loads of the atoms, the other half
+//  of the kernel, run on 10 CUs.)
+template <int T>
+static __global__ __launch_bounds__(T) void order_binned(int N, const float* __restrict__ pos,
                                                                       const int* __restrict__ tag, CellGrid* __restrict__ grid,
                                                                       const int* __restrict__ hist,
                                                                       const int* __restrict__ bins, int bin_cap,
@@ -373,12 +379,12 @@ static __global__ __launch_bounds__(kBinnedThreads) void order_binned(int N, con
                                                                       int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos,
                                                                       int* __restrict__ sorted_cell) {
     __shared__ int s_start[kBinnedCells + 1];
-    __shared__ int wave_tot[kBinnedThreads / 64];
+    __shared__ int wave_tot[T / 64];
     const CellGrid g = *grid;
-    const int i = blockIdx.x * kBinnedThreads + threadIdx.x;
+    const int i = blockIdx.x * T + threadIdx.x;
     const int c = (i < N && g.ok) ? atom_cell[i] : 0;
-    order_block<kBinnedThreads>(i, c, N, g, grid, pos, tag, hist, bins, bin_cap, cell_start, sorted_atom, sorted_pos, sorted_cell,
-                                s_start, wave_tot);
+    order_block<T>(i, c, N, g, grid, pos, tag, hist, bins, bin_cap, cell_start, sorted_atom, sorted_pos, sorted_cell,
+                   s_start, wave_tot);
 }
 
 // The same stencil as ONE flat candidate index space: lane r < 18 looks up range r, a wave scan gives
@@ -627,7 +633,9 @@ struct CellBuffers {
 };
 
 static inline bool cell_build_is_binned(int N, bool periodic, const CellBuffers& b) {
-    return periodic && b.hist != nullptr && b.bins != nullptr && N <= kBinnedAtoms;
+    // (callers hand over hist / bins only for systems their bins are sized for: the stateful handles up to kBinnedAtoms atoms, with
+    //  bins that grow in check(); getNeighborPairs up to kPairsBinnedAtoms with a fixed bin of 128 ids per cell)
+    return periodic && b.hist != nullptr && b.bins != nullptr;
 }
 
 static inline void launch_cell_build(hipStream_t stream, int N, const float* pos, const float* box, bool periodic, float cutoff,
@@ -636,7 +644,7 @@ static inline void launch_cell_build(hipStream_t stream, int N, const float* pos
     if (cell_build_is_binned(N, periodic, b)) {
         hipLaunchKernelGGL(bin_atoms, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, box, cutoff, b.max_cells, b.grid, b.hist, b.bins,
                            b.bin_cap, b.atom_cell, b.fine);
-        hipLaunchKernelGGL(order_binned, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, tag, b.grid, b.hist, b.bins, b.bin_cap,
+        hipLaunchKernelGGL(order_binned<kBinnedThreads>, dim3(nb), dim3(kBinnedThreads), 0, stream, N, pos, tag, b.grid, b.hist, b.bins, b.bin_cap,
                            b.atom_cell, b.cell_start, b.sorted_atom, b.sorted_pos, b.sorted_cell);
         return;
     }

@@ -352,22 +352,99 @@ __global__ void to_float_positions(int n3, const T* __restrict__ in, float* __re
     if (k < n3) out[k] = (float)in[k];
 }
 
+// ---- backward: forces of the pairs added up WITHOUT float atomics --------------------------------------------------
+// The reference scatters six floating-point atomicAdds per pair (getNeighborPairsCUDA.cu:93-100): the sums depend on the order
+// in which the hardware happens to serve them.  The op receives nothing but the four tensors -- any list, in any order, possibly
+// edited by the caller -- so there is no row structure to rely on and no owner to gather.  Instead every contribution is turned
+// into a 64-bit FIXED-POINT number on one scale for the whole call (2^40 units for the largest contribution of the call) and added
+// with integer atomics: integer addition is associative, the result is the same bit pattern whatever the order (round 4;
+// tests/test_neighbor_pairs_gpu.py::test_backward_bitwise_reproducible).  One unit is 2^-40 of the largest contribution: 9e-13,
+// far below the resolution of either dtype's own summation.  Three launches: the largest |g| of the call (one integer atomicMax per
+// block), the accumulation, the conversion back.
 template <typename T>
-__global__ void pairs_backward(long long num_slots, const int32_t* __restrict__ neighbors, const T* __restrict__ deltas,
-                               const T* __restrict__ distances, const T* __restrict__ grad_deltas,
-                               const T* __restrict__ grad_distances, T* __restrict__ grad_positions) {
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= num_slots) return;
-    const int a = neighbors[k];
+__device__ __forceinline__ void pair_gradient(long long k, long long num_slots, const int32_t* __restrict__ neighbors,
+                                              const T* __restrict__ deltas, const T* __restrict__ distances,
+                                              const T* __restrict__ grad_deltas, const T* __restrict__ grad_distances, int& a, int& b,
+                                              T (&g)[3]) {
+    a = neighbors[k];
+    b = -1;
+    g[0] = g[1] = g[2] = T(0);
     if (a < 0) return;                                                   // CUDA.cu:93-94
-    const int b = neighbors[num_slots + k];
+    b = neighbors[num_slots + k];
     const T gd = grad_distances[k] / distances[k];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const T g = grad_deltas[3 * k + c] + deltas[3 * k + c] * gd;     // CUDA.cu:96-99
-        atomicAdd(&grad_positions[3 * a + c], g);
-        atomicAdd(&grad_positions[3 * b + c], -g);
+    for (int c = 0; c < 3; c++) g[c] = grad_deltas[3 * k + c] + deltas[3 * k + c] * gd;     // CUDA.cu:96-99
+}
+
+// scratch: [0] the bit pattern of the largest |g| (non-negative IEEE numbers order like integers), [1] set when a contribution
+// was NaN / infinite, [2 .. 2 + 3N) the accumulators
+template <typename T>
+__global__ __launch_bounds__(256) void pairs_backward_max(long long num_slots, const int32_t* __restrict__ neighbors,
+                                                          const T* __restrict__ deltas, const T* __restrict__ distances,
+                                                          const T* __restrict__ grad_deltas, const T* __restrict__ grad_distances,
+                                                          unsigned long long* __restrict__ scratch) {
+    __shared__ double red[256 / 64];
+    double m = 0.0;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < num_slots; k += (long long)gridDim.x * 256) {
+        int a, b;
+        T g[3];
+        pair_gradient(k, num_slots, neighbors, deltas, distances, grad_deltas, grad_distances, a, b, g);
+        const double v = fmax(fabs((double)g[0]), fmax(fabs((double)g[1]), fabs((double)g[2])));
+        if (v == v && v <= 1.7e308) m = fmax(m, v);                      // (NaN / inf contributions do not set the scale)
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / 64; w++) m = fmax(m, red[w]);
+        atomicMax(&scratch[0], (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+__device__ __forceinline__ double pairs_fixed_scale(const unsigned long long* scratch) {
+    const double m = __longlong_as_double((long long)scratch[0]);
+    if (!(m > 0.0)) return 1.0;
+    int e;
+    frexp(m, &e);                                                        // m = f 2^e, 1/2 <= f < 1
+    return ldexp(1.0, 40 - e);                                           // |g| scale < 2^40: 2^22 such terms fit an int64
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairs_backward_accumulate(long long num_slots, const int32_t* __restrict__ neighbors,
+                                                                 const T* __restrict__ deltas, const T* __restrict__ distances,
+                                                                 const T* __restrict__ grad_deltas, const T* __restrict__ grad_distances,
+                                                                 unsigned long long* __restrict__ scratch) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= num_slots) return;
+    int a, b;
+    T g[3];
+    pair_gradient(k, num_slots, neighbors, deltas, distances, grad_deltas, grad_distances, a, b, g);
+    if (a < 0) return;
+    const double scale = pairs_fixed_scale(scratch);
+    unsigned long long* acc = scratch + 2;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double v = (double)g[c] * scale;
+        // (a NaN / infinite gradient poisons two atoms in the reference; here it cannot enter the fixed-point sum: it raises the
+        //  flag word, and every output of the call is NaN)
+        const long long q = (v == v && fabs(v) < 9.0e18) ? __double2ll_rn(v) : 0;
+        if (q != 0) {
+            atomicAdd(&acc[3 * (size_t)a + c], (unsigned long long)q);
+            atomicAdd(&acc[3 * (size_t)b + c], (unsigned long long)(-q));
+        }
+        if (!(v == v) || !(fabs(v) < 9.0e18)) scratch[1] = 1;        // (benign race: everyone writes the same value)
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairs_backward_finish(int n3, const unsigned long long* __restrict__ scratch, T* __restrict__ grad_positions) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n3) return;
+    const bool poisoned = scratch[1] != 0;
+    const double inv = 1.0 / pairs_fixed_scale(scratch);
+    const double v = (double)(long long)scratch[2 + k] * inv;
+    grad_positions[k] = poisoned ? (T)NAN : (T)v;
 }
 
 // workspace layout (bytes): row_count[N+1] | row_offset[N+1] | cell grid arrays | float positions | row staging
@@ -386,6 +463,8 @@ struct Workspace {
     float* fpos;
     int* st_col;          // [N][kStageCap]
     void* st_rec;         // [N][kStageCap] Staged<T> (sized for double)
+    int* hist;            // [kHistWords] two-launch grid build (periodic systems of up to kPairsBinnedAtoms atoms), zeroed by every call
+    int* bins;            // [kBinnedCells][kPairsBinCap]
     int max_cells;
 };
 
@@ -412,6 +491,9 @@ size_t carve(Workspace* w, char* base, int N) {
     const bool staged = N >= kCellThreshold;          // only the cell-grid path stages rows
     tmp.st_col = (int*)take(staged ? sizeof(int) * (size_t)N * kStageCap : 0);
     tmp.st_rec = (void*)take(staged ? sizeof(Staged<double>) * (size_t)N * kStageCap : 0);
+    const bool binned = staged && N <= kPairsBinnedAtoms;
+    tmp.hist = (int*)take(binned ? sizeof(int) * kHistWords : 0);
+    tmp.bins = (int*)take(binned ? sizeof(int) * (size_t)kBinnedCells * kPairsBinCap : 0);
     if (w) *w = tmp;
     return off;
 }
@@ -464,8 +546,17 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
             }
         }
         // (the grid also emits cell-ordered positions; they land in scratch this op does not otherwise use)
-        const CellBuffers cb{w.grid, w.cell_count, w.cell_start, w.atom_cell, w.atom_rank, w.unsorted_atom, w.sorted_atom,
-                             w.sorted_pos, w.max_cells};
+        CellBuffers cb{w.grid, w.cell_count, w.cell_start, w.atom_cell, w.atom_rank, w.unsorted_atom, w.sorted_atom,
+                       w.sorted_pos, w.max_cells};
+        // A periodic system of up to kPairsBinnedAtoms atoms takes the two-launch grid of the stateful handles (celllist.h:
+        // bin_atoms + order_binned) behind ONE memset of its 32 KiB histogram -- three launches where grid_setup / assign_cells /
+        // scan_cells / fill_cells / order_cells are five (round 4; the workspace is the caller's and arrives dirty, so the
+        // histogram cannot be left clean by the previous call as the handles do).  A cell with more than kPairsBinCap atoms
+        // (nine times liquid density at the usual cell size) clears grid.ok: every row then scans all columns -- correct, slow.
+        if (periodic && N <= kPairsBinnedAtoms) {
+            NNPOPS_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(int) * kHistWords, stream));
+            cb.hist = w.hist; cb.bins = w.bins; cb.bin_cap = kPairsBinCap;
+        }
         launch_cell_build(stream, N, fpos, fbox, periodic != 0, (float)cutoff, nullptr, cb);
         const dim3 rgrid(div_up(N, 4)), rblock(256);       // one wave per row
         Staged<T>* st_rec = (Staged<T>*)w.st_rec;
@@ -491,12 +582,17 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
 
 template <typename T>
 int backward_impl(int N, long long num_slots, const int32_t* neighbors, const T* deltas, const T* distances,
-                  const T* grad_deltas, const T* grad_distances, T* grad_positions, hipStream_t stream) {
-    NNPOPS_HIP_TRY(hipMemsetAsync(grad_positions, 0, sizeof(T) * 3 * (size_t)N, stream));
-    if (num_slots <= 0) return NNPOPS_OK;
-    const int tb = 256;
-    hipLaunchKernelGGL(pairs_backward<T>, dim3(div_up(num_slots, tb)), dim3(tb), 0, stream, num_slots, neighbors, deltas,
-                       distances, grad_deltas, grad_distances, grad_positions);
+                  const T* grad_deltas, const T* grad_distances, T* grad_positions, void* workspace, hipStream_t stream) {
+    unsigned long long* scratch = (unsigned long long*)workspace;
+    NNPOPS_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(unsigned long long) * (2 + 3 * (size_t)N), stream));
+    if (num_slots > 0) {
+        const int nb_max = (int)std::min<long long>(div_up(num_slots, 256), 2048);
+        hipLaunchKernelGGL(pairs_backward_max<T>, dim3(nb_max), dim3(256), 0, stream, num_slots, neighbors, deltas, distances, grad_deltas,
+                           grad_distances, scratch);
+        hipLaunchKernelGGL(pairs_backward_accumulate<T>, dim3(div_up(num_slots, 256)), dim3(256), 0, stream, num_slots, neighbors, deltas,
+                           distances, grad_deltas, grad_distances, scratch);
+    }
+    hipLaunchKernelGGL(pairs_backward_finish<T>, dim3(div_up(3 * N, 256)), dim3(256), 0, stream, 3 * N, scratch, grad_positions);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
@@ -530,19 +626,37 @@ int nnpops_neighbor_pairs_forward(int dtype, int num_atoms, const void* position
                                 (double*)deltas, (double*)distances, num_pairs, workspace, s);
 }
 
-int nnpops_neighbor_pairs_backward(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors, const void* deltas,
-                                   const void* distances, const void* grad_deltas, const void* grad_distances,
-                                   void* grad_positions, void* stream) {
+int64_t nnpops_neighbor_pairs_backward_workspace_bytes(int num_atoms) {
+    return num_atoms < 0 ? 0 : (int64_t)sizeof(unsigned long long) * (2 + 3 * (int64_t)num_atoms);
+}
+
+int nnpops_neighbor_pairs_backward_ws(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors, const void* deltas,
+                                      const void* distances, const void* grad_deltas, const void* grad_distances,
+                                      void* grad_positions, void* workspace, void* stream) {
     NNPOPS_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (float32) or 1 (float64)");
     NNPOPS_REQUIRE(num_atoms > 0 && num_slots >= 0, "bad sizes");
-    NNPOPS_REQUIRE(grad_positions != nullptr, "NULL device pointer");
+    NNPOPS_REQUIRE(grad_positions != nullptr && workspace != nullptr, "NULL device pointer");
+    NNPOPS_REQUIRE(((uintptr_t)workspace & 7) == 0, "the workspace must be 8-byte aligned");
     NNPOPS_REQUIRE(num_slots == 0 || (neighbors && deltas && distances && grad_deltas && grad_distances), "NULL device pointer");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == 0)
         return backward_impl<float>(num_atoms, num_slots, neighbors, (const float*)deltas, (const float*)distances,
-                                    (const float*)grad_deltas, (const float*)grad_distances, (float*)grad_positions, s);
+                                    (const float*)grad_deltas, (const float*)grad_distances, (float*)grad_positions, workspace, s);
     return backward_impl<double>(num_atoms, num_slots, neighbors, (const double*)deltas, (const double*)distances,
-                                 (const double*)grad_deltas, (const double*)grad_distances, (double*)grad_positions, s);
+                                 (const double*)grad_deltas, (const double*)grad_distances, (double*)grad_positions, workspace, s);
+}
+
+int nnpops_neighbor_pairs_backward(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors, const void* deltas,
+                                   const void* distances, const void* grad_deltas, const void* grad_distances,
+                                   void* grad_positions, void* stream) {
+    // (the entry point of rounds 1-3, kept: takes its scratch from the stream-ordered allocator)
+    NNPOPS_REQUIRE(num_atoms > 0, "bad sizes");
+    void* ws = nullptr;
+    NNPOPS_HIP_TRY(hipMallocAsync(&ws, (size_t)nnpops_neighbor_pairs_backward_workspace_bytes(num_atoms), (hipStream_t)stream));
+    const int rc = nnpops_neighbor_pairs_backward_ws(dtype, num_atoms, num_slots, neighbors, deltas, distances, grad_deltas, grad_distances,
+                                                     grad_positions, ws, stream);
+    (void)hipFreeAsync(ws, (hipStream_t)stream);
+    return rc;
 }
 
 }  // extern "C"

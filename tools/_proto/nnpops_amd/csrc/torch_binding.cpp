@@ -177,6 +177,16 @@ public:
     // Additive: how often forward() pays the host round trip that verifies the neighbour capacities (and grows them).
     // 1 (default) = every call, k = every k-th call, 0 = only the first.  Between checks an overflow goes unnoticed, as
     // inside a captured graph -- for production loops whose densities are known (cf. getNeighborPairs' checkErrors).
+    // Extension: the builders' sticky overflow word as an int32[1] DEVICE tensor (no copy, no synchronisation): non-zero when a
+    // forward since the last capacity check overflowed a neighbour buffer -- what a caller replaying a captured graph, where no
+    // check can run, looks at (nnpops_hip.h: nnpops_ani_overflow_word).  Needs one forward() first.
+    Tensor overflowFlag() {
+        if (!impl) throw std::runtime_error("overflow_flag() called before forward()");
+        const int32_t* word = nullptr;
+        if (nnpops_ani_overflow_word(impl, &word) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::overflow_flag");
+        return torch::from_blob(const_cast<int32_t*>(word), {1}, torch::TensorOptions().device(device).dtype(torch::kInt32));
+    }
+
     void setCheckInterval(int64_t interval) {
         if (interval < 0) throw std::runtime_error("The check interval has to be >= 0");
         checkInterval = interval;
@@ -269,8 +279,11 @@ public:
             if (capturing) break;                     // no host synchronisation inside a graph capture
             // (additive knob, like getNeighborPairs' checkErrors: the capacity check costs a host round trip;
             // interval k checks every k-th call, 0 never again after the first)
-            const bool due = calls == 0 || (checkInterval > 0 && calls % checkInterval == 0);
-            calls++;
+            // (forceCheck: this is the re-issue of a step whose deferred check reported an overflow -- a second overflow, e.g. row
+            //  capacity after the cell bins, must be caught now, whatever the interval; the re-issue is not a counted call)
+            const bool due = forceCheck || calls == 0 || (checkInterval > 0 && calls % checkInterval == 0);
+            if (!forceCheck) calls++;
+            forceCheck = false;
             if (!due && attempt == 0) break;
             if (defer_check && nnpops_ani_check_begin(impl) == 1) { checkPending = true; break; }
             const int rc = nnpops_ani_check(impl, nullptr, nullptr);
@@ -331,6 +344,7 @@ public:
         const int rc = nnpops_ani_check_end(impl);
         if (rc == NNPOPS_OK) return false;
         if (rc != NNPOPS_ERR_CAPACITY) raise_last("NNPOpsANISymmetryFunctions::forward");
+        forceCheck = true;              // the caller issues the step again: that build is verified whatever the check interval
         return true;
     }
 
@@ -371,6 +385,7 @@ private:
     int64_t numRadial = 0, numAngular = 0;
     nnpops_ani_t impl = nullptr;
     int64_t checkInterval = 1;      // capacity check every k-th forward (0: only the first); see setCheckInterval
+    bool forceCheck = false;        // the next forwardImpl() re-issues a step after a reported overflow: always checked
     int64_t calls = 0;
     bool checkPending = false;
 };
@@ -543,6 +558,7 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
         .def("forward", &Holder::forward)
         .def("backward", &Holder::backward)
         .def("set_check_interval", &Holder::setCheckInterval)
+        .def("overflow_flag", &Holder::overflowFlag)
         .def("set_molecules", &Holder::setMolecules)
         .def_pickle([](const HolderPtr& self) -> std::string { return Holder::serialize(self); },
                     [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
@@ -866,9 +882,11 @@ public:
         Tensor grad_positions = torch::empty({num_atoms, 3}, deltas.options());
         const int dtype = deltas.scalar_type() == torch::kFloat64 ? 1 : 0;
         c10::hip::HIPGuard guard(deltas.device().index());
-        if (nnpops_neighbor_pairs_backward(dtype, (int)num_atoms, distances.size(0), neighbors.data_ptr<int32_t>(), deltas.data_ptr(),
-                                           distances.data_ptr(), grad_deltas.data_ptr(), grad_distances.data_ptr(),
-                                           grad_positions.data_ptr(), current_stream(deltas.device())) != NNPOPS_OK)
+        // (scratch for the order-independent fixed-point sums of the backward pass: no float atomics, nnpops_hip.h)
+        Tensor workspace = torch::empty({nnpops_neighbor_pairs_backward_workspace_bytes((int)num_atoms) / 8}, deltas.options().dtype(torch::kInt64));
+        if (nnpops_neighbor_pairs_backward_ws(dtype, (int)num_atoms, distances.size(0), neighbors.data_ptr<int32_t>(), deltas.data_ptr(),
+                                              distances.data_ptr(), grad_deltas.data_ptr(), grad_distances.data_ptr(),
+                                              grad_positions.data_ptr(), workspace.data_ptr(), current_stream(deltas.device())) != NNPOPS_OK)
             raise_last("neighbors::getNeighborPairs backward");
         return {grad_positions, Tensor(), Tensor(), Tensor(), Tensor()};
     }

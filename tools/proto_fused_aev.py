@@ -41,6 +41,7 @@ def build_variant(workdir):
     import shutil
     from nnpops_amd import build as hb
     src_dir = os.path.join(workdir, "nnpops_amd", "csrc")      # (host_common.h includes ../../include/nnpops_hip.h)
+    shutil.rmtree(os.path.join(workdir, "nnpops_amd"), ignore_errors=True)
     shutil.copytree(hb.CSRC, src_dir, ignore=shutil.ignore_patterns("_obj"))
     os.makedirs(os.path.join(workdir, "include"), exist_ok=True)
     shutil.copy(os.path.join(ROOT, "include", "nnpops_hip.h"), os.path.join(workdir, "include", "nnpops_hip.h"))
