@@ -460,7 +460,7 @@ def run_aev(args, R):
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "valu": dom["valu"],
                      "longest_kernel": roof(longest),
                      "limiter": "not HBM: the per-atom kernels are bound by vector-instruction issue while the chip is full and by "
-                                "latency in the last occupancy round (DESIGN.md s3/s6: 390-1160 VALU instructions per atom per "
+                                "latency in the last occupancy round (DESIGN.md s3/s7: 390-1160 VALU instructions per atom per "
                                 "kernel, 1.2-2.8 rounds of resident waves at 10 000 atoms)",
                      "angular": {"forward": roof("angular_forward"), "backward": roof("angular_backward")},
                      "per_kernel": {k: roof(k) for k in ROOFLINE_KERNELS},
@@ -782,7 +782,7 @@ def run_torchani(args, R):
             call_ms = 1e3 * (time.perf_counter() - t1) / steps
             assert bool(torch.isfinite(e_call).all()) and bool(torch.isfinite(f_call).all())
         # ... and what the step costs when the networks multiply ALL 1008 AEV columns, the identically-zero blocks of absent species
-        # included, as the reference's dense BatchedLinear does (OptimizedTorchANI(live_columns=False); DESIGN.md s3.8c)
+        # included, as the reference's dense BatchedLinear does (OptimizedTorchANI(live_columns=False); DESIGN.md s3.9)
         nets_live = opt.neural_networks[0]
         if one_node and graph_ms is not None and hasattr(nets_live, "x_blocks") and nets_live.x_blocks.numel():
             live_opt = opt
@@ -803,7 +803,7 @@ def run_torchani(args, R):
     nn_weight_bytes = sum(b.numel() * 4 for name, b in opt.neural_networks.named_buffers() if "layer" in name)
     tflops_dense = 2 * flops_fwd / elapsed * steps / 1e12    # the reference's formulation: every one of the 1008 columns multiplied
     # what is actually multiplied: inside the one-node step the networks run over the AEV column blocks this molecule's species
-    # can fill (water: H and O of the 7 species -> 128 of the 1008 columns; the others are identically zero), DESIGN.md s3.8c
+    # can fill (water: H and O of the 7 species -> 128 of the 1008 columns; the others are identically zero), DESIGN.md s3.9
     nets0 = opt.neural_networks[0]
     live_cols = 16 * int(nets0.x_blocks.numel()) if one_node and hasattr(nets0, "x_blocks") and nets0.x_blocks.numel() else 1008
     macs_live = {s: live_cols * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}

@@ -369,7 +369,10 @@ static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const 
 // (T threads per block.  Every block scans the whole histogram -- 23 cells per thread at 256 threads for the 5 832-cell grid of
 //  the 10 000-atom frame -- but blocks of 1 024 threads, whose scan is four times shorter, measured SLOWER: the two grid kernels
 //  together 8.9 -> 10.9 us (round 4, interleaved A/B): with 10 blocks instead of 40 the ranking loads of the atoms, the other half
-//  of the kernel, run on 10 CUs.)
+//  of the kernel, run on 10 CUs.  Also built and measured in round 4: a second histogram of the ROWS of cells counted by bin_atoms,
+//  so that this kernel scans 324 row totals instead of 5 832 cells and adds up the few cell counts in front of an atom's cell:
+//  8.6 -> 11.3 us at 10 000 atoms and 12.7 -> 33.5 us at 40 000 -- the extra atomic of every atom lands on a few hundred hot
+//  words, and same-address atomics serialise in the L2.)
 template <int T>
 static __global__ __launch_bounds__(T) void order_binned(int N, const float* __restrict__ pos,
                                                                       const int* __restrict__ tag, CellGrid* __restrict__ grid,

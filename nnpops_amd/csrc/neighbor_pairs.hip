@@ -346,6 +346,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_rows(int N, const int* __rest
     if (tid == 0) { block_prefix[nb] = carry; num_pairs[0] = carry; }
 }
 
+// (a launch of our own instead of hipMemsetAsync: the runtime's fill path costs the host ~20 us per call on this stack, a kernel ~3)
+__global__ __launch_bounds__(256) void zero_words(long long n, int* __restrict__ p) {
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) p[k] = 0;
+}
+
 template <typename T>
 __global__ void to_float_positions(int n3, const T* __restrict__ in, float* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -554,7 +559,7 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
         // histogram cannot be left clean by the previous call as the handles do).  A cell with more than kPairsBinCap atoms
         // (nine times liquid density at the usual cell size) clears grid.ok: every row then scans all columns -- correct, slow.
         if (periodic && N <= kPairsBinnedAtoms) {
-            NNPOPS_HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(int) * kHistWords, stream));
+            hipLaunchKernelGGL(zero_words, dim3(div_up(kHistWords, 256)), dim3(256), 0, stream, (long long)kHistWords, w.hist);
             cb.hist = w.hist; cb.bins = w.bins; cb.bin_cap = kPairsBinCap;
         }
         launch_cell_build(stream, N, fpos, fbox, periodic != 0, (float)cutoff, nullptr, cb);
@@ -584,7 +589,10 @@ template <typename T>
 int backward_impl(int N, long long num_slots, const int32_t* neighbors, const T* deltas, const T* distances,
                   const T* grad_deltas, const T* grad_distances, T* grad_positions, void* workspace, hipStream_t stream) {
     unsigned long long* scratch = (unsigned long long*)workspace;
-    NNPOPS_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(unsigned long long) * (2 + 3 * (size_t)N), stream));
+    {
+        const long long words = 2 * (2 + 3 * (long long)N);
+        hipLaunchKernelGGL(zero_words, dim3((unsigned)std::min<long long>(div_up(words, 256), 4096)), dim3(256), 0, stream, words, (int*)scratch);
+    }
     if (num_slots > 0) {
         const int nb_max = (int)std::min<long long>(div_up(num_slots, 256), 2048);
         hipLaunchKernelGGL(pairs_backward_max<T>, dim3(nb_max), dim3(256), 0, stream, num_slots, neighbors, deltas, distances, grad_deltas,
