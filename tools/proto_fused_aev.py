@@ -64,6 +64,10 @@ def build_variant(workdir):
         assert p.wait() == 0
     lib = os.path.join(workdir, "libnnpops_hip.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    for o in objs:
+        os.remove(o)
+    shutil.rmtree(os.path.join(workdir, "nnpops_amd"), ignore_errors=True)       # (the patched copy of the sources is not kept)
+    shutil.rmtree(os.path.join(workdir, "include"), ignore_errors=True)
     return lib
 
 
