@@ -285,6 +285,19 @@ class Ranks:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def describe(self):
+        """What the process group really is (N > 1): ranks as torch.distributed counts them, backend, RCCL version -- so that a reader
+        of the line can confirm that N ranks over RCCL produced it."""
+        if not self.dist:
+            return None
+        import torch
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                     # noqa: BLE001
+            ver = None
+        return {"world_size": int(self.dist.get_world_size()), "backend": str(self.dist.get_backend()),
+                "rccl_version": ver, "devices_visible": int(torch.cuda.device_count())}
+
     def close(self):
         if self.dist:
             self.dist.barrier()
@@ -448,6 +461,7 @@ def run_aev(args, R):
                                "7 species uniform, Rcr 5.1 / Rca 3.5, 16 radial + 32 angular functions (AEV width 1008); "
                                "one independent frame per GPU" + (", forces of all frames all_gathered every step (RCCL)" if dist else ""),
                    "atoms": n, "frames_per_gpu": 1, "max_neighbors_rcr": max_row, "max_neighbors_rca": max_ang},
+        "process_group": R.describe(),
         "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
         "kernels_us_sum": round(1e6 * sum(kern.values()), 2),
         "event_pair_overhead_us": round(1e6 * event_overhead, 2),
