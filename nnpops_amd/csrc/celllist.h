@@ -520,6 +520,9 @@ __device__ __forceinline__ int wide_stencil_slot(const WideStencil& S, int base,
 // order_binned rank by id), so the partners of `row` in a cell are a PREFIX of that cell's run: 27 lanes
 // binary-search their cell for the first id >= row, and the flat candidate space is the concatenation of
 // the 27 prefixes -- half the candidates of the full stencil, none of them rejected for their id.
+// (Round 4: counting the ids below `row` with independent loads of the whole cell instead of the four or five dependent loads of
+//  the search was built and measured -- pairs_cells_stage 82 -> 142 us at 100 000 atoms: the kernel is bound by the number of
+//  loads it issues, not by the length of that chain.)
 constexpr int kStencilCells = 27;
 struct PrefixStencil {
     int pre[kStencilCells];       // first flat index of cell r            (wave-uniform: SGPRs)
