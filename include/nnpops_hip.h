@@ -236,7 +236,10 @@ int nnpops_neighbor_pairs_backward_ws(int dtype, int num_atoms, int64_t num_slot
  * (pme.py:66-73,93); may be NULL when max_exclusions == 0.  alpha: Ewald splitting parameter; coulomb: 1/(4 pi eps0) in the
  * caller's units.  energy: device float[1]; position_deriv: device [num_atoms][3] = dE/dpositions; charge_deriv: device
  * [num_atoms] = dE/dcharges; all three fully overwritten.  workspace: device scratch of at least
- * nnpops_pme_direct_workspace_bytes(...) bytes.  Graph-capturable. */
+ * nnpops_pme_direct_workspace_bytes(...) bytes -- about num_atoms x min(4 x num_pairs / num_atoms + 32, 2048) x 16 bytes (a row of
+ * incoming contributions per atom; num_pairs is the capacity of the list, so a heavily padded list costs workspace up to that
+ * clamp: 32 KiB per atom).  The table of exclusions must be SYMMETRIC: every atom takes the terms of its excluded pairs from its own
+ * row (the Python wrapper checks it once).  Graph-capturable. */
 int64_t nnpops_pme_direct_workspace_bytes(int64_t num_pairs, int num_atoms, int max_exclusions);
 int nnpops_pme_direct(int num_atoms, int64_t num_pairs, int max_exclusions, const float* positions, const float* charges,
                       const int32_t* neighbors, const float* deltas, const float* distances, const int32_t* exclusions,

@@ -233,9 +233,12 @@ int gather_blocks(int num_atoms) { return (int)std::min<long long>(std::max<long
 
 // entries an atom's incoming row holds: a half list gives the atom with the lowest index ALL its neighbours (twice the
 // average), dense spots more; plus one entry per run of the atom's own pairs
+// (num_pairs is the CAPACITY of the caller's list, padding included: a generously padded list, or max_num_pairs = -1 with its
+//  N (N - 1) / 2 slots, must not size the rows -- 2 048 entries are more than an atom has partners inside any cutoff PME is run with
+//  (12 A at liquid density: 720), and an atom that does receive more falls back to the spill array: 32 KB per atom at most)
 int incoming_capacity(long long num_pairs, int num_atoms) {
     const long long avg = (num_pairs + num_atoms - 1) / std::max(num_atoms, 1);
-    return (int)std::min<long long>(4 * avg + 32, 1 << 16);
+    return (int)std::min<long long>(4 * avg + 32, 2048);
 }
 
 struct PmeWorkspace {

@@ -29,6 +29,21 @@ class PME:
             raise ValueError('exclusions must be 2D')
         self.gridx, self.gridy, self.gridz, self.order = gridx, gridy, gridz, order
         self.alpha, self.coulomb = alpha, coulomb
+        # The table must be symmetric -- j in row i exactly when i is in row j (the reference documents it, pme.py:66-73, and its
+        # kernel visits an excluded pair from the row of the higher index only).  The owner-computes HIP kernel has every atom take
+        # the terms of its excluded pairs from ITS OWN row (nnpops_hip.h: nnpops_pme_direct): a one-sided table would give
+        # derivatives that differ between the device and the host path without any error.  Checked here, once.
+        ex = exclusions.to(torch.int64).cpu()
+        n, width = ex.shape
+        if width > 0 and n > 0:
+            if bool(((ex >= n) | (ex < -1)).any()):
+                raise ValueError('exclusions must hold atom indices or -1')
+            rows = torch.arange(n).unsqueeze(1).expand(n, width)
+            valid = ex >= 0
+            pairs = torch.stack([rows[valid], ex[valid]], dim=1)
+            keys = set((pairs[:, 0] * n + pairs[:, 1]).tolist())
+            if any((j * n + i) not in keys for i, j in pairs.tolist()):
+                raise ValueError('exclusions must be symmetric: if atom j is excluded from atom i, atom i must be excluded from atom j')
         # rows sorted in descending order: the kernels stop scanning a row at the first entry below the partner (pme.py:93)
         self.exclusions, _ = torch.sort(exclusions.to(torch.int32), descending=True)
 

@@ -85,3 +85,17 @@ def test_ops_run_below_autograd_and_validate_their_arguments(golden_dir):
     torch.autograd.grad(e, p2, retain_graph=True)
     with pytest.raises(RuntimeError, match="second derivatives are not implemented"):
         torch.autograd.grad(e, p2, create_graph=True)
+
+
+def test_one_sided_exclusion_table_is_refused():
+    """The HIP kernel is owner-computes: every atom reads the terms of its excluded pairs from its own row, so the table must be
+    symmetric (the reference documents the same requirement, pme.py:66-73).  The wrapper checks it once at construction."""
+    import pytest
+    import torch
+    from NNPOps.pme import PME
+    sym = torch.tensor([[1, -1], [0, 2], [1, -1]])
+    PME(8, 8, 8, 5, 0.3, 138.9, sym)                                   # 0-1, 1-2 listed from both ends
+    with pytest.raises(ValueError, match="symmetric"):
+        PME(8, 8, 8, 5, 0.3, 138.9, torch.tensor([[1, -1], [-1, -1], [-1, -1]]))      # 1 in row 0, 0 not in row 1
+    with pytest.raises(ValueError, match="atom indices"):
+        PME(8, 8, 8, 5, 0.3, 138.9, torch.tensor([[7, -1], [-1, -1], [-1, -1]]))
