@@ -562,3 +562,52 @@ def test_reference_test_molecules(golden_dir, name, surface):
     # the reference's own bar (TestSymmetryFunctions.py:66-70,102-105): relative error of every gradient component
     big = np.abs(g_ref) > 1e-3 * fmax
     assert np.max(np.abs((gr - g_ref)[big] / g_ref[big])) < 5e-3
+
+
+def test_backward_classes_regroup_when_an_atom_outgrows_its_class(monkeypatch):
+    """The angular backward runs one launch per class of atoms (pair matrix of 32 / 48 / all record slots, nnpops_ani_check).  A later
+    frame in which an atom of the 32-slot class has more angular neighbours than its class allows is flagged by the neighbour
+    build (overflow bit 3), reported by check() as NNPOPS_ERR_CAPACITY and evaluated again with new classes: forces of BOTH
+    frames must be the oracle's, with the classes on and off."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    dev = torch.device("cuda:0")
+    # many loose molecules (at most ~28 angular neighbours) and ONE compact one that makes the records 64 slots wide
+    mols, species = [], []
+    for m in range(40):
+        p, s = workloads.conformer(60, seed=100 + m)
+        mols.append(1.35 * p if m else p)                             # molecule 0 stays compact
+        species.append(s)
+    offsets = np.concatenate([[0], np.cumsum([len(p) for p in mols])]).astype(np.int32)
+    species = np.concatenate(species)
+    frame_a = np.concatenate(mols).astype(np.float32)
+    frame_b = frame_a.copy()
+    lo, hi = offsets[7], offsets[8]
+    frame_b[lo:hi] = (mols[7] / 1.35).astype(np.float32)              # molecule 7 shrinks: its atoms leave the 32-slot class
+    results = {}
+    for classes in ("1", "0"):
+        monkeypatch.setenv("NNPOPS_ANI_BWD_CLASSES", classes)
+        monkeypatch.setenv("NNPOPS_ANI_BWD_CLASS_MIN", "0")
+        sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=False)
+        sym.set_molecules(offsets)
+        out = []
+        for frame in (frame_a, frame_b, frame_a):
+            tp = torch.tensor(frame, device=dev)
+            radial, angular = sym.compute(tp, None)
+            gen = torch.Generator(device=dev).manual_seed(3)
+            g_r = torch.randn(radial.shape, device=dev, generator=gen)
+            g_a = torch.randn(angular.shape, device=dev, generator=gen)
+            out.append((frame, g_r.cpu().numpy(), g_a.cpu().numpy(), sym.backprop(g_r, g_a).cpu().numpy()))
+        results[classes] = out
+    assert sym.neighbor_stats()[1] > 32                               # (the records really are wider than the 32-slot class)
+    for classes, out in results.items():
+        for frame, wr, wa, grad in out:
+            ref = np.zeros_like(grad)
+            for m in range(len(offsets) - 1):                         # per-molecule oracle: molecules never interact
+                a, b = offsets[m], offsets[m + 1]
+                o = AniOracle(7, 5.1, 3.5, species[a:b], rf, af, periodic=False)
+                o.forward(frame[a:b], None)
+                ref[a:b] = o.backward(wr[a:b], wa[a:b])
+            assert np.abs(grad - ref).max() <= 1e-4 * np.abs(ref).max(), classes
+    for (_, _, _, g1), (_, _, _, g0) in zip(results["1"], results["0"]):
+        assert np.array_equal(g1, g0)                                 # same kernel arithmetic per atom, whatever the launch it ran in
