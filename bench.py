@@ -373,6 +373,17 @@ def run_aev(args, R):
     for _ in range(args.warmup):
         step()
     breakdown = sym.get_timing() if args.warmup else {}
+    # ... and once more with every bracketed kernel launched TWICE inside its bracket (they are idempotent): the difference between
+    # the double and the single bracket is the kernel alone, whatever the events cost on the stream.  The fitted uniform correction
+    # of the first round-4 version was within 1.4 % of rocprofv3 on one box and 7 % off on the next: what an event pair adds is
+    # neither constant from box to box nor the same for every kernel.
+    doubled = {}
+    if args.warmup and not dist:
+        sym.set_timing_repeat(2)
+        for _ in range(args.warmup):
+            step()
+        doubled = sym.get_timing()
+        sym.set_timing_repeat(1)
     sym.enable_timing(False)
     if not args.warmup:
         step()
@@ -414,20 +425,39 @@ def run_aev(args, R):
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
-    # Kernel durations from event brackets.  An event pair around a kernel reports the kernel PLUS part of the events' own stream time;
-    # subtracting what an EMPTY pair reports (`event_overhead`, ~3.6 us) removes too much -- the kernels of a step run back to back
-    # (the rocprofv3 timeline of this loop has no idle time, profiles/r03d_timeline.txt), so their durations must add up to the step,
-    # and with the full subtraction they came 15 % short (0.248 in the line where rocprofv3 said 0.218).  The
-    # correction is therefore FITTED: the same amount `bracket_correction` is taken off every bracket, chosen so that the brackets
-    # of one step add up to the un-bracketed step time, and never more than the empty pair costs.  The per-kernel figures then are
-    # what rocprofv3's kernel-trace averages are (dispatch to end), which is what profiles/r04*_kernel_stats.txt holds.
+    # Kernel durations from event brackets.  A bracket reports the kernel PLUS what the two events cost on the stream, and that
+    # cost is not a constant (see the warm-up above).  So every per-atom kernel is calibrated by itself: single bracket b1, double
+    # bracket b2 (two launches inside) -> kernel = b2 - b1, overhead of its bracket = b1 - kernel.  The dominant kernel is bracketed
+    # again inside the timed region (every 8th step) and that overhead is taken off.  The two cell-grid kernels (not idempotent as a
+    # pair: one bracket, one launch each) get what is left of the step -- the kernels run back to back, the rocprofv3 timeline of
+    # this loop has no idle time.  Without the double brackets (N > 1 ranks, --warmup 0): the fitted uniform correction.
     raw = {k: v for k, v in kern_all.items() if v > 0}        # s per bracket, warm-up pass (every kernel bracketed)
     ms_dom, c_dom = timing[dominant]
     raw_dom_timed = 1e-3 * ms_dom / max(c_dom, 1)             # ... the dominant one again, from the timed region (every 8th step)
     step_s = elapsed / args.steps
-    correction = min(max((sum(raw.values()) - step_s) / max(len(raw), 1), 0.0), event_overhead) if raw else 0.0
-    kern = {k: (max(v - correction, 1e-9) if v > 0 else 0.0) for k, v in kern_all.items()}
-    kern[dominant] = max(raw_dom_timed - correction, 1e-9)
+    dbl = {k: (1e-3 * ms / max(c, 1)) for k, (ms, c) in doubled.items() if c > 0 and ms > 0}
+    calibrated = bool(dbl) and all(k in dbl and k in raw for k in ROOFLINE_KERNELS)
+    overhead = {}
+    if calibrated:
+        kern = {k: 0.0 for k in kern_all}
+        # (double minus single bracket is the kernel alone only where the second launch runs like the first: true of the two
+        #  angular kernels -- a second and third launch in a row take the same time, their inputs are private to the atom -- not of
+        #  the neighbour build and the radial backward, whose second launch finds the rows it gathers in the L2 and comes out
+        #  1-1.5 us short of rocprofv3.  Those two take the mean overhead of the angular brackets off their single bracket.)
+        for k in ("angular_forward", "angular_backward"):
+            kern[k] = max(dbl[k] - raw[k], 1e-9)
+            overhead[k] = raw[k] - kern[k]
+        mean_overhead = max(0.5 * (overhead["angular_forward"] + overhead["angular_backward"]), 0.0)
+        for k in ("neighbors", "radial_backward"):
+            overhead[k] = mean_overhead
+            kern[k] = max(raw[k] - mean_overhead, 1e-9)
+        kern[dominant] = max(raw_dom_timed - overhead[dominant], 1e-9)
+        kern["cell_grid"] = max(step_s - sum(kern[k] for k in ROOFLINE_KERNELS), 0.0)
+        correction = overhead[dominant]
+    else:
+        correction = min(max((sum(raw.values()) - step_s) / max(len(raw), 1), 0.0), event_overhead) if raw else 0.0
+        kern = {k: (max(v - correction, 1e-9) if v > 0 else 0.0) for k, v in kern_all.items()}
+        kern[dominant] = max(raw_dom_timed - correction, 1e-9)
     step_bytes = n * (16 + 2 * (na_w + nr_w) * 4 + 12)        # N * (16 + 2 * 4032 + 12)
     # HBM traffic and instruction counts of these kernels, measured now (rocprofv3 on three steps of this same workload; the
     # counters come from their own passes, the TIMES above from the un-profiled run)
@@ -466,9 +496,14 @@ def run_aev(args, R):
         "kernels_us_sum": round(1e6 * sum(kern.values()), 2),
         "event_pair_overhead_us": round(1e6 * event_overhead, 2),
         "bracket_correction_us": round(1e6 * correction, 2),
-        "kernels_us_note": "event brackets minus `bracket_correction_us`, the one amount that makes the brackets of a step add up to "
-                           "ms_per_step (the kernels run back to back; never more than an empty event pair costs): comparable with "
-                           "rocprofv3 --kernel-trace averages",
+        "bracket_overhead_us": {k: round(1e6 * v, 2) for k, v in overhead.items()} or None,
+        "kernels_us_note": ("angular kernels = double bracket (two launches inside) minus single bracket; the dominant kernel = its bracket in "
+                            "the timed region minus the overhead so calibrated (`bracket_correction_us`); neighbour build and radial backward "
+                            "= single bracket minus the mean overhead of the angular brackets (their second launch runs warm); cell_grid = "
+                            "what is left of the step (the kernels run back to back): comparable with rocprofv3 --kernel-trace averages"
+                            if calibrated else
+                            "event brackets minus `bracket_correction_us`, the one amount that makes the brackets of a step add up to "
+                            "ms_per_step (no double brackets in this run)"),
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "valu": dom["valu"],

@@ -116,6 +116,8 @@ struct nnpops_ani {
     int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     int timing_every = 1;           // ... on every timing_every-th launch
+    int timing_repeat = 1;          // launches of the kernel INSIDE a bracket (nnpops_ani_set_timing_repeat): 2 lets a caller take the
+                                    // difference of a double and a single bracket -- the kernel alone, whatever the events cost
     unsigned timing_seen[NNPOPS_ANI_NUM_KERNELS] = {};
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
     size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {};
@@ -380,8 +382,13 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, cons
 
 int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out, const Span& sp) {
     KernelTimer timer(h, forward ? NNPOPS_ANI_K_ANGULAR_FWD : NNPOPS_ANI_K_ANGULAR_BWD, sp.stream);
-    if (h->generic) return h->hp.torchani ? launch_generic<true>(h, forward, g, out, sp) : launch_generic<false>(h, forward, g, out, sp);
-    return h->hp.torchani ? dispatch_factors<true>(h, forward, g, out, sp) : dispatch_factors<false>(h, forward, g, out, sp);
+    const int reps = timer.active ? h->timing_repeat : 1;      // (every kernel of this path is idempotent: same inputs, same outputs)
+    int rc = NNPOPS_OK;
+    for (int rep = 0; rep < reps && rc == NNPOPS_OK; rep++) {
+        if (h->generic) rc = h->hp.torchani ? launch_generic<true>(h, forward, g, out, sp) : launch_generic<false>(h, forward, g, out, sp);
+        else rc = h->hp.torchani ? dispatch_factors<true>(h, forward, g, out, sp) : dispatch_factors<false>(h, forward, g, out, sp);
+    }
+    return rc;
 }
 
 // The fused neighbour build + angular forward (ani_build_forward.h): the ANI-1x / ANI-2x factor shape, two waves per atom.
@@ -790,6 +797,7 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
         }
         {
         KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
+        for (int rep = 0, reps = timer.active ? h->timing_repeat : 1; rep < reps; rep++) {
         if (use_cells) {
             if (per)
                 hipLaunchKernelGGL(ani_neighbors_cells<true>, sgrid, ablock, lds_b, sp.stream, h->d_params, box, h->d_grid,
@@ -809,6 +817,7 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
             hipLaunchKernelGGL(ani_neighbors_allpairs<false>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
                                h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
                                h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
+        }
         }
         NNPOPS_HIP_TRY(hipGetLastError());
         // (the radial AEV is written by the builder wave itself: radial_forward_from_lds)
@@ -862,6 +871,7 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     for (int q = 0; q < nspans; q++) {
         const Span& sp = spans[q];
         KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD, sp.stream);
+        for (int rep = 0, reps = timer.active ? h->timing_repeat : 1; rep < reps; rep++) {
         const int nr4 = h->hp.nR / 4;
         const bool lanes = h->rbwd_lanes && h->hp.nR % 4 == 0 && nr4 >= 1 && nr4 <= 8 && h->ld_radial % 4 == 0 &&
                            (h->cap_angular == 32 || h->cap_angular == 64) && (reinterpret_cast<uintptr_t>(radial_deriv) & 15) == 0;
@@ -888,6 +898,7 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
         hipLaunchKernelGGL(ani_radial_backward, dim3(div_up(sp.nw, wpg_r)), ablock, lds_r, sp.stream, h->d_params, h->d_species, h->d_nbr, h->cap,
                            h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
                            sp.order, position_deriv, lds_rw, sp.w0, sp.nw);
+        }
     }
     rc = join_streams(h, spans, nspans);
     if (rc != NNPOPS_OK) return rc;
@@ -1110,6 +1121,13 @@ int nnpops_ani_set_timing_stride(nnpops_ani_t h, int every) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
     NNPOPS_REQUIRE(every >= 1, "timing stride must be at least 1 (got %d)", every);
     h->timing_every = every;
+    return NNPOPS_OK;
+}
+
+int nnpops_ani_set_timing_repeat(nnpops_ani_t h, int launches) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    NNPOPS_REQUIRE(launches == 1 || launches == 2, "a bracket holds one or two launches of its kernel (got %d)", launches);
+    h->timing_repeat = launches;
     return NNPOPS_OK;
 }
 
