@@ -111,7 +111,9 @@ struct nnpops_ani {
     std::vector<BwdClass> bwd_classes;       // stretches of d_work_order, by decreasing tile (check() builds them with the order)
     bool bwd_by_class = true;                // $NNPOPS_ANI_BWD_CLASSES=0: one launch with the full-size pair matrix
     bool bwd_two_waves = false;              // the atoms average 200 triples or more (check()): two waves per atom in the backward kernel
+    double mean_triples = 0;                 // triples per atom of the frame check() last looked at
     int bwd_class_min = 512;                 // smallest class launched on its own ($NNPOPS_ANI_BWD_CLASS_MIN)
+    int bwd_class_atoms = 16384;             // systems of fewer atoms take one backward launch ($NNPOPS_ANI_BWD_CLASS_ATOMS)
     int cell_atoms = 1800;          // systems of at least this many atoms search their neighbours through the cell grid ($NNPOPS_ANI_CELL_ATOMS)
     int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
@@ -176,6 +178,9 @@ int forward_chunk(const nnpops_ani* h, size_t fixed_lds_bytes, size_t bytes_per_
         const size_t lds = fixed_lds_bytes + (size_t)(ch + 1) * bytes_per_triple;
         if (lds <= 160 * 1024 && h->hp.N <= 256L * (long)(160 * 1024 / lds)) return ch;
     }
+    // dense systems (compact molecules: 400+ triples per atom): 256 triples per chunk are two passes where 192 are three -- a
+    // 7 600-atom block of the conformer batch 40.1 -> 36.5 us, the whole batch equal
+    if (h->mean_triples >= 256.0 && h->fwd_chunk < 256 && fixed_lds_bytes + 257 * bytes_per_triple <= 160 * 1024) return 256;
     return h->fwd_chunk;
 }
 
@@ -623,6 +628,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     hp.class_tile = h->d_class_tile;
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASSES")) h->bwd_by_class = std::atoi(e) != 0;
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_MIN")) h->bwd_class_min = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_ATOMS")) h->bwd_class_atoms = std::max(0, std::atoi(e));
     if ((rc = dev_alloc(&h->d_unsorted_atom, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_bucket_offsets, (size_t)num_atoms * (hp.NB + 1)))) return cleanup(rc);
@@ -1008,9 +1014,12 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         {
             double triples = 0;
             for (int cnt : counts) triples += 0.5 * cnt * (cnt - 1);
-            h->bwd_two_waves = triples / std::max<size_t>(counts.size(), 1) >= 200.0;
+            h->mean_triples = triples / std::max<size_t>(counts.size(), 1);
+            h->bwd_two_waves = h->mean_triples >= 200.0;
         }
-        if (h->cap_angular > 48 && h->bwd_by_class) {          // (record capacities are 32, 64, 128, ...)
+        // (classes pay when every launch can fill the chip: the 61 199-atom conformer batch 304 -> 246 us; on a 7 600-atom block of
+        //  it three launches are 3 us slower than one)
+        if (h->cap_angular > 48 && h->bwd_by_class && h->hp.N >= h->bwd_class_atoms) {          // (record capacities are 32, 64, 128, ...)
             const int tiles[3] = {h->cap_angular, 48, 32}, above[3] = {44, 28, -1};      // class c: atoms with more than above[c] neighbours
             // (a class of a few hundred atoms is a launch that cannot fill the chip: it takes the next class with it -- at the
             //  larger pair matrix -- until it has bwd_class_min atoms)

@@ -588,6 +588,7 @@ def test_backward_classes_regroup_when_an_atom_outgrows_its_class(monkeypatch):
     for classes in ("1", "0"):
         monkeypatch.setenv("NNPOPS_ANI_BWD_CLASSES", classes)
         monkeypatch.setenv("NNPOPS_ANI_BWD_CLASS_MIN", "0")
+        monkeypatch.setenv("NNPOPS_ANI_BWD_CLASS_ATOMS", "0")          # (by default only systems of 16 384+ atoms are launched by class)
         sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=False)
         sym.set_molecules(offsets)
         out = []
