@@ -369,21 +369,25 @@ def run_aev(args, R):
     # dominant kernel.  An event costs ~4.5 us of stream time (profiles/r02f_timeline.txt: the two gaps of a step sit
     # exactly around the bracketed kernel), so inside the timed region only the dominant kernel -- the one the roofline
     # line is about -- is bracketed, and only on every 8th step.
+    # (the two bracketed passes run at least 300 steps each -- 30 ms: the bracket overhead below is a difference of three means and
+    #  50 steps leave it +-1 us of noise; they are untimed like the W warm-up steps they contain)
+    cal_steps = max(args.warmup, 300) if args.warmup else 0
     sym.enable_timing(True)
-    for _ in range(args.warmup):
+    for _ in range(cal_steps):
         step()
     breakdown = sym.get_timing() if args.warmup else {}
-    # ... and once more with every bracketed kernel launched TWICE inside its bracket (they are idempotent): the difference between
-    # the double and the single bracket is the kernel alone, whatever the events cost on the stream.  The fitted uniform correction
-    # of the first round-4 version was within 1.4 % of rocprofv3 on one box and 7 % off on the next: what an event pair adds is
-    # neither constant from box to box nor the same for every kernel.
-    doubled = {}
+    # ... and once more with ONE bracket around neighbour build + angular forward and ONE around the two backward kernels: the sum of
+    # two single brackets minus the merged one is what a bracket adds to the stream -- measured in place (same launches, same cache
+    # state).  It is neither the same on every box nor what an EMPTY bracket reports (3.5 us): 0.4 ... 1.7 us were seen.  (Two
+    # earlier round-4 attempts -- one fitted amount for all brackets; each kernel launched twice inside its bracket -- agreed with
+    # rocprofv3 within 2 % on one box and missed by 7-11 % on the next.)
+    merged = {}
     if args.warmup and not dist:
-        sym.set_timing_repeat(2)
-        for _ in range(args.warmup):
+        sym.set_timing_merge(True)
+        for _ in range(cal_steps):
             step()
-        doubled = sym.get_timing()
-        sym.set_timing_repeat(1)
+        merged = sym.get_timing()
+        sym.set_timing_merge(False)
     sym.enable_timing(False)
     if not args.warmup:
         step()
@@ -425,32 +429,25 @@ def run_aev(args, R):
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
-    # Kernel durations from event brackets.  A bracket reports the kernel PLUS what the two events cost on the stream, and that
-    # cost is not a constant (see the warm-up above).  So every per-atom kernel is calibrated by itself: single bracket b1, double
-    # bracket b2 (two launches inside) -> kernel = b2 - b1, overhead of its bracket = b1 - kernel.  The dominant kernel is bracketed
-    # again inside the timed region (every 8th step) and that overhead is taken off.  The two cell-grid kernels (not idempotent as a
-    # pair: one bracket, one launch each) get what is left of the step -- the kernels run back to back, the rocprofv3 timeline of
-    # this loop has no idle time.  Without the double brackets (N > 1 ranks, --warmup 0): the fitted uniform correction.
+    # Kernel durations from event brackets.  A bracket reports the kernel PLUS what the two events cost on the stream; that cost is
+    # measured in place (warm-up above): o_fwd = bracket(build) + bracket(forward) - bracket(build + forward), o_bwd likewise for the two
+    # backward kernels, and taken off the single brackets -- the dominant kernel's bracket of the TIMED region included.  The two
+    # cell-grid kernels (one bracket around both) get what is left of the step: the kernels run back to back, the rocprofv3 timeline
+    # of this loop has no idle time.  Without the merged brackets (N > 1 ranks, --warmup 0): one fitted amount for all brackets.
     raw = {k: v for k, v in kern_all.items() if v > 0}        # s per bracket, warm-up pass (every kernel bracketed)
     ms_dom, c_dom = timing[dominant]
     raw_dom_timed = 1e-3 * ms_dom / max(c_dom, 1)             # ... the dominant one again, from the timed region (every 8th step)
     step_s = elapsed / args.steps
-    dbl = {k: (1e-3 * ms / max(c, 1)) for k, (ms, c) in doubled.items() if c > 0 and ms > 0}
-    calibrated = bool(dbl) and all(k in dbl and k in raw for k in ROOFLINE_KERNELS)
+    mrg = {k: (1e-3 * ms / max(c, 1)) for k, (ms, c) in merged.items() if c > 0 and ms > 0}
+    calibrated = all(k in raw for k in ROOFLINE_KERNELS) and "neighbors" in mrg and "angular_backward" in mrg
     overhead = {}
     if calibrated:
+        o_fwd = min(max(raw["neighbors"] + raw["angular_forward"] - mrg["neighbors"], 0.0), event_overhead)
+        o_bwd = min(max(raw["angular_backward"] + raw["radial_backward"] - mrg["angular_backward"], 0.0), event_overhead)
+        overhead = {"neighbors": o_fwd, "angular_forward": o_fwd, "angular_backward": o_bwd, "radial_backward": o_bwd}
         kern = {k: 0.0 for k in kern_all}
-        # (double minus single bracket is the kernel alone only where the second launch runs like the first: true of the two
-        #  angular kernels -- a second and third launch in a row take the same time, their inputs are private to the atom -- not of
-        #  the neighbour build and the radial backward, whose second launch finds the rows it gathers in the L2 and comes out
-        #  1-1.5 us short of rocprofv3.  Those two take the mean overhead of the angular brackets off their single bracket.)
-        for k in ("angular_forward", "angular_backward"):
-            kern[k] = max(dbl[k] - raw[k], 1e-9)
-            overhead[k] = raw[k] - kern[k]
-        mean_overhead = max(0.5 * (overhead["angular_forward"] + overhead["angular_backward"]), 0.0)
-        for k in ("neighbors", "radial_backward"):
-            overhead[k] = mean_overhead
-            kern[k] = max(raw[k] - mean_overhead, 1e-9)
+        for k in ROOFLINE_KERNELS:
+            kern[k] = max(raw[k] - overhead[k], 1e-9)
         kern[dominant] = max(raw_dom_timed - overhead[dominant], 1e-9)
         kern["cell_grid"] = max(step_s - sum(kern[k] for k in ROOFLINE_KERNELS), 0.0)
         correction = overhead[dominant]
@@ -497,10 +494,10 @@ def run_aev(args, R):
         "event_pair_overhead_us": round(1e6 * event_overhead, 2),
         "bracket_correction_us": round(1e6 * correction, 2),
         "bracket_overhead_us": {k: round(1e6 * v, 2) for k, v in overhead.items()} or None,
-        "kernels_us_note": ("angular kernels = double bracket (two launches inside) minus single bracket; the dominant kernel = its bracket in "
-                            "the timed region minus the overhead so calibrated (`bracket_correction_us`); neighbour build and radial backward "
-                            "= single bracket minus the mean overhead of the angular brackets (their second launch runs warm); cell_grid = "
-                            "what is left of the step (the kernels run back to back): comparable with rocprofv3 --kernel-trace averages"
+        "kernels_us_note": ("single event brackets minus what a bracket adds to the stream, measured in place: bracket(build) + bracket(forward) "
+                            "- bracket(build + forward), and the same for the two backward kernels (`bracket_overhead_us`); the dominant kernel "
+                            "from its brackets in the timed region; cell_grid = what is left of the step (the kernels run back to back): "
+                            "comparable with rocprofv3 --kernel-trace averages"
                             if calibrated else
                             "event brackets minus `bracket_correction_us`, the one amount that makes the brackets of a step add up to "
                             "ms_per_step (no double brackets in this run)"),

@@ -150,11 +150,12 @@ int nnpops_ani_get_timing(nnpops_ani_t h, double* total_ms, int* launches);
 /* What an event pair reports for an EMPTY bracket on the handle's stream (median of 21, milliseconds; blocks):
  * subtract it from a per-launch average to compare with a profiler's kernel durations. */
 int nnpops_ani_timing_overhead(nnpops_ani_t h, double* ms);
-/* launches = 2: while timing is enabled every bracketed kernel is launched TWICE inside its bracket (all of them are idempotent;
- * the cell-grid pair is not and keeps one launch).  The difference between a double and a single bracket is the duration of the
- * kernel alone, whatever the events themselves cost on the stream -- how bench.py calibrates its brackets against rocprofv3's
- * kernel durations.  launches = 1 restores the normal behaviour.  Nothing changes when timing is off. */
-int nnpops_ani_set_timing_repeat(nnpops_ani_t h, int launches);
+/* merge != 0: while timing is enabled there is ONE bracket around neighbour build + angular forward (its time is reported under the
+ * neighbour build) and ONE around angular backward + radial backward (reported under the angular backward); the four single
+ * brackets are off, the cell grid's stays.  (single bracket A) + (single bracket B) - (merged bracket A+B) is what ONE bracket adds
+ * to the stream -- measured in place, same launches, same cache state -- which is how bench.py makes its event figures comparable
+ * with rocprofv3's kernel durations.  merge = 0 restores the per-kernel brackets.  Nothing changes when timing is off. */
+int nnpops_ani_set_timing_merge(nnpops_ani_t h, int merge);
 
 /* ------------------------------------------------------------------------------------------
  * SchNet continuous-filter convolution (replaces CFConvNeighbors / CFConv and their Cuda* subclasses)

@@ -45,7 +45,7 @@ SIGNATURES = {
     "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nnpops_ani_timing_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "nnpops_ani_overflow_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
-    "nnpops_ani_set_timing_repeat": (C.c_int, [C.c_void_p, C.c_int]),
+    "nnpops_ani_set_timing_merge": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
     "nnpops_cfconv_neighbors_destroy": (C.c_int, [C.c_void_p]),
     "nnpops_cfconv_neighbors_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -238,9 +238,10 @@ class AniSymmetryFunctions:
         _check(self._lib.nnpops_ani_set_timing_stride(self._h, int(every)))
         _check(self._lib.nnpops_ani_enable_timing(self._h, mask))
 
-    def set_timing_repeat(self, launches):
-        """1 (normal) or 2 launches of every bracketed kernel inside its bracket: double minus single bracket = the kernel alone."""
-        _check(self._lib.nnpops_ani_set_timing_repeat(self._h, int(launches)))
+    def set_timing_merge(self, merge):
+        """True: one bracket around build + angular forward (reported as "neighbors") and one around the two backward kernels (reported as
+        "angular_backward") instead of the four single ones: single + single - merged = what a bracket costs, measured in place."""
+        _check(self._lib.nnpops_ani_set_timing_merge(self._h, int(bool(merge))))
 
     def get_timing(self):
         """-> {kernel: (total_ms, launches)} since the last call; blocks on the stream."""

@@ -118,8 +118,9 @@ struct nnpops_ani {
     int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     int timing_every = 1;           // ... on every timing_every-th launch
-    int timing_repeat = 1;          // launches of the kernel INSIDE a bracket (nnpops_ani_set_timing_repeat): 2 lets a caller take the
-                                    // difference of a double and a single bracket -- the kernel alone, whatever the events cost
+    bool timing_merge = false;      // nnpops_ani_set_timing_merge: ONE bracket around neighbour build + angular forward (reported as the
+                                    // build) and ONE around angular + radial backward (reported as the angular backward); the sum of
+                                    // the two single brackets minus the merged one is what a bracket costs, measured in place
     unsigned timing_seen[NNPOPS_ANI_NUM_KERNELS] = {};
     std::vector<hipEvent_t> ev_start[NNPOPS_ANI_NUM_KERNELS], ev_stop[NNPOPS_ANI_NUM_KERNELS];
     size_t ev_used[NNPOPS_ANI_NUM_KERNELS] = {};
@@ -132,8 +133,9 @@ struct KernelTimer {
     nnpops_ani* h;
     int id;
     hipStream_t stream;
-    KernelTimer(nnpops_ani* h_, int id_, hipStream_t s_ = nullptr) : h(h_), id(id_), stream(s_ ? s_ : h_->stream) {
+    KernelTimer(nnpops_ani* h_, int id_, hipStream_t s_ = nullptr, bool merged = false) : h(h_), id(id_), stream(s_ ? s_ : h_->stream) {
         if (!(h->timing_mask >> id & 1)) return;
+        if (h->timing_merge != merged && id != NNPOPS_ANI_K_CELL_GRID) return;      // (merge mode: only the two merged brackets and the grid's)
         if (h->timing_seen[id]++ % (unsigned)h->timing_every != 0) return;
         active = true;
         if (h->ev_used[id] == h->ev_start[id].size()) {
@@ -387,13 +389,8 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, cons
 
 int dispatch_angular(nnpops_ani* h, bool forward, const float* g, float* out, const Span& sp) {
     KernelTimer timer(h, forward ? NNPOPS_ANI_K_ANGULAR_FWD : NNPOPS_ANI_K_ANGULAR_BWD, sp.stream);
-    const int reps = timer.active ? h->timing_repeat : 1;      // (every kernel of this path is idempotent: same inputs, same outputs)
-    int rc = NNPOPS_OK;
-    for (int rep = 0; rep < reps && rc == NNPOPS_OK; rep++) {
-        if (h->generic) rc = h->hp.torchani ? launch_generic<true>(h, forward, g, out, sp) : launch_generic<false>(h, forward, g, out, sp);
-        else rc = h->hp.torchani ? dispatch_factors<true>(h, forward, g, out, sp) : dispatch_factors<false>(h, forward, g, out, sp);
-    }
-    return rc;
+    if (h->generic) return h->hp.torchani ? launch_generic<true>(h, forward, g, out, sp) : launch_generic<false>(h, forward, g, out, sp);
+    return h->hp.torchani ? dispatch_factors<true>(h, forward, g, out, sp) : dispatch_factors<false>(h, forward, g, out, sp);
 }
 
 // The fused neighbour build + angular forward (ani_build_forward.h): the ANI-1x / ANI-2x factor shape, two waves per atom.
@@ -801,9 +798,9 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
             if (rc != NNPOPS_OK) return rc;
             continue;
         }
+        KernelTimer merged_timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream, /*merged=*/true);      // (spans the angular forward below)
         {
         KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
-        for (int rep = 0, reps = timer.active ? h->timing_repeat : 1; rep < reps; rep++) {
         if (use_cells) {
             if (per)
                 hipLaunchKernelGGL(ani_neighbors_cells<true>, sgrid, ablock, lds_b, sp.stream, h->d_params, box, h->d_grid,
@@ -823,7 +820,6 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
             hipLaunchKernelGGL(ani_neighbors_allpairs<false>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
                                h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
                                h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
-        }
         }
         NNPOPS_HIP_TRY(hipGetLastError());
         // (the radial AEV is written by the builder wave itself: radial_forward_from_lds)
@@ -865,6 +861,7 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     const int nspans = make_spans(h, spans);
     int rc = fork_streams(h, spans, nspans);
     if (rc != NNPOPS_OK) return rc;
+    KernelTimer merged_timer(h, NNPOPS_ANI_K_ANGULAR_BWD, spans[0].stream, /*merged=*/true);      // (spans the radial backward below)
     for (int q = 0; q < nspans; q++) {
         rc = dispatch_angular(h, false, angular_deriv, nullptr, spans[q]);
         if (rc != NNPOPS_OK) return rc;
@@ -877,7 +874,6 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     for (int q = 0; q < nspans; q++) {
         const Span& sp = spans[q];
         KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD, sp.stream);
-        for (int rep = 0, reps = timer.active ? h->timing_repeat : 1; rep < reps; rep++) {
         const int nr4 = h->hp.nR / 4;
         const bool lanes = h->rbwd_lanes && h->hp.nR % 4 == 0 && nr4 >= 1 && nr4 <= 8 && h->ld_radial % 4 == 0 &&
                            (h->cap_angular == 32 || h->cap_angular == 64) && (reinterpret_cast<uintptr_t>(radial_deriv) & 15) == 0;
@@ -904,7 +900,6 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
         hipLaunchKernelGGL(ani_radial_backward, dim3(div_up(sp.nw, wpg_r)), ablock, lds_r, sp.stream, h->d_params, h->d_species, h->d_nbr, h->cap,
                            h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
                            sp.order, position_deriv, lds_rw, sp.w0, sp.nw);
-        }
     }
     rc = join_streams(h, spans, nspans);
     if (rc != NNPOPS_OK) return rc;
@@ -1133,10 +1128,9 @@ int nnpops_ani_set_timing_stride(nnpops_ani_t h, int every) {
     return NNPOPS_OK;
 }
 
-int nnpops_ani_set_timing_repeat(nnpops_ani_t h, int launches) {
+int nnpops_ani_set_timing_merge(nnpops_ani_t h, int merge) {
     NNPOPS_REQUIRE(h != nullptr, "NULL handle");
-    NNPOPS_REQUIRE(launches == 1 || launches == 2, "a bracket holds one or two launches of its kernel (got %d)", launches);
-    h->timing_repeat = launches;
+    h->timing_merge = merge != 0;
     return NNPOPS_OK;
 }
 
