@@ -53,6 +53,7 @@ struct nnpops_ani {
     // streams finish in 0.83x the time of one full-size evaluation on one stream, tools/two_streams.py).
     bool backward_forced = false;   // $NNPOPS_ANI_BACKWARD given: no automatic choice of the two-wave kernel for dense systems
     bool fwd_uniform = false;       // every radial factor shares its eta, every angular factor its zeta (set at create; $NNPOPS_ANI_FWD_UNI=0)
+    bool fwd_grid = true;           // ... and eight radial factors sit on equally spaced shifts (what the UNI forward kernel assumes of eight)
     int fuse_forward = -1;          // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h).  -1: for
                                     // systems of up to kFuseAtoms atoms, where a launch less is worth 6-13 % of a step (600 atoms:
                                     // 33.7 -> 29.6 us, 3 000: 49.5 -> 46.3) -- at 5 000 it breaks even and at 10 000 its lower
@@ -275,7 +276,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (h->fwd_waves_per_atom == 2) {                      // a 128-lane workgroup per atom
             int groups = N;
             if (h->fwd_atoms_per_group > 1) groups = div_up(N, h->fwd_atoms_per_group);
-            const bool uni = h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP;      // one eta, one zeta, no padded factor slots
+            const bool uni = h->fwd_uniform && h->fwd_grid && h->hp.nFR == NFRP && h->hp.nFZ == NFZP;      // one eta, one zeta, no padded factor slots
             // balanced phase 2 (per-atom quad table, ani_angular_mfma.h: DYN): needs the row assembled in LDS and a lane per bucket
             const bool dyn = h->fwd_dynamic && (vec_ok & 8) && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * (NFRP + NFZP);
             auto k = h->fwd_occ == 6 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 6> : h->fwd_occ == 8 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 8>
@@ -413,7 +414,7 @@ int launch_build_forward(nnpops_ani* h, const BuildInputs& in, const BuildOutput
     const int CH = fused_chunk(h);
     const size_t lds = (build_forward_lds_bytes<8, 4>(h->cap, h->cap_angular, h->hp.S, h->hp.NB, CH, &tri_offset) + 15) & ~(size_t)15;
     const int vec_ok = 1 | (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);
-    const bool uni = h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4;
+    const bool uni = h->fwd_uniform && h->fwd_grid && h->hp.nFR == 8 && h->hp.nFZ == 4;
     const bool dyn = h->fwd_dynamic && h->fwd_row_via_lds && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * 12;
     auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6>
            : dyn ? (uni ? ani_build_forward<TA, 8, 4, 7, true, true> : ani_build_forward<TA, 8, 4, 7, false, true>)
@@ -531,6 +532,21 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     h->fwd_uniform = !h->generic;
     for (int a = 1; a < hp.nFR; a++) h->fwd_uniform = h->fwd_uniform && hp.fr_c[a] == hp.fr_c[0];
     for (int z = 1; z < hp.nFZ; z++) h->fwd_uniform = h->fwd_uniform && hp.fz_zeta[z] == hp.fz_zeta[0];
+    h->fwd_grid = true;
+    if (h->fwd_uniform && hp.nFR == 8) {
+        // Eight radial factors of one eta on equally spaced shifts (every ANI-2x-shaped model): the UNI forward kernel gets them
+        // by recurrence (GeoRadial, ani_kernels.h).  A list that is not such a grid takes the kernel that evaluates factor by factor.
+        const double rs0 = hp.fr_rs[0], d = ((double)hp.fr_rs[7] - rs0) / 7.0, c = hp.fr_c[0];
+        for (int a = 1; a < 8; a++) h->fwd_grid = h->fwd_grid && std::fabs((double)hp.fr_rs[a] - (rs0 + a * d)) <= 1e-6 * std::fabs(d);
+        // (the ratios must stay inside the fp32 range over 0 <= x <= Rca: exponents k0 +- k1 (x - Rs_1), then +- 8 c d^2)
+        const double rs1 = rs0 + d;
+        const double reach = 2.0 * std::fabs(c * d) * std::max(std::fabs(rs1), std::fabs((double)hp.rca - rs1)) + 9.0 * std::fabs(c) * d * d;
+        h->fwd_grid = h->fwd_grid && d != 0.0 && reach < 120.0;
+        GeoRadial& g = hp.geo;
+        g.rs1 = (float)(rs0 + d); g.c = (float)c; g.k1 = (float)(-2.0 * c * d); g.k0 = (float)(c * d * d);
+        g.q = (float)std::exp2(2.0 * c * d * d); g.q4 = (float)std::exp2(8.0 * c * d * d); g.qi4 = (float)std::exp2(-8.0 * c * d * d);
+        g.d4 = (float)(4.0 * d);
+    }
     if (const char* e = std::getenv("NNPOPS_ANI_FWD_UNI")) h->fwd_uniform = h->fwd_uniform && std::atoi(e) != 0;
     // Matrix-core forward kernel: quads are handed the species pairs that can occur among this system's atoms.
     {

@@ -36,6 +36,9 @@ __device__ __forceinline__ void triple_forces_pk(const float4& A, const float4& 
     const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
     const v2f rb2 = {g.rbar, g.rbar}, c2 = {g.c, g.c}, s2 = {g.s, g.s}, one = {1.0f, 1.0f};
     float R[NFRP], dR[NFRP];
+    // (The forward kernel's recurrence for eight equally spaced shifts -- radial_factors_geo8, four transcendentals instead of
+    //  eight -- was built here too and measured 15.5 -> 15.7 us: the derivative needs every (rbar - Rs_a) anyway, and the packed
+    //  sub / mul / mul below already handles two factors per instruction.)
 #pragma unroll
     for (int a = 0; a < NFRP; a += 2) {
         const v2f sh = rb2 - v2f{frs[a], frs[a + 1]};

@@ -30,7 +30,6 @@
 namespace nnpops {
 
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kFwdSlots = 32;          // 2 sets x 16 quads
 
@@ -106,6 +105,7 @@ struct MfmaForward {
     int sbk[NS], spart[NS];
     float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];   // constants of the two factor families (wave-uniform)
     float frc0, zz0, zb0;                                                 // UNI: the shared eta / zeta / bias
+    GeoRadial geo;                                                        // UNI with eight radial factors: the recurrence's constants
 
     __device__ __forceinline__ void sync() const {
         if constexpr (WPA == 2) __syncthreads();
@@ -143,6 +143,11 @@ struct MfmaForward {
             zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;             // 1 - zeta: the 2^(1-zeta) of ref :104-109 folded into the exponent
         }
         frc0 = P->fr_c[0]; zz0 = P->fz_zeta[0]; zb0 = P->fz_bias[0];
+        if constexpr (UNI && NFRP == 8) {
+            static_assert(NFRP != 8 || NR4 == 2, "factor order of the 16-byte records");
+            geo.rs1 = P->geo.rs1; geo.c = P->geo.c; geo.k1 = P->geo.k1; geo.k0 = P->geo.k0;
+            geo.q = P->geo.q; geo.q4 = P->geo.q4; geo.qi4 = P->geo.qi4; geo.d4 = P->geo.d4;
+        }
     }
     __device__ __forceinline__ void write_zero_record() const {
         if (role == 0 && lane < REC) fac[CH * REC + lane] = 0.f;
@@ -226,10 +231,17 @@ struct MfmaForward {
                     const float4 A2 = recB[p], B2 = recB[q];
                     const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
                     float vr[NFRP], vz[NFZP];
+                    if constexpr (UNI && NFRP == 8) {          // one eta, equally spaced shifts: four transcendentals for the eight factors
+                        v2f R04, R15, R26, R37, Y;             // the record holds {R0, R4, R1, R5 | R2, R6, R3, R7}: the pairs as they come
+                        radial_factors_geo8(g.rbar, geo, R04, R15, R26, R37, Y);
+                        vr[0] = R04.x; vr[1] = R04.y; vr[2] = R15.x; vr[3] = R15.y;
+                        vr[4] = R26.x; vr[5] = R26.y; vr[6] = R37.x; vr[7] = R37.y;
+                    } else {
 #pragma unroll
-                    for (int a = 0; a < NFRP; a++) {           // stored so that column nn finds its NR4 values together
-                        const float sh = g.rbar - frs[a];
-                        vr[(a & 3) * NR4 + (a >> 2)] = fast_exp2((UNI ? frc0 : frc[a]) * sh * sh);
+                        for (int a = 0; a < NFRP; a++) {       // stored so that column nn finds its NR4 values together
+                            const float sh = g.rbar - frs[a];
+                            vr[(a & 3) * NR4 + (a >> 2)] = fast_exp2((UNI ? frc0 : frc[a]) * sh * sh);
+                        }
                     }
 #pragma unroll
                     for (int z = 0; z < NFZP; z++) {

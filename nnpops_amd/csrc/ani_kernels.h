@@ -49,6 +49,31 @@ constexpr int kMaxSpecies = 16;
 constexpr int kMaxBuckets = kMaxSpecies * (kMaxSpecies + 1) / 2;
 constexpr int kMaxAngularCap = 256;  // p and q of a triple word are 8 bits each
 
+// Eight radial factors of one eta on equally spaced shifts (ANI-2x: ShfA = 0.8 + 0.3375 a): g_a = 2^(c (x - Rs_a)^2) obeys
+//     g_{a+1} / g_a = u_a = 2^(c d^2 - 2 c d y_a),   g_{a-1} / g_a = 2^(c d^2 + 2 c d y_a),   u_{a+1} = u_a 2^(2 c d^2)        (y_a = x - Rs_a)
+// so the eight of them cost FOUR transcendentals (g_1, g_5 and the two ratios at a = 1) and twelve multiplies instead of eight
+// (v_exp_f32 runs at a quarter of the rate of a multiply).  Two starting points keep every chain at two steps: the rounding of the
+// ratios' exponents (|e| < 32: 1e-6 absolute) enters a factor at most three times.  Constants from the host, in double.
+struct GeoRadial {
+    float rs1, c, k1, k0;            // Rs_1;  -eta log2(e);  -2 c d;  c d^2
+    float q, q4, qi4, d4;            // 2^(2 c d^2), its 4th power and the inverse of that; 4 d
+};
+typedef float v2f __attribute__((ext_vector_type(2)));
+// The two chains (from g_1 and from g_5) side by side in the halves of packed registers: R04 = {g_0, g_4}, R15 = {g_1, g_5},
+// R26, R37; Y = {x - Rs_1, x - Rs_5}.
+__device__ __forceinline__ void radial_factors_geo8(float x, const GeoRadial& G, v2f& R04, v2f& R15, v2f& R26, v2f& R37, v2f& Y) {
+    const float y1 = x - G.rs1;
+    Y = v2f{y1, y1 - G.d4};
+    const v2f arg = (v2f{G.c, G.c} * Y) * Y;
+    R15 = v2f{fast_exp2(arg.x), fast_exp2(arg.y)};
+    const float e1 = G.k1 * y1;
+    const float u1 = fast_exp2(G.k0 + e1), d1 = fast_exp2(G.k0 - e1);
+    const v2f U = v2f{u1, u1} * v2f{1.0f, G.q4}, D = v2f{d1, d1} * v2f{1.0f, G.qi4};
+    R04 = R15 * D;
+    R26 = R15 * U;
+    R37 = R26 * (U * v2f{G.q, G.q});
+}
+
 struct AniParams {
     int N, S, nR, nA, NB, nFR, nFZ;
     int periodic, torchani;
@@ -88,6 +113,7 @@ struct AniParams {
     int fwd_nabsent;                 // species pairs that cannot occur in this system (their output blocks are zero)
     int fwd_absent[kMaxBuckets];
     int fwd_zero_shift;              // log2 of the lanes that zero one absent block (16 bytes each), <= 6
+    GeoRadial geo;                   // UNI forward kernel with eight radial factors (valid when the host set nnpops_ani::fwd_grid)
 };
 
 // What the angular BACKWARD kernel needs of the parameter block, passed BY VALUE in the kernel arguments.  Read through the AniParams
@@ -360,6 +386,10 @@ __device__ __forceinline__ void radial_forward_from_lds(const AniParams* __restr
     // order: back-to-back hits on one bin are safe) instead of a compare/select per species in registers.  The next
     // neighbour is read before the bin of this one (LDS float atomics would need no read at all, but they run at a
     // fraction of the rate: 65 us instead of 26 for the kernel).
+    // (Round 4: the scatter as a matrix product on the matrix core -- v_mfma_f32_16x16x4_f32, A = one-hot species of four
+    //  neighbours, B = their terms, out[species][k] in four accumulator registers, no bins -- was built, passes the parity
+    //  tests and measured SLOWER: builder 19.6 -> 21.7 us at 10 000 atoms, interleaved.  14 issues of 32 cycles per atom are
+    //  1.8 us of matrix pipe for the whole frame, which the bins' LDS round trips, hidden behind the other waves, do not cost.)
     const int k = lane & (KP - 1), stream = lane >> kshift, nstreams = 64 >> kshift;
     const float ck = P->rad_c[min(k, nR - 1)], rs = P->rad_rs[min(k, nR - 1)];
     float* bins = (float*)(nb_bin + cap);              // [nstreams][S][KP] = 64 * S floats

@@ -482,7 +482,7 @@ def test_strided_rows_write_one_aev_array(pad):
 
 
 @pytest.mark.parametrize("torchani", [True, False])
-@pytest.mark.parametrize("kind", ["irregular", "too_many_factors", "forced_grid"])
+@pytest.mark.parametrize("kind", ["irregular", "too_many_factors", "forced_grid", "off_grid_shifts", "other_grid"])
 def test_arbitrary_angular_function_lists(monkeypatch, kind, torchani):
     """The reference core evaluates ANY vector of AngularFunction records one by one (CpuANISymmetryFunctions.cpp:153-194).
     Lists that are not a full {(eta,rs)} x {(zeta,thetas)} grid -- here: a grid with holes, a duplicate and shuffled order;
@@ -497,12 +497,28 @@ def test_arbitrary_angular_function_lists(monkeypatch, kind, torchani):
     elif kind == "too_many_factors":
         zs = [(float(z), float(t)) for z in (1.0, 4.0, 14.1) for t in np.linspace(0.3, 2.8, 4)]      # 12 (zeta, thetas) factors
         af = np.array([[12.5, r, z, t] for r in (0.8, 1.9, 3.0) for z, t in zs], dtype=np.float32)    # 36 functions
+    elif kind == "off_grid_shifts":
+        # a full 8 x 4 grid of one eta whose eight shifts are NOT equally spaced: the matrix-core forward kernel must not take its
+        # recurrence for the radial factors (ani_kernels.h: radial_factors_geo8) but evaluate them one by one
+        shifts = (0.8, 1.1, 1.5, 1.8125, 2.2, 2.4875, 2.9, 3.1625)
+        af = np.array([[12.5, r, 14.1, t] for r in shifts for t in (0.3927, 1.1781, 1.9635, 2.7489)], dtype=np.float32)
+    elif kind == "other_grid":
+        # ... and an equally spaced grid with other constants than ANI-2x's (sharper, wider apart, descending): the recurrence's
+        # constants come from the list, not from the model
+        shifts = 3.3 - 0.36 * np.arange(8)
+        af = np.array([[19.0, r, 9.0, t] for r in shifts for t in (0.3927, 1.1781, 1.9635, 2.7489)], dtype=np.float32)
     else:
         monkeypatch.setenv("NNPOPS_ANI_GENERIC", "1")
     pos, species, box = workloads.random_box(420, seed=91)
-    _run_case(7, 5.1, 3.5, species, rf, af, pos, box, torchani=torchani)
+    _, a_default, _ = _run_case(7, 5.1, 3.5, species, rf, af, pos, box, torchani=torchani)
     mol, sp = workloads.conformer(45, seed=92)
     _run_case(7, 5.1, 3.5, sp, rf, af, mol, None, torchani=torchani)
+    if kind in ("off_grid_shifts", "other_grid"):
+        # which forward arithmetic ran: against the factor-by-factor kernel ($NNPOPS_ANI_FWD_UNI=0) the off-grid list must give the
+        # same bits (it IS that kernel), the grid a different rounding of the same numbers (the recurrence)
+        monkeypatch.setenv("NNPOPS_ANI_FWD_UNI", "0")
+        _, a_plain, _ = _run_case(7, 5.1, 3.5, species, rf, af, pos, box, torchani=torchani)
+        assert np.array_equal(a_default, a_plain) == (kind == "off_grid_shifts")
 
 
 # ---------------------------------------------------------------- the reference's own test molecules

@@ -54,6 +54,26 @@ def _worker(rank, world, port, sizes, out_dir):
     dist.destroy_process_group()
 
 
+def test_one_rank_rccl_group_runs_the_gather(tmp_path):
+    """What a one-device box can say about the RCCL path: a one-rank "nccl" group (RCCL initialises, its stream ordering against
+    ours holds) carries nnpops_amd.parallel.gather_rows, and tools/rccl_world1_check.py the asynchronous double-buffered
+    all_gather_into_tensor / all_reduce / barrier sequence of bench.py's N > 1 path."""
+    import json
+    import subprocess
+    import sys
+    import torch.multiprocessing as mp
+    sizes = np.random.default_rng(3).integers(20, 70, size=24).tolist()
+    mp.spawn(_worker, args=(1, _free_port(), sizes, str(tmp_path)), nprocs=1, join=True)
+    assert torch.equal(torch.load(tmp_path / "full_0.pt"), _forces(0, sizes, 0, len(sizes)).cpu())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_world1_check.py")], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["backend"] == "nccl" and line["gather_matches"] and line["rccl_version"]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices")
 def test_two_ranks_gather_exactly_the_single_gpu_forces(tmp_path):
     import torch.multiprocessing as mp
