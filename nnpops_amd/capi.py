@@ -45,6 +45,7 @@ SIGNATURES = {
     "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nnpops_ani_timing_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "nnpops_ani_overflow_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "nnpops_ani_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nnpops_ani_set_timing_merge": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
     "nnpops_cfconv_neighbors_destroy": (C.c_int, [C.c_void_p]),
@@ -237,6 +238,12 @@ class AniSymmetryFunctions:
             mask = sum(1 << (self.KERNELS.index(k) + 1) for k in only)
         _check(self._lib.nnpops_ani_set_timing_stride(self._h, int(every)))
         _check(self._lib.nnpops_ani_enable_timing(self._h, mask))
+
+    def describe(self):
+        """-> {key: value} of nnpops_ani_describe: which kernels this handle runs (forward, backward, uniform, grid, literal, ...)."""
+        buf = C.create_string_buffer(512)
+        _check(self._lib.nnpops_ani_describe(self._h, buf, 512))
+        return dict(word.split("=", 1) for word in buf.value.decode().split())
 
     def set_timing_merge(self, merge):
         """True: one bracket around build + angular forward (reported as "neighbors") and one around the two backward kernels (reported as

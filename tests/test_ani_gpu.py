@@ -519,6 +519,37 @@ def test_arbitrary_angular_function_lists(monkeypatch, kind, torchani):
         monkeypatch.setenv("NNPOPS_ANI_FWD_UNI", "0")
         _, a_plain, _ = _run_case(7, 5.1, 3.5, species, rf, af, pos, box, torchani=torchani)
         assert np.array_equal(a_default, a_plain) == (kind == "off_grid_shifts")
+        monkeypatch.delenv("NNPOPS_ANI_FWD_UNI")
+        from nnpops_amd.capi import AniSymmetryFunctions
+        what = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=torchani).describe()
+        assert what["uniform"] == "1" and what["literal"] == "0" and what["grid"] == ("0" if kind == "off_grid_shifts" else "1")
+
+
+@pytest.mark.parametrize("fuse", ["0", "1"])
+@pytest.mark.parametrize("kind", ["seven_species", "organic"])
+def test_published_ani2x_constants_run_the_literal_kernels(monkeypatch, kind, fuse):
+    """The ANI-2x parameter set selects forward kernels that carry its derived constants as literals (ani_kernels.h: Ani2xAngular;
+    chosen only when every constant nnpops_ani_create derives equals the compiled-in one bit for bit).  Same arithmetic on the same
+    numbers: the AEV must equal what the constants-in-registers kernels give ($NNPOPS_ANI_FWD_LITERAL=0) to the last bit or two,
+    and both pass the oracle; a set that differs in one parameter must not take them."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    monkeypatch.setenv("NNPOPS_ANI_FUSE", fuse)
+    rf, af = workloads.ani2x_functions()
+    if kind == "seven_species":
+        pos, species, box = workloads.random_box(700, seed=5)
+    else:
+        pos, species, box = workloads.random_box(700, seed=6, n_species=7, species_probs=[0.5, 0.3, 0.1, 0.1, 0, 0, 0])
+    assert AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True).describe()["literal"] == "1"
+    _, a_lit, _ = _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
+    monkeypatch.setenv("NNPOPS_ANI_FWD_LITERAL", "0")
+    assert AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True).describe()["literal"] == "0"
+    _, a_reg, _ = _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
+    np.testing.assert_allclose(a_lit, a_reg, rtol=2e-6, atol=1e-9)
+    monkeypatch.delenv("NNPOPS_ANI_FWD_LITERAL")
+    af2 = af.copy()
+    af2[:, 2] = 14.0                                           # another zeta: not the published set
+    assert AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af2, periodic=True).describe()["literal"] == "0"
+    _run_case(7, 5.1, 3.5, species, rf, af2, pos, box)
 
 
 # ---------------------------------------------------------------- the reference's own test molecules

@@ -107,12 +107,6 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
  * a non-zero word found there means that every evaluation since the previous check may have been incomplete.  The address is
  * valid for the life of the handle. */
 int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word);
-/* Which kernels this handle runs, as one line of `key=value` words (for logs and tests; the words may grow): forward= merge |
- * chunked | mfma; backward= kernel number; generic= the function list does not factor; uniform= one eta and one zeta; grid= eight
- * radial factors on equally spaced shifts (taken by recurrence); literal= the constants are the published ANI-2x set and the
- * forward kernels carry them as literals; dynamic_quads, fused_build, cap, cap_angular, chunk, classes, cells: state after the last
- * compute() / check().  Writes at most `capacity` bytes including the terminator.  Additive. */
-int nnpops_ani_describe(nnpops_ani_t h, char* text, int capacity);
 /* The same check in two halves for callers that have more work to queue behind compute(): _begin (right after compute) queues
  * one single-thread launch that publishes the overflow word and a stamp into pinned host memory and returns 1 -- or 0 when the check cannot be deferred (first calls, while
  * capacities are still being fitted): call nnpops_ani_check() then.  _end (after the consumers of this build have been launched;

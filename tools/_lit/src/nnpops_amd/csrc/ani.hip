@@ -20,7 +20,6 @@
 
 using namespace nnpops;
 
-constexpr int kFuseAtoms = 4096;       // systems of up to this many atoms build and run the angular forward in one workgroup (ani_build_forward.h)
 struct nnpops_ani {
     AniParams hp{};                 // host copy of the parameter block
     AngularConsts ac{};             // what the angular backward kernel needs of it, passed by value (ani_kernels.h)
@@ -55,7 +54,6 @@ struct nnpops_ani {
     bool backward_forced = false;   // $NNPOPS_ANI_BACKWARD given: no automatic choice of the two-wave kernel for dense systems
     bool fwd_uniform = false;       // every radial factor shares its eta, every angular factor its zeta (set at create; $NNPOPS_ANI_FWD_UNI=0)
     bool fwd_grid = true;           // ... and eight radial factors sit on equally spaced shifts (what the UNI forward kernel assumes of eight)
-    bool fwd_literal = false;       // ... and every derived constant equals the compiled-in ANI-2x set bit for bit (Ani2xAngular): literal kernels
     int fuse_forward = -1;          // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h).  -1: for
                                     // systems of up to kFuseAtoms atoms, where a launch less is worth 6-13 % of a step (600 atoms:
                                     // 33.7 -> 29.6 us, 3 000: 49.5 -> 46.3) -- at 5 000 it breaks even and at 10 000 its lower
@@ -282,12 +280,8 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             // balanced phase 2 (per-atom quad table, ani_angular_mfma.h: DYN): needs the row assembled in LDS and a lane per bucket
             const bool dyn = h->fwd_dynamic && (vec_ok & 8) && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * (NFRP + NFZP);
             auto k = h->fwd_occ == 6 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 6> : h->fwd_occ == 8 ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 8>
-                   : dyn ? (uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, 1, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, 0, true>)
-                   : uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, 1> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
-            if constexpr (NFRP == 8 && NFZP == 4) {            // the published ANI-2x constants: kernels that carry them as literals
-                if (uni && h->fwd_literal && h->fwd_occ != 6 && h->fwd_occ != 8)
-                    k = dyn ? ani_angular_forward_mfma<TA, 8, 4, 2, 7, 2, true> : ani_angular_forward_mfma<TA, 8, 4, 2, 7, 2>;
-            }
+                   : dyn ? (uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, false, true>)
+                   : uni ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7>;
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
             hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
                                h->d_recB, h->d_tri, h->d_cnt_a, h->d_cnt_ro, out, h->ld_angular, vec_ok, lw, sp.ang_order, sp.w0, sp.nw);
@@ -407,6 +401,7 @@ int fused_chunk(const nnpops_ani* h) {
 }
 
 bool build_forward_fused(const nnpops_ani* h, const float* angular) {
+    constexpr int kFuseAtoms = 4096;
     const bool want = h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0;
     return want && !h->generic && h->forward_kernel == 2 && h->fwd_waves_per_atom == 2 && h->nfrp == 8 && h->nfzp == 4 &&
            h->nstreams == 1 && h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)angular & 15) == 0 &&
@@ -422,9 +417,8 @@ int launch_build_forward(nnpops_ani* h, const BuildInputs& in, const BuildOutput
     const bool uni = h->fwd_uniform && h->fwd_grid && h->hp.nFR == 8 && h->hp.nFZ == 4;
     const bool dyn = h->fwd_dynamic && h->fwd_row_via_lds && h->hp.NB <= 63 && h->hp.NB * h->hp.nA <= CH * 12;
     auto k = h->fwd_occ == 6 ? ani_build_forward<TA, 8, 4, 6>
-           : dyn ? (uni ? ani_build_forward<TA, 8, 4, 7, 1, true> : ani_build_forward<TA, 8, 4, 7, 0, true>)
-           : uni ? ani_build_forward<TA, 8, 4, 7, 1> : ani_build_forward<TA, 8, 4, 7>;
-    if (uni && h->fwd_literal && h->fwd_occ != 6) k = dyn ? ani_build_forward<TA, 8, 4, 7, 2, true> : ani_build_forward<TA, 8, 4, 7, 2>;
+           : dyn ? (uni ? ani_build_forward<TA, 8, 4, 7, true, true> : ani_build_forward<TA, 8, 4, 7, false, true>)
+           : uni ? ani_build_forward<TA, 8, 4, 7, true> : ani_build_forward<TA, 8, 4, 7>;
     if (lds > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(sp.nw), dim3(128), lds, sp.stream, h->d_params, in, out, h->cap, h->cap_angular, CH, angular,
                        h->ld_angular, vec_ok, tri_offset, sp.w0, sp.nw);
@@ -554,17 +548,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         g.d4 = (float)(4.0 * d);
     }
     if (const char* e = std::getenv("NNPOPS_ANI_FWD_UNI")) h->fwd_uniform = h->fwd_uniform && std::atoi(e) != 0;
-    {   // the published ANI-2x constants? (bit-for-bit: a model that differs in the last place keeps its constants in registers)
-        using L = Ani2xAngular;
-        const GeoRadial& g = hp.geo;
-        const float lz[4] = {L::zc0, L::zc1, L::zc2, L::zc3}, ls[4] = {L::zs0, L::zs1, L::zs2, L::zs3};
-        bool same = h->fwd_uniform && h->fwd_grid && hp.nFR == 8 && hp.nFZ == 4 && hp.fz_zeta[0] == L::zeta && hp.fz_bias[0] == L::zbias &&
-                    g.rs1 == L::rs1 && g.c == L::c && g.k1 == L::k1 && g.k0 == L::k0 && g.q == L::q && g.q4 == L::q4 && g.qi4 == L::qi4 &&
-                    g.d4 == L::d4;
-        for (int z = 0; z < 4 && same; z++) same = hp.fz_cos[z] == lz[z] && hp.fz_sin[z] == ls[z];
-        h->fwd_literal = same;
-        if (const char* e = std::getenv("NNPOPS_ANI_FWD_LITERAL")) h->fwd_literal = h->fwd_literal && std::atoi(e) != 0;
-    }
     // Matrix-core forward kernel: quads are handed the species pairs that can occur among this system's atoms.
     {
         std::vector<char> present(num_species, 0);
@@ -1144,19 +1127,6 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
 int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word) {
     NNPOPS_REQUIRE(h != nullptr && word != nullptr, "NULL argument");
     *word = reinterpret_cast<const int32_t*>(h->d_status + kStatOverflow);
-    return NNPOPS_OK;
-}
-
-int nnpops_ani_describe(nnpops_ani_t h, char* text, int capacity) {
-    NNPOPS_REQUIRE(h != nullptr && text != nullptr && capacity > 0, "NULL argument");
-    const bool uni = h->fwd_uniform && h->hp.nFR == h->nfrp && h->hp.nFZ == h->nfzp;
-    const bool shape2x = h->nfrp == 8 && h->nfzp == 4;
-    std::snprintf(text, (size_t)capacity,
-                  "forward=%s backward=%d generic=%d uniform=%d grid=%d literal=%d dynamic_quads=%d fused_build=%d cap=%d cap_angular=%d "
-                  "chunk=%d classes=%d cells=%d",
-                  h->forward_kernel == 2 ? "mfma" : h->forward_kernel == 1 ? "chunked" : "merge", h->backward_kernel, (int)h->generic,
-                  (int)uni, (int)(uni && h->fwd_grid), (int)(uni && h->fwd_grid && shape2x && h->fwd_literal), (int)h->fwd_dynamic,
-                  (int)(h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0), h->cap, h->cap_angular, h->fwd_chunk, (int)h->bwd_classes.size(), (int)h->last_used_cells);
     return NNPOPS_OK;
 }
 

@@ -77,7 +77,6 @@ __device__ __forceinline__ const float* lds_ptr(int byte_address) {
 // list read back from global memory) and ani_build_forward (ani_build_forward.h: the neighbour build of the same atom
 // runs first in the same workgroup and leaves them in LDS).
 // UNI: every radial factor has the same eta and every angular factor the same zeta (ANI-1x / 1ccx / 2x: one EtaA, one Zeta)
-// (1; 2: ... and the constants are those of the published ANI-2x set, compiled in as literals: Ani2xAngular, ani_kernels.h)
 // and no factor slot is padding: 13 fewer wave-uniform constants to hold in scalar registers through phase 1 -- the kernel
 // parks scalars in vector lanes when they run out (one vector instruction to park, one to fetch back).
 // DYN (two waves per atom, row assembled in LDS, at most 63 buckets): the quads are dealt out PER ATOM.  With a fixed quad per species
@@ -87,7 +86,7 @@ __device__ __forceinline__ const float* lds_ptr(int byte_address) {
 // shared by consecutive quads of ONE wave (never across the two), whose partial blocks are added with a segmented shuffle before
 // the row is assembled; species pairs without triples get no quad at all (the row is zero-filled first).  Steps: 14 -> ~9 for the
 // 7-species liquid, 9 -> 5 for water.
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, int UNI = 0, bool DYN = false>
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, bool UNI = false, bool DYN = false>
 struct MfmaForward {
     static_assert(!DYN || WPA == 2, "the per-atom quad table is built by the first of two waves");
     static constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
@@ -134,32 +133,28 @@ struct MfmaForward {
             sbk[s] = P->fwd_slot_bucket[(role * NS + s) * 16 + quad];          // -1: unused slot
             spart[s] = ((role * NS + s) * 16 + quad) & (K - 1);
         }
-        if constexpr (UNI == 2) {
-            static_assert(UNI != 2 || (NFRP == 8 && NFZP == 4 && NR4 == 2), "the literal set is ANI-2x's 8 x 4");
-            zz0 = Ani2xAngular::zeta; zb0 = Ani2xAngular::zbias;
-            geo.rs1 = Ani2xAngular::rs1; geo.c = Ani2xAngular::c; geo.k1 = Ani2xAngular::k1; geo.k0 = Ani2xAngular::k0;
-            geo.q = Ani2xAngular::q; geo.q4 = Ani2xAngular::q4; geo.qi4 = Ani2xAngular::qi4; geo.d4 = Ani2xAngular::d4;
 #pragma unroll
-            for (int z = 0; z < NFZP; z++) {
-                constexpr float c4[4] = {Ani2xAngular::zc0, Ani2xAngular::zc1, Ani2xAngular::zc2, Ani2xAngular::zc3};
-                constexpr float s4[4] = {Ani2xAngular::zs0, Ani2xAngular::zs1, Ani2xAngular::zs2, Ani2xAngular::zs3};
-                zc[z] = c4[z & 3]; zs[z] = s4[z & 3];
-            }
-        } else {
+        for (int a = 0; a < NFRP; a++) { frc[a] = a < nFR ? P->fr_c[a] : 0.f; frs[a] = a < nFR ? P->fr_rs[a] : 0.f; }
 #pragma unroll
-            for (int a = 0; a < NFRP; a++) { frc[a] = a < nFR ? P->fr_c[a] : 0.f; frs[a] = a < nFR ? P->fr_rs[a] : 0.f; }
-#pragma unroll
-            for (int z = 0; z < NFZP; z++) {
-                zz[z] = z < nFZ ? P->fz_zeta[z] : 1.f;
-                zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
-                zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
-                zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;             // 1 - zeta: the 2^(1-zeta) of ref :104-109 folded into the exponent
-            }
-            frc0 = P->fr_c[0]; zz0 = P->fz_zeta[0]; zb0 = P->fz_bias[0];
-            if constexpr (UNI && NFRP == 8) {
-                static_assert(NFRP != 8 || NR4 == 2, "factor order of the 16-byte records");
-                geo.rs1 = P->geo.rs1; geo.c = P->geo.c; geo.k1 = P->geo.k1; geo.k0 = P->geo.k0;
-                geo.q = P->geo.q; geo.q4 = P->geo.q4; geo.qi4 = P->geo.qi4; geo.d4 = P->geo.d4;
+        for (int z = 0; z < NFZP; z++) {
+            zz[z] = z < nFZ ? P->fz_zeta[z] : 1.f;
+            zc[z] = z < nFZ ? P->fz_cos[z] : 0.f;
+            zs[z] = z < nFZ ? P->fz_sin[z] : 0.f;
+            zb[z] = z < nFZ ? P->fz_bias[z] : 0.f;             // 1 - zeta: the 2^(1-zeta) of ref :104-109 folded into the exponent
+        }
+        frc0 = P->fr_c[0]; zz0 = P->fz_zeta[0]; zb0 = P->fz_bias[0];
+        if constexpr (UNI && NFRP == 8) {
+            static_assert(NFRP != 8 || NR4 == 2, "factor order of the 16-byte records");
+            geo.rs1 = P->geo.rs1; geo.c = P->geo.c; geo.k1 = P->geo.k1; geo.k0 = P->geo.k0;
+            geo.q = P->geo.q; geo.q4 = P->geo.q4; geo.qi4 = P->geo.qi4; geo.d4 = P->geo.d4;
+            if constexpr (NFZP == 4) {
+                zz0 = 14.100000381469727f; zb0 = -13.100000381469727f;
+                zc[0] = 0.9238795042037964f; zs[0] = 0.3826834559440613f;
+                zc[1] = 0.3826834261417389f; zs[1] = 0.9238795042037964f;
+                zc[2] = -0.3826833963394165f; zs[2] = 0.9238795638084412f;
+                zc[3] = -0.9238795042037964f; zs[3] = 0.38268348574638367f;
+                geo.rs1 = 1.1375000476837158f; geo.c = -18.033687591552734f; geo.k1 = 12.172739028930664f; geo.k0 = -2.054149627685547f;
+                geo.q = 0.057980071753263474f; geo.q4 = 1.1300950973236468e-05f; geo.qi4 = 88488.1328125f; geo.d4 = 1.3499999046325684f;
             }
         }
     }
@@ -428,7 +423,7 @@ struct MfmaForward {
     }
 };
 
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC, int UNI = 0, bool DYN = false>
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC, bool UNI = false, bool DYN = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
     const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,

@@ -52,7 +52,7 @@ struct BuildOutputs {
     int ld_radial;
 };
 
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, int UNI = 0, bool DYN = false>
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, bool UNI = false, bool DYN = false>
 __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* __restrict__ P, BuildInputs in, BuildOutputs out, int cap,
                                                               int capA, int CH, float* __restrict__ angular, int ld_angular,
                                                               int vec_ok, int tri_offset, int w0, int nw) {

@@ -58,19 +58,6 @@ struct GeoRadial {
     float rs1, c, k1, k0;            // Rs_1;  -eta log2(e);  -2 c d;  c d^2
     float q, q4, qi4, d4;            // 2^(2 c d^2), its 4th power and the inverse of that; 4 d
 };
-// The angular factor constants of the published ANI-2x set (EtaA 12.5, Zeta 14.1, ShfA 0.8 + 0.3375 a, ShfZ (2 z + 1) pi / 8;
-// reference src/ani/BenchmarkCudaANISymmetryFunctions.cu:101-153), exactly as nnpops_ani_create derives them from those parameters.
-// A handle whose derived constants equal these bit for bit (checked there; anything else keeps the constants in registers) runs
-// forward kernels that carry them as LITERALS: the matrix-core forward kernel keeps ~110 wave-uniform values alive against 94 scalar
-// registers at seven waves per SIMD, the overflow is parked in vector lanes (v_writelane / v_readlane: vector-issue slots, the
-// resource these kernels are bound by), and these 18 constants are most of it -- 19 parked values become 6, the forward kernel
-// 17.0 -> 15.8 us at 10 000 atoms (round 4, interleaved A/B).
-struct Ani2xAngular {
-    static constexpr float zeta = 0x1.c333340000000p+3f, zbias = -0x1.a333340000000p+3f;
-    static constexpr float zc0 = 0x1.d906bc0000000p-1f, zc1 = 0x1.87de2a0000000p-2f, zc2 = -0x1.87de280000000p-2f, zc3 = -0x1.d906bc0000000p-1f;      // cos(ShfZ)
-    static constexpr float zs0 = 0x1.87de2c0000000p-2f, zs1 = 0x1.d906bc0000000p-1f, zs2 = 0x1.d906be0000000p-1f, zs3 = 0x1.87de2e0000000p-2f;      // sin(ShfZ)
-    static constexpr float rs1 = 0x1.2333340000000p+0f, c = -0x1.2089fc0000000p+4f, k1 = 0x1.8587140000000p+3f, k0 = -0x1.06ee600000000p+1f, q = 0x1.daf9060000000p-5f, q4 = 0x1.7b326e0000000p-17f, qi4 = 0x1.59a8220000000p+16f, d4 = 0x1.5999980000000p+0f;      // GeoRadial
-};
 typedef float v2f __attribute__((ext_vector_type(2)));
 // The two chains (from g_1 and from g_5) side by side in the halves of packed registers: R04 = {g_0, g_4}, R15 = {g_1, g_5},
 // R26, R37; Y = {x - Rs_1, x - Rs_5}.
