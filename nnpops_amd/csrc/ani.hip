@@ -55,6 +55,7 @@ struct nnpops_ani {
     bool backward_forced = false;   // $NNPOPS_ANI_BACKWARD given: no automatic choice of the two-wave kernel for dense systems
     bool fwd_uniform = false;       // every radial factor shares its eta, every angular factor its zeta (set at create; $NNPOPS_ANI_FWD_UNI=0)
     bool fwd_grid = true;           // ... and eight radial factors sit on equally spaced shifts (what the UNI forward kernel assumes of eight)
+    bool bwd_literal = true;        // ($NNPOPS_ANI_BWD_LITERAL=0: the backward kernel keeps its constants in registers)
     bool fwd_literal = false;       // ... and every derived constant equals the compiled-in ANI-2x set bit for bit (Ani2xAngular): literal kernels
     int fuse_forward = -1;          // neighbour build and angular forward of an atom in one workgroup (ani_build_forward.h).  -1: for
                                     // systems of up to kFuseAtoms atoms, where a launch less is worth 6-13 % of a step (600 atoms:
@@ -333,12 +334,16 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         void (*k)(const AniParams*, const AngularConsts, int, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
                   float4*, float4*, int, int, int, const int*, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
-                         : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, true>
+                         : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, 1>
                                                                                        : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
           : mode == 2 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, true>
-          : mode == 3 ? ((h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false, false, true>
+          : mode == 3 ? ((h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false, false, 1>
                                                                                        : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false>)
                       : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, true>;
+        if constexpr (NFRP == 8 && NFZP == 4) {                // the published ANI-2x constants as literals (Ani2xAngular)
+            if (h->fwd_literal && h->bwd_literal && h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4 && !h->occ6 && (mode == 1 || mode == 3))
+                k = mode == 1 ? ani_angular_backward_pair<TA, 8, 4, 5, 1, false, false, 2> : ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2>;
+        }
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
@@ -564,6 +569,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         for (int z = 0; z < 4 && same; z++) same = hp.fz_cos[z] == lz[z] && hp.fz_sin[z] == ls[z];
         h->fwd_literal = same;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_LITERAL")) h->fwd_literal = h->fwd_literal && std::atoi(e) != 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_BWD_LITERAL")) h->bwd_literal = std::atoi(e) != 0;
     }
     // Matrix-core forward kernel: quads are handed the species pairs that can occur among this system's atoms.
     {

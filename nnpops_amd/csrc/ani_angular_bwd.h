@@ -111,7 +111,7 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 // global memory in the caller's order (GLDS must be false, NFRP / NFZP are not used).
 // UNI: one eta for every radial factor, one zeta for every angular factor, no padded factor slots (ani_angular_mfma.h):
 // 20 fewer wave-uniform constants in scalar registers.
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, bool UNI = false>
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, int UNI = 0>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
     const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, int tile, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
@@ -147,18 +147,29 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     static_assert(!(GENERIC && GLDS), "generic function lists read their gradients from global memory");
     // (constants from the by-value block, padded on the host: no dependent scalar loads in the workgroup's prologue, ani_kernels.h)
     float frc[NFRP], frs[NFRP], fren[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];
+    if constexpr (UNI == 2) {                                  // the published ANI-2x set, compiled in (ani_kernels.h: Ani2xAngular)
+        static_assert(UNI != 2 || (NFRP == 8 && NFZP == 4), "the literal set is ANI-2x's 8 x 4");
+        using L = Ani2xAngular;
+        constexpr float rs8[8] = {L::rs_0, L::rs_1, L::rs_2, L::rs_3, L::rs_4, L::rs_5, L::rs_6, L::rs_7};
+        constexpr float c4[4] = {L::zc0, L::zc1, L::zc2, L::zc3}, s4[4] = {L::zs0, L::zs1, L::zs2, L::zs3};
 #pragma unroll
-    for (int a = 0; a < NFRP; a++) {
-        frc[a] = C.fr_c[UNI ? 0 : a];
-        frs[a] = C.fr_rs[a];
-        fren[a] = C.fr_negeta[UNI ? 0 : a];
-    }
+        for (int a = 0; a < NFRP; a++) { frc[a] = L::c; frs[a] = rs8[a & 7]; fren[a] = L::negeta; }
 #pragma unroll
-    for (int z = 0; z < NFZP; z++) {
-        zz[z] = C.fz_zeta[UNI ? 0 : z];
-        zc[z] = C.fz_cos[z];
-        zs[z] = C.fz_sin[z];
-        zb[z] = C.fz_bias[UNI ? 0 : z];
+        for (int z = 0; z < NFZP; z++) { zz[z] = L::zeta; zc[z] = c4[z & 3]; zs[z] = s4[z & 3]; zb[z] = L::zbias; }
+    } else {
+#pragma unroll
+        for (int a = 0; a < NFRP; a++) {
+            frc[a] = C.fr_c[UNI ? 0 : a];
+            frs[a] = C.fr_rs[a];
+            fren[a] = C.fr_negeta[UNI ? 0 : a];
+        }
+#pragma unroll
+        for (int z = 0; z < NFZP; z++) {
+            zz[z] = C.fz_zeta[UNI ? 0 : z];
+            zc[z] = C.fz_cos[z];
+            zs[z] = C.fz_sin[z];
+            zb[z] = C.fz_bias[UNI ? 0 : z];
+        }
     }
 
     const int stride_atoms = gridDim.x * atoms_per_group;

@@ -69,6 +69,8 @@ struct Ani2xAngular {
     static constexpr float zeta = 0x1.c333340000000p+3f, zbias = -0x1.a333340000000p+3f;
     static constexpr float zc0 = 0x1.d906bc0000000p-1f, zc1 = 0x1.87de2a0000000p-2f, zc2 = -0x1.87de280000000p-2f, zc3 = -0x1.d906bc0000000p-1f;      // cos(ShfZ)
     static constexpr float zs0 = 0x1.87de2c0000000p-2f, zs1 = 0x1.d906bc0000000p-1f, zs2 = 0x1.d906be0000000p-1f, zs3 = 0x1.87de2e0000000p-2f;      // sin(ShfZ)
+    static constexpr float rs_0 = 0x1.99999a0000000p-1f, rs_1 = 0x1.2333340000000p+0f, rs_2 = 0x1.79999a0000000p+0f, rs_3 = 0x1.d000000000000p+0f, rs_4 = 0x1.1333340000000p+1f, rs_5 = 0x1.3e66660000000p+1f, rs_6 = 0x1.69999a0000000p+1f, rs_7 = 0x1.94cccc0000000p+1f;      // ShfA
+    static constexpr float negeta = -0x1.9000000000000p+3f;
     static constexpr float rs1 = 0x1.2333340000000p+0f, c = -0x1.2089fc0000000p+4f, k1 = 0x1.8587140000000p+3f, k0 = -0x1.06ee600000000p+1f, q = 0x1.daf9060000000p-5f, q4 = 0x1.7b326e0000000p-17f, qi4 = 0x1.59a8220000000p+16f, d4 = 0x1.5999980000000p+0f;      // GeoRadial
 };
 typedef float v2f __attribute__((ext_vector_type(2)));
