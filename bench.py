@@ -195,9 +195,38 @@ def _pmc_pass(counters, atoms, workdir, tag):
     return res
 
 
+def _trace_pass(atoms, workdir):
+    """rocprofv3 --kernel-trace (no counters) over 300 steps of this very workload -> {roofline key: average kernel duration in us}
+    (None when rocprofv3 is missing or the pass fails): the figure the committed profiles/ summaries hold, taken in the same run."""
+    import glob
+    import shutil
+    import sqlite3
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = os.path.join(workdir, "kt")
+    cmd = [exe, "--kernel-trace", "-d", out, "-o", "kt", "--output-format", "rocpd", "--", sys.executable, os.path.abspath(__file__),
+           "--steps", "300", "--warmup", "0", "--settle", "50", "--atoms", str(atoms), "--no-side", "--no-cpu-baseline", "--no-pmc"]
+    try:
+        subprocess.run(cmd, cwd=workdir, env=dict(os.environ, TMPDIR=workdir), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=90, check=True)
+        dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+        if not dbs:
+            return None
+        rows = sqlite3.connect(dbs[0]).execute("select name, count(*), avg(duration) from kernels group by name").fetchall()
+    except Exception:
+        return None
+    res = {}
+    for name, calls, avg_ns in rows:
+        for frag, key in PMC_KERNEL_OF.items():
+            if frag in name and calls >= 100:
+                res[key] = res.get(key, 0.0) + avg_ns / 1e3          # (the two grid kernels add up)
+    return res
+
+
 def measure_counters(atoms):
-    """-> ({kernel: HBM bytes per launch}, {kernel: {valu, mfma, waves}}) from four rocprofv3 passes of this very workload, or
-    ({}, {}) when rocprofv3 is not available.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE reports half
+    """-> ({kernel: HBM bytes per launch}, {kernel: {valu, mfma, waves}}, {kernel: rocprofv3's average duration in us}) from four
+    rocprofv3 passes of this very workload, or empty dicts when rocprofv3 is not available.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE reports half
     the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is."""
     import shutil
     import tempfile
@@ -206,6 +235,7 @@ def measure_counters(atoms):
         fetch = _pmc_pass(["FETCH_SIZE"], atoms, workdir, "fetch")
         write = _pmc_pass(["WRITE_SIZE"], atoms, workdir, "write") if fetch else None
         sq = _pmc_pass(["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA"], atoms, workdir, "sq") if fetch else None
+        traced = _trace_pass(atoms, workdir) if fetch else None
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
     traffic, insts = {}, {}
@@ -217,7 +247,7 @@ def measure_counters(atoms):
         for k, c in sq.items():
             insts[k] = {"valu": c.get("SQ_INSTS_VALU", 0.0), "mfma": c.get("SQ_INSTS_MFMA", 0.0), "salu": c.get("SQ_INSTS_SALU", 0.0),
                         "lds": c.get("SQ_INSTS_LDS", 0.0), "waves": c.get("SQ_WAVES", 0.0)}
-    return traffic, insts
+    return traffic, insts, (traced or {})
 
 
 # =============================================================================================
@@ -373,21 +403,26 @@ def run_aev(args, R):
     #  50 steps leave it +-1 us of noise; they are untimed like the W warm-up steps they contain)
     cal_steps = max(args.warmup, 300) if args.warmup else 0
     sym.enable_timing(True)
-    for _ in range(cal_steps):
-        step()
-    breakdown = sym.get_timing() if args.warmup else {}
-    # ... and once more with ONE bracket around neighbour build + angular forward and ONE around the two backward kernels: the sum of
-    # two single brackets minus the merged one is what a bracket adds to the stream -- measured in place (same launches, same cache
-    # state).  It is neither the same on every box nor what an EMPTY bracket reports (3.5 us): 0.4 ... 1.7 us were seen.  (Two
-    # earlier round-4 attempts -- one fitted amount for all brackets; each kernel launched twice inside its bracket -- agreed with
+    # ... single brackets (one per kernel) and merged ones -- ONE bracket around neighbour build + angular forward and ONE around the two
+    # backward kernels -- in alternating blocks of 100 steps: the sum of two single brackets minus the merged one is what a bracket adds
+    # to the stream, measured in place (same launches, same cache state; alternating, so that a clock that drifts during these 60 ms
+    # drifts under both).  It is neither the same on every box nor what an EMPTY bracket reports (3.5 us): 0.2 ... 1.7 us were seen.
+    # (Two earlier round-4 attempts -- one fitted amount for all brackets; each kernel launched twice inside its bracket -- agreed with
     # rocprofv3 within 2 % on one box and missed by 7-11 % on the next.)
-    merged = {}
-    if args.warmup and not dist:
-        sym.set_timing_merge(True)
-        for _ in range(cal_steps):
+    def add(total, part):
+        for k, (ms, c) in part.items():
+            t = total.get(k, (0.0, 0))
+            total[k] = (t[0] + ms, t[1] + c)
+    breakdown, merged = {}, {}
+    calibrate = bool(args.warmup) and not dist
+    blocks = 6 if calibrate else 1
+    per_block = -(-cal_steps // (blocks // 2 if calibrate else 1))
+    for b in range(blocks if args.warmup else 0):
+        sym.set_timing_merge(bool(b & 1))
+        for _ in range(per_block):
             step()
-        merged = sym.get_timing()
-        sym.set_timing_merge(False)
+        add(merged if b & 1 else breakdown, sym.get_timing())
+    sym.set_timing_merge(False)
     sym.enable_timing(False)
     if not args.warmup:
         step()
@@ -458,7 +493,7 @@ def run_aev(args, R):
     step_bytes = n * (16 + 2 * (na_w + nr_w) * 4 + 12)        # N * (16 + 2 * 4032 + 12)
     # HBM traffic and instruction counts of these kernels, measured now (rocprofv3 on three steps of this same workload; the
     # counters come from their own passes, the TIMES above from the un-profiled run)
-    traffic_all, insts = ({}, {}) if (args.no_pmc or world > 1) else measure_counters(n)
+    traffic_all, insts, traced = ({}, {}, {}) if (args.no_pmc or world > 1) else measure_counters(n)
     traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run: (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch" if traffic_all else None
 
     def valu_floor(k):
@@ -475,8 +510,12 @@ def run_aev(args, R):
 
     def roof(k):
         ach = alg[k] / kern[k] / 1e9 if kern.get(k, 0) > 0 else 0.0
-        return {"kernel": ROCPROF_NAME[k], "us": round(1e6 * kern.get(k, 0.0), 2), "algorithmic_bytes_per_launch": alg[k],
-                "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(k), "valu": valu_floor(k)}
+        res = {"kernel": ROCPROF_NAME[k], "us": round(1e6 * kern.get(k, 0.0), 2), "algorithmic_bytes_per_launch": alg[k],
+               "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(k), "valu": valu_floor(k)}
+        if traced.get(k):                                     # the same kernel as rocprofv3 --kernel-trace times it, in this run
+            res["us_rocprofv3"] = round(traced[k], 2)
+            res["frac_rocprofv3"] = round(alg[k] / (traced[k] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        return res
 
     dom = roof(dominant)
     out = {
@@ -491,6 +530,7 @@ def run_aev(args, R):
         "process_group": R.describe(),
         "kernels_us": {k: round(1e6 * v, 2) for k, v in kern.items()},
         "kernels_us_sum": round(1e6 * sum(kern.values()), 2),
+        "kernels_us_rocprofv3": ({k: round(v, 2) for k, v in traced.items()} or None),      # rocprofv3 --kernel-trace of 300 steps, run from here
         "event_pair_overhead_us": round(1e6 * event_overhead, 2),
         "bracket_correction_us": round(1e6 * correction, 2),
         "bracket_overhead_us": {k: round(1e6 * v, 2) for k, v in overhead.items()} or None,
@@ -502,7 +542,8 @@ def run_aev(args, R):
                             "event brackets minus `bracket_correction_us`, the one amount that makes the brackets of a step add up to "
                             "ms_per_step (no double brackets in this run)"),
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source,
+                     "frac": dom["frac"], "us_rocprofv3": dom.get("us_rocprofv3"), "frac_rocprofv3": dom.get("frac_rocprofv3"),
+                     "traffic": dom["traffic"], "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "valu": dom["valu"],
                      "longest_kernel": roof(longest),
                      "limiter": "not HBM: the per-atom kernels are bound by vector-instruction issue while the chip is full and by "

@@ -215,6 +215,10 @@ def test_default_bench_line_carries_measured_counters():
     for name, k in roof["per_kernel"].items():
         assert k["traffic"] is not None and k["traffic"] >= 0.9 * k["algorithmic_bytes_per_launch"], (name, k)
         assert 0.05 < k["valu"]["frac"] <= 1.0 and k["valu"]["valu_per_atom"] > 100, (name, k)
+        # the event-bracket figure of the line against rocprofv3's own duration of the same kernel, taken in the same run
+        assert abs(k["us"] - k["us_rocprofv3"]) <= 0.08 * k["us_rocprofv3"], (name, k)
+    assert abs(roof["frac"] - roof["frac_rocprofv3"]) <= 0.08 * roof["frac_rocprofv3"]
+    assert line["kernels_us_rocprofv3"]["cell_grid"] < 20
     four = sum(k["traffic"] for k in roof["per_kernel"].values())            # (the step also counts the two cell-grid kernels)
     assert four <= roof["step"]["traffic"] <= four + 16 * 2 ** 20
 
