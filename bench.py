@@ -910,7 +910,7 @@ def run_torchani(args, R):
         "data": "synthetic",
         "config": {"workload": f"OptimizedTorchANI, {n}-atom periodic water box (667 H2O), ANI-2x AEV + 8 x ANI-2x-shaped networks, "
                                f"random weights, BatchedNN layout = {args.nn_layout}, "
-                               + ("AEV + networks as one autograd node (8 launches per energy+forces step)" if one_node else "four-module composition")
+                               + ("AEV + networks as one autograd node (7 launches per energy+forces step)" if one_node else "four-module composition")
                                + (", replayed as one HIP graph" if args.graph else ""), "atoms": n,
                    "nn_weight_bytes": nn_weight_bytes, "nn_layout": args.nn_layout, "one_autograd_node": one_node,
                    "aev_columns": 1008, "aev_columns_multiplied": live_cols},

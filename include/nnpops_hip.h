@@ -120,6 +120,10 @@ int nnpops_ani_describe(nnpops_ani_t h, char* text, int capacity);
  * nnpops_ani_check() would: NNPOPS_OK, or NNPOPS_ERR_CAPACITY after growing the buffers -- compute() and everything queued
  * behind it must then be issued again.  Additive (the reference has no capacity check: its neighbour list is the N x N matrix). */
 int nnpops_ani_check_begin(nnpops_ani_t h);
+/* _begin without its launch, for a caller whose NEXT kernel on the stream can do the publishing itself (nnpops_mlp_forward with
+ * the frame's publish_* fields): returns 1 and the three values to hand to that kernel, or 0 when the check cannot be deferred.
+ * The caller must launch that kernel before nnpops_ani_check_end(), which otherwise waits for the stream and runs the full check. */
+int nnpops_ani_check_begin_with(nnpops_ani_t h, const int32_t** word, int32_t** publish_to, int32_t* stamp);
 int nnpops_ani_check_end(nnpops_ani_t h);
 /* Neighbour search used by compute(): 0 = automatic, 1 = all-pairs scan (the reference's
  * algorithm, O(N^2)), 2 = cell list (O(N); periodic boxes must be at least 3 cells wide per axis). */
@@ -334,6 +338,10 @@ typedef struct {
      * energy mean of nnpops_mlp_energy_mean (mean_out, a device float) or nnpops_mlp_energy_mean_shifted (mean_shift and
      * mean_out_shifted, device doubles) with scale mean_scale -- same numbers, one launch fewer. */
     float mean_scale; float* mean_out; const double* mean_shift; double* mean_out_shifted;
+    /* Optional, honoured by nnpops_mlp_forward: its first thread copies *publish_word to publish_to[1] and then stores publish_stamp
+     * to publish_to[0] (system scope, release) -- the deferred capacity check of an ANI handle (nnpops_ani_check_begin_with) riding
+     * along instead of taking a launch of its own.  All three come from that call; NULL / 0: nothing is published. */
+    const int32_t* publish_word; int32_t* publish_to; int32_t publish_stamp;
 } nnpops_mlp_frame;
 int64_t nnpops_mlp_packed_halves(int rows, int cols);
 int64_t nnpops_mlp_d1_halves(int num_atoms, int num_members, int h1);

@@ -41,7 +41,7 @@ class OptimizedTorchANI(torch.nn.Module):
 class FusedOptimizedTorchANI(OptimizedTorchANI):
     """OptimizedTorchANI whose forward is ``torch.ops.NNPOpsANISymmetryFunctions.energy``: neighbour search + AEV + the four
     layers of every atomic network (+, when the positions require a gradient, the networks' input gradient and the AEV
-    backward) issued back to back from one C++ call -- 8 kernel launches, one autograd node whose backward is a single
+    backward) issued back to back from one C++ call -- 7 kernel launches (the capacity check rides in the first network launch), one autograd node whose backward is a single
     multiplication -- instead of the ~45 launches the composition records.  Not constructed directly: ``OptimizedTorchANI(...)``
     turns into it.  Second derivatives are refused (use ``fused_step=False``)."""
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "nnpops_ani_timing_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "nnpops_ani_overflow_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "nnpops_ani_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nnpops_ani_check_begin_with": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "nnpops_ani_set_timing_merge": (C.c_int, [C.c_void_p, C.c_int]),
     "nnpops_cfconv_neighbors_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_float, C.c_int, C.c_int]),
     "nnpops_cfconv_neighbors_destroy": (C.c_int, [C.c_void_p]),
@@ -513,7 +514,8 @@ class _MlpFrame(C.Structure):
                 ("rows", C.c_void_p), ("energies", C.c_void_p), ("alpha", C.c_float), ("dx", C.c_void_p), ("lddx", C.c_int),
                 ("upstream", C.c_void_p), ("dx_scale", C.c_float), ("kinds", _MlpKind * MLP_MAX_KINDS),
                 ("x_groups", C.c_void_p), ("dead_groups", C.c_void_p), ("num_dead_groups", C.c_int), ("dx_partial", C.c_void_p),
-                ("mean_scale", C.c_float), ("mean_out", C.c_void_p), ("mean_shift", C.c_void_p), ("mean_out_shifted", C.c_void_p)]
+                ("mean_scale", C.c_float), ("mean_out", C.c_void_p), ("mean_shift", C.c_void_p), ("mean_out_shifted", C.c_void_p),
+                ("publish_word", C.c_void_p), ("publish_to", C.c_void_p), ("publish_stamp", C.c_int32)]
 
 
 def mlp_pack(w, rows, cols, transpose=False, permute=False):

@@ -962,8 +962,8 @@ __global__ void ani_publish_status(const int* __restrict__ status, int* __restri
 }  // namespace
 extern "C" {
 
-int nnpops_ani_check_begin(nnpops_ani_t h) {
-    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+// -> 1: the handle can defer its check and has a fresh stamp (host words allocated); 0: not deferrable
+static int check_begin_prepare(nnpops_ani_t h) {
     h->check_pending = false;
     if (!h->cap_fitted || h->backward_kernel == 0) return 0;          // the full check has decisions to make: not deferrable
     DeviceGuard guard(h->device);
@@ -978,8 +978,25 @@ int nnpops_ani_check_begin(nnpops_ani_t h) {
         }
     }
     h->check_stamp = h->check_stamp == 0x7fffffff ? 1 : h->check_stamp + 1;
+    return 1;
+}
+
+int nnpops_ani_check_begin(nnpops_ani_t h) {
+    NNPOPS_REQUIRE(h != nullptr, "NULL handle");
+    if (!check_begin_prepare(h)) return 0;
+    DeviceGuard guard(h->device);
     hipLaunchKernelGGL(ani_publish_status, dim3(1), dim3(1), 0, h->stream, h->d_status, h->h_status_dev, h->check_stamp);
     if (hipGetLastError() != hipSuccess) return 0;
+    h->check_pending = true;
+    return 1;
+}
+
+int nnpops_ani_check_begin_with(nnpops_ani_t h, const int32_t** word, int32_t** publish_to, int32_t* stamp) {
+    NNPOPS_REQUIRE(h != nullptr && word != nullptr && publish_to != nullptr && stamp != nullptr, "NULL argument");
+    if (!check_begin_prepare(h)) return 0;
+    *word = reinterpret_cast<const int32_t*>(h->d_status + kStatOverflow);
+    *publish_to = reinterpret_cast<int32_t*>(h->h_status_dev);
+    *stamp = h->check_stamp;
     h->check_pending = true;
     return 1;
 }

@@ -78,6 +78,7 @@ struct MlpArgs {
     const int* dead_groups; int num_dead;   // 16-column blocks of dx the gradient pass sets to zero
     float* dx_partial; int n_grouped;       // optional [M][n_grouped][F]: every member's W0^T dE/dy1, formed by the forward launch
     float mean_scale; float* mean_out; const double* mean_shift; double* mean_out_shifted;   // optional: the energy mean rides along (mlp_sum_members)
+    const int* publish_word; int* publish_to; int publish_stamp;                             // optional: an ANI handle's deferred capacity check rides along (mlp_forward)
     KindDesc kinds[NNPOPS_MLP_MAX_KINDS];
 };
 
@@ -208,6 +209,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
     const int local = blockIdx.x - kd.block0;
     const int m = local % g.M, tile = local / g.M;
     if (tid < 64) xgroup[tid] = 16 * tid < g.F ? (g.x_groups ? g.x_groups[tid] : tid) : 0;
+    if (g.publish_to && blockIdx.x == 0 && tid == 64) {     // (nnpops_hip.h: publish_*; what ani_publish_status would need a launch for)
+        const int word = __hip_atomic_load(g.publish_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g.publish_to[1], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&g.publish_to[0], g.publish_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
     const int r0 = tile * kTile;                            // first atom of the tile inside the kind
     const int kgD = lane >> 4, a16 = lane & 15;
@@ -628,6 +634,8 @@ int check_and_fill(const nnpops_mlp_frame* fr, MlpArgs& g, bool grad, int blocks
     g.x_groups = fr->x_groups; g.dead_groups = fr->dead_groups; g.num_dead = fr->dead_groups ? fr->num_dead_groups : 0;
     g.dx_partial = grad ? fr->dx_partial : nullptr;
     g.mean_scale = fr->mean_scale; g.mean_out = fr->mean_out; g.mean_shift = fr->mean_shift; g.mean_out_shifted = fr->mean_out_shifted;
+    g.publish_word = fr->publish_word; g.publish_to = fr->publish_word ? fr->publish_to : nullptr; g.publish_stamp = fr->publish_stamp;
+    NNPOPS_REQUIRE(!fr->publish_word || fr->publish_to, "publish_word without publish_to");
     NNPOPS_REQUIRE(!(fr->mean_out && fr->mean_out_shifted) && (!fr->mean_out_shifted || fr->mean_shift), "one energy mean: float, or shifted double with its shift");
     NNPOPS_REQUIRE(!fr->x_groups || fr->num_features % 16 == 0, "x_groups maps blocks of 16 features: the feature count must be a multiple of 16 (got %d)",
                    fr->num_features);

@@ -285,7 +285,10 @@ public:
             if (!forceCheck) calls++;
             forceCheck = false;
             if (!due && attempt == 0) break;
-            if (defer_check && nnpops_ani_check_begin(impl) == 1) { checkPending = true; break; }
+            if (defer_check && publishInline) {                // (the caller's next launch publishes the word: energy_step)
+                if (nnpops_ani_check_begin_with(impl, &publishWord, &publishTo, &publishStamp) == 1) { checkPending = true; break; }
+                publishWord = nullptr;
+            } else if (defer_check && nnpops_ani_check_begin(impl) == 1) { checkPending = true; break; }
             const int rc = nnpops_ani_check(impl, nullptr, nullptr);
             if (rc == NNPOPS_OK) break;
             if (rc != NNPOPS_ERR_CAPACITY || attempt > 8) raise_last("NNPOpsANISymmetryFunctions::forward");
@@ -388,6 +391,11 @@ private:
     bool forceCheck = false;        // the next forwardImpl() re-issues a step after a reported overflow: always checked
     int64_t calls = 0;
     bool checkPending = false;
+public:
+    // energy_step: the capacity check's word is published by nnpops_mlp_forward (frame.publish_*) instead of a launch of its own
+    bool publishInline = false;
+    const int32_t* publishWord = nullptr; int32_t* publishTo = nullptr; int32_t publishStamp = 0;
+private:
 };
 
 class AutogradFunctions : public torch::autograd::Function<AutogradFunctions> {
@@ -452,10 +460,15 @@ std::pair<Tensor, Tensor> energy_step(const HolderPtr& holder, const Tensor& fra
     Tensor energy, kept;
     for (int attempt = 0;; attempt++) {
         TORCH_CHECK(attempt <= 8, "NNPOpsANISymmetryFunctions::energy: neighbour buffers kept overflowing");
+        holder->publishInline = true; holder->publishWord = nullptr;
         const Tensor aev = holder->forwardImpl(positions, cell, true, /*defer_check=*/true)[0];
+        holder->publishInline = false;
         c10::hip::HIPGuard guard(aev.device().index());
         void* stream = current_stream(aev.device());
         MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks);
+        if (holder->publishWord) {                              // the deferred check's word goes out with the first network launch
+            call.frame.publish_word = holder->publishWord; call.frame.publish_to = holder->publishTo; call.frame.publish_stamp = holder->publishStamp;
+        }
         if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
         // the ensemble mean (BatchedNN.py:109), shifted by the self energy when the caller hands it over: its own small launch,
         // or -- when the input gradient is only a sum over the members (dx_partial) -- a passenger of that launch
