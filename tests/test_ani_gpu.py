@@ -541,6 +541,8 @@ def test_published_ani2x_constants_run_the_literal_kernels(monkeypatch, kind, fu
         pos, species, box = workloads.random_box(700, seed=6, n_species=7, species_probs=[0.5, 0.3, 0.1, 0.1, 0, 0, 0])
     assert AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True).describe()["literal"] == "1"
     _, a_lit, _ = _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
+    assert AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True, torchani=False).describe()["literal"] == "1"
+    _run_case(7, 5.1, 3.5, species, rf, af, pos, box, torchani=False)         # (the paper's angle: its own instantiations of the literal kernels)
     monkeypatch.setenv("NNPOPS_ANI_FWD_LITERAL", "0")
     assert AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True).describe()["literal"] == "0"
     _, a_reg, _ = _run_case(7, 5.1, 3.5, species, rf, af, pos, box)
