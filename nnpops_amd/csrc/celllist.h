@@ -290,11 +290,11 @@ constexpr int kBinnedThreads = 256;
 constexpr int kHistWords = kBinnedCells + 1;
 
 // phase 1 of the binned build for atom i (any i; returns its cell, or -1)
-__device__ __forceinline__ int bin_one_atom(int i, int N, const CellGrid& g, const float* __restrict__ pos, int* __restrict__ hist,
+__device__ __forceinline__ int bin_one_atom(int i, int N, const CellGrid& g, float x, float y, float z, int* __restrict__ hist,
                                             int* __restrict__ bins, int bin_cap) {
     if (i >= N || !g.ok) return -1;
     int cx, cy, cz;
-    cell_of(g, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], cx, cy, cz);
+    cell_of(g, x, y, z, cx, cy, cz);
     const int c = (cz * g.ny + cy) * g.nx + cx;
     const int r = atomicAdd(&hist[c], 1);
     if (r < bin_cap) bins[(size_t)c * bin_cap + r] = i;
@@ -302,23 +302,40 @@ __device__ __forceinline__ int bin_one_atom(int i, int N, const CellGrid& g, con
     return c;
 }
 
-// phase 2 (whole block): scan of the histogram in LDS, then atom i (cell c) is ranked inside its bin and published
+// phase 2 (whole block): scan of the histogram in LDS, then atom i (cell c) is ranked inside its bin and published.
+// Everything that does not depend on another load is requested up front -- the grid, the atom's cell, position and tag, the whole
+// (8 192-word) histogram, then the first eight ids of the atom's bin as soon as the cell is there: two round trips to memory and
+// the scan, where "grid, then cell and counts, then bin, then position" was four.
 template <int T>
-__device__ __forceinline__ void order_block(int i, int c, int N, const CellGrid& g, CellGrid* __restrict__ grid,
-                                            const float* __restrict__ pos, const int* __restrict__ tag, const int* __restrict__ hist,
-                                            const int* __restrict__ bins, int bin_cap, int* __restrict__ cell_start,
+__device__ __forceinline__ void order_block(int N, CellGrid* __restrict__ grid, const float* __restrict__ pos,
+                                            const int* __restrict__ tag, const int* __restrict__ hist, const int* __restrict__ bins,
+                                            int bin_cap, const int* __restrict__ atom_cell, int* __restrict__ cell_start,
                                             int* __restrict__ sorted_atom, float4* __restrict__ sorted_pos,
                                             int* __restrict__ sorted_cell, int* s_start, int* wave_tot) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * T + tid, ic = min(i, N - 1);
+    const CellGrid g = *grid;
+    const int c = atom_cell[ic];
+    const float px = pos[3 * ic], py = pos[3 * ic + 1], pz = pos[3 * ic + 2];
+    const int packed = ic | (tag ? (tag[ic] << kTagShift) : 0);
+    const int overflowed = hist[kBinnedCells];
+    constexpr int PER = kBinnedCells / T;
+    int mine[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) mine[q] = hist[q * T + tid];
+    // (cell ids of a grid that was not built are stale: stay inside the bins)
+    const int4* bin4 = reinterpret_cast<const int4*>(bins + (size_t)min(max(c, 0), kBinnedCells - 1) * bin_cap);    // bin_cap is a multiple of 4
+    const int4 first = bin4[0], second = bin_cap >= 8 ? bin4[1] : make_int4(0, 0, 0, 0);
     if (!g.ok) return;
-    if (hist[kBinnedCells] != 0) {                            // a bin overflowed: this grid is unusable
+    if (overflowed != 0) {                                    // a bin overflowed: this grid is unusable
         if (blockIdx.x == 0 && tid == 0) { grid->ok = 0; grid->bin_overflow = 1; }
         return;
     }
     const int ncells = g.ncells;
     // exclusive scan of the histogram, redundantly in every block: coalesced into LDS, then thread t owns a
     // contiguous run of cells
-    for (int q = tid; q < ncells; q += T) s_start[q] = hist[q];
+#pragma unroll
+    for (int q = 0; q < PER; q++) s_start[q * T + tid] = mine[q];
     __syncthreads();
     const int per = (ncells + T - 1) / T;
     const int c0 = min(tid * per, ncells), c1 = min(c0 + per, ncells);
@@ -337,17 +354,12 @@ __device__ __forceinline__ void order_block(int i, int c, int N, const CellGrid&
 
     if (i >= N) return;
     const int lo = s_start[c], n = s_start[c + 1] - lo;
-    const int* bin = bins + (size_t)c * bin_cap;
-    int rank = 0;                                             // deterministic order inside the cell
-    const int4* bin4 = reinterpret_cast<const int4*>(bin);    // bin_cap is a multiple of 4
-    for (int k = 0; k < n; k += 4) {
-        const int4 v = bin4[k >> 2];
-        rank += (v.x < i) + (k + 1 < n && v.y < i) + (k + 2 < n && v.z < i) + (k + 3 < n && v.w < i);
-    }
+    auto below = [&](const int4& v, int k) { return (k < n && v.x < i) + (k + 1 < n && v.y < i) + (k + 2 < n && v.z < i) + (k + 3 < n && v.w < i); };
+    int rank = below(first, 0) + below(second, 4);            // deterministic order inside the cell
+    for (int k = 8; k < n; k += 4) rank += below(bin4[k >> 2], k);
     sorted_atom[lo + rank] = i;
     if (sorted_cell) sorted_cell[lo + rank] = c;              // (a consumer that walks the sorted order gets the cell without a dependent load)
-    const int packed = i | (tag ? (tag[i] << kTagShift) : 0);
-    sorted_pos[lo + rank] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(packed));
+    sorted_pos[lo + rank] = make_float4(px, py, pz, __int_as_float(packed));
 }
 
 static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const float* __restrict__ pos,
@@ -356,13 +368,17 @@ static __global__ __launch_bounds__(kBinnedThreads) void bin_atoms(int N, const 
                                                                    int* __restrict__ bins, int bin_cap,
                                                                    int* __restrict__ atom_cell, int fine) {
     __shared__ CellGrid g;
+    // (the position is requested BEFORE the grid is decided: the box and the atom come back in one round trip, not two -- these
+    //  two kernels are nothing but their chains of dependent loads)
+    const int i = blockIdx.x * kBinnedThreads + threadIdx.x;
+    const int ic = min(i, N - 1);
+    const float x = pos[3 * ic], y = pos[3 * ic + 1], z = pos[3 * ic + 2];
     if (threadIdx.x == 0) {
         g = decide_grid(1, box, nullptr, nullptr, cutoff, min(max_cells, kBinnedCells), fine);
         if (blockIdx.x == 0) *grid = g;
     }
     __syncthreads();
-    const int i = blockIdx.x * kBinnedThreads + threadIdx.x;
-    const int c = bin_one_atom(i, N, g, pos, hist, bins, bin_cap);
+    const int c = bin_one_atom(i, N, g, x, y, z, hist, bins, bin_cap);
     if (c >= 0) atom_cell[i] = c;
 }
 
@@ -383,11 +399,7 @@ static __global__ __launch_bounds__(T) void order_binned(int N, const float* __r
                                                                       int* __restrict__ sorted_cell) {
     __shared__ int s_start[kBinnedCells + 1];
     __shared__ int wave_tot[T / 64];
-    const CellGrid g = *grid;
-    const int i = blockIdx.x * T + threadIdx.x;
-    const int c = (i < N && g.ok) ? atom_cell[i] : 0;
-    order_block<T>(i, c, N, g, grid, pos, tag, hist, bins, bin_cap, cell_start, sorted_atom, sorted_pos, sorted_cell,
-                   s_start, wave_tot);
+    order_block<T>(N, grid, pos, tag, hist, bins, bin_cap, atom_cell, cell_start, sorted_atom, sorted_pos, sorted_cell, s_start, wave_tot);
 }
 
 // The same stencil as ONE flat candidate index space: lane r < 18 looks up range r, a wave scan gives
