@@ -32,7 +32,8 @@ struct nnpops_ani {
     // device state
     int32_t* d_species = nullptr;
     int2* d_segment = nullptr;      // [N] per-atom [lo, hi) of its molecule (batched handles only)
-    float4* d_nbr = nullptr;        // [N][cap] records {dx, dy, dz, (species<<24)|atom}
+    float4* d_nbr = nullptr;        // [N][cap] records {dx, dy, dz, (species<<24)|atom}, rows by POSITION of the radial backward's walk (slot in cell order / atom index)
+    int* d_cnt_pos = nullptr;       // [N] na | nro << 16, by the same position
     float4* d_recA = nullptr;       // [N][cap_angular] sorted angular records {dx,dy,dz,r}
     float4* d_recB = nullptr;       // [N][cap_angular]                        {fc,dfc,1/r,word}
     int* d_ids = nullptr;           // [N][cap_angular] atom ids in record order (reverse lookup of the backward gather)
@@ -640,6 +641,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_species, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_a, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_ro, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_cnt_pos, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_centre_force, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_status, (size_t)kStatWords))) return cleanup(rc);
     if ((rc = alloc_rows(h))) return cleanup(rc);
@@ -712,7 +714,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess ||
         hipMemset(h->d_cnt_a, 0, sizeof(int) * num_atoms) != hipSuccess ||
-        hipMemset(h->d_cnt_ro, 0, sizeof(int) * num_atoms) != hipSuccess)
+        hipMemset(h->d_cnt_ro, 0, sizeof(int) * num_atoms) != hipSuccess || hipMemset(h->d_cnt_pos, 0, sizeof(int) * num_atoms) != hipSuccess)
         return cleanup(fail(NNPOPS_ERR_HIP, "parameter upload failed: %s", hipGetErrorString(hipGetLastError())));
     *out = h;
     return NNPOPS_OK;
@@ -722,7 +724,7 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     if (!h) return NNPOPS_OK;
     DeviceGuard guard(h->device);
     dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_segment);
-    dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_status);
+    dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_cnt_pos); dev_free(h->d_status);
     dev_free(h->d_ids); dev_free(h->d_leg_force); dev_free(h->d_centre_force); dev_free(h->d_bucket_offsets);
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
@@ -832,7 +834,7 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
             KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
             const BuildInputs in{box, h->d_grid, h->d_cell_start, h->d_sorted_cell, h->d_sorted_pos, h->d_hist, positions, h->d_species,
                                  h->d_segment, use_cells ? 1 : 0, per ? 1 : 0};
-            const BuildOutputs out{h->d_nbr, h->d_recA, h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial};
+            const BuildOutputs out{h->d_nbr, h->d_recA, h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_cnt_pos, h->d_status, radial, h->ld_radial};
             rc = h->hp.torchani ? launch_build_forward<true>(h, in, out, angular, sp) : launch_build_forward<false>(h, in, out, angular, sp);
             if (rc != NNPOPS_OK) return rc;
             continue;
@@ -844,21 +846,21 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
             if (per)
                 hipLaunchKernelGGL(ani_neighbors_cells<true>, sgrid, ablock, lds_b, sp.stream, h->d_params, box, h->d_grid,
                                    h->d_cell_start, h->d_sorted_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                                   h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist,
+                                   h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_cnt_pos, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist,
                                    sp.w0, sp.nw);
             else
                 hipLaunchKernelGGL(ani_neighbors_cells<false>, sgrid, ablock, lds_b, sp.stream, h->d_params, box, h->d_grid,
                                    h->d_cell_start, h->d_sorted_cell, h->d_sorted_pos, h->d_nbr, h->cap, h->cap_angular, h->d_recA,
-                                   h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist,
+                                   h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_cnt_pos, h->d_status, radial, h->ld_radial, lds_bw, h->d_hist,
                                    sp.w0, sp.nw);
         } else if (per)
             hipLaunchKernelGGL(ani_neighbors_allpairs<true>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
                                h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                               h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
+                               h->d_cnt_a, h->d_cnt_ro, h->d_cnt_pos, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
         else
             hipLaunchKernelGGL(ani_neighbors_allpairs<false>, sgrid, ablock, lds_b, sp.stream, h->d_params, positions, box,
                                h->d_species, h->d_segment, h->d_nbr, h->cap, h->cap_angular, h->d_recA, h->d_recB, h->d_ids, h->d_tri,
-                               h->d_cnt_a, h->d_cnt_ro, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
+                               h->d_cnt_a, h->d_cnt_ro, h->d_cnt_pos, h->d_status, radial, h->ld_radial, lds_bw, sp.w0, sp.nw);
         }
         NNPOPS_HIP_TRY(hipGetLastError());
         // (the radial AEV is written by the builder wave itself: radial_forward_from_lds)
@@ -933,11 +935,11 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
                 default: k = wide ? ani_radial_backward_lanes<8, 64> : ani_radial_backward_lanes<8, 32>; break;
             }
             hipLaunchKernelGGL(k, dim3(div_up(sp.nw, wpg)), dim3(64 * wpg), (size_t)lw * wpg, sp.stream, h->d_params, h->d_species, h->d_nbr,
-                               h->cap, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
+                               h->cap, h->d_cnt_pos, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
                                sp.order, position_deriv, lw, sp.w0, sp.nw);
         } else
         hipLaunchKernelGGL(ani_radial_backward, dim3(div_up(sp.nw, wpg_r)), ablock, lds_r, sp.stream, h->d_params, h->d_species, h->d_nbr, h->cap,
-                           h->cap_angular, h->d_cnt_a, h->d_cnt_ro, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
+                           h->cap_angular, h->d_cnt_pos, radial_deriv, h->ld_radial, h->d_ids, h->d_leg_force, h->d_centre_force,
                            sp.order, position_deriv, lds_rw, sp.w0, sp.nw);
     }
     rc = join_streams(h, spans, nspans);

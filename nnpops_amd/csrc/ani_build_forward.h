@@ -47,7 +47,7 @@ struct BuildInputs {
 struct BuildOutputs {
     float4* nbr;
     float4 *recA, *recB;
-    int *ids, *tri, *cnt_a, *cnt_ro, *status;
+    int *ids, *tri, *cnt_a, *cnt_ro, *cnt_pos, *status;      // (nbr rows and cnt_pos go by position: slot in cell order, or the atom index)
     float* radial;
     int ld_radial;
 };
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
             }
             if (lane == 0) {
                 out.cnt_a[i] = na; out.cnt_ro[i] = nro;
+                out.cnt_pos[slot_id] = min(na, 0xffff) | (min(nro, 0xffff) << 16);
                 shared[0] = na; shared[1] = nro;
                 if (na > capA || na + nro > cap) atomicOr(&out.status[kStatOverflow], 1);      // (ani_kernels.h: builders flag their own overflow)
                 else if (na > (int)P->class_tile[i]) atomicOr(&out.status[kStatOverflow], 8);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
         clamp_counts(na_raw, nro_raw, cap, capA, n, nro_c);
         if (!void_grid) {
             if (role == 1) {
-                flush_row(out.nbr + (size_t)i * cap, stage, cap, na_raw, nro_raw);
+                flush_row(out.nbr + (size_t)slot_id * cap, stage, cap, na_raw, nro_raw);
                 radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, out.radial + (size_t)i * out.ld_radial);
             } else {
                 finalize_angular(P, stage, n, out.recA + (size_t)i * capA, out.recB + (size_t)i * capA, out.ids + (size_t)i * capA, capA,

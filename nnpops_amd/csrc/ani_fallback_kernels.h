@@ -28,8 +28,7 @@ namespace nnpops {
 __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const AniParams* __restrict__ P,
                                                           const int* __restrict__ species,
                                                           const float4* __restrict__ nbr, int cap, int cap_angular,
-                                                          const int* __restrict__ cnt_a,
-                                                          const int* __restrict__ cnt_ro,
+                                                          const int* __restrict__ cnt_pos,   // rows and counts by position of the walk
                                                           const float* __restrict__ radial_grad, int ld_radial,
                                                           const int* __restrict__ ids,
                                                           const float4* __restrict__ leg_force,
@@ -58,9 +57,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
     int* nb_j = nb_sp + cap;
 
     int na, nro;
-    clamp_counts(cnt_a[i], cnt_ro[i], cap, cap_angular, na, nro);
+    const int counts = cnt_pos[w];
+    clamp_counts(counts & 0xffff, counts >> 16, cap, cap_angular, na, nro);
     const int total = na + nro;
-    const float4* row = nbr + (size_t)i * cap;
+    const float4* row = nbr + (size_t)w * cap;
     const float inv_rcr = P->inv_rcr;
     const int si = species[i];
 

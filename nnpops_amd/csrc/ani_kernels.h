@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
                                                              int cap, int capA, float4* __restrict__ recA,
                                                              float4* __restrict__ recB, int* __restrict__ ids,
                                                              int* __restrict__ tri,
-                                                             int* __restrict__ cnt_a, int* __restrict__ cnt_ro, int* __restrict__ status,
+                                                             int* __restrict__ cnt_a, int* __restrict__ cnt_ro, int* __restrict__ cnt_pos, int* __restrict__ status,
                                                              float* __restrict__ radial, int ld_radial, int lds_per_wave, int w0, int nw) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     float4* stage = (float4*)(lds_raw + (size_t)wave_in_group() * lds_per_wave);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     Box b{};
     if (PERIODIC) b = load_box(box);
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-    float4* row = nbr + (size_t)i * cap;
+    float4* row = nbr + (size_t)i * cap;                  // (rows and cnt_pos go by POSITION in the walk of the radial backward: here the atom index)
     // batched molecules: an atom only sees the atoms of its own molecule (independent systems in one handle)
     const int lo = segment ? segment[i].x : 0, hi = segment ? segment[i].y : N;
     int na = 0, nro = 0;
@@ -479,6 +479,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     }
     if (lane == 0) {
         cnt_a[i] = na; cnt_ro[i] = nro;
+        cnt_pos[i] = min(na, 0xffff) | (min(nro, 0xffff) << 16);
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
                                                           int cap, int capA, float4* __restrict__ recA,
                                                           float4* __restrict__ recB, int* __restrict__ ids,
                                                           int* __restrict__ tri,
-                                                          int* __restrict__ cnt_a, int* __restrict__ cnt_ro,
+                                                          int* __restrict__ cnt_a, int* __restrict__ cnt_ro, int* __restrict__ cnt_pos,
                                                           int* __restrict__ status, float* __restrict__ radial,
                                                           int ld_radial, int lds_per_wave, int* __restrict__ cell_hist, int slot0, int nslots) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
             if (slot_id == 0) atomicOr(&status[kStatOverflow], g.bin_overflow ? 6 : 2);   // 4: grow the cell bins
             cnt_a[slot_id] = 0;                            // keep the consumers of this (void) build harmless
             cnt_ro[slot_id] = 0;
+            cnt_pos[slot_id] = 0;
         }
         return;
     }
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     const int i = __float_as_int(me.w) & kIdMask;
     int cx, cy, cz;
     split_cell(g, c, cx, cy, cz);                          // (no integer division; exact: celllist.h)
-    float4* row = nbr + (size_t)i * cap;
+    float4* row = nbr + (size_t)slot_id * cap;            // (by position in cell order: the radial backward walks the same order and needs no atom id to find it)
     int na = 0, nro = 0;
     const WideStencil st = gather_wide_stencil(g, cell_start, cx, cy, cz);
     int* strip = (int*)rscratch;                           // the radial scratch is idle during the scan
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     }
     if (lane == 0) {
         cnt_a[i] = na; cnt_ro[i] = nro;
+        cnt_pos[slot_id] = min(na, 0xffff) | (min(nro, 0xffff) << 16);
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);

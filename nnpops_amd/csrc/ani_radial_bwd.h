@@ -23,7 +23,7 @@ namespace nnpops {
 template <int NR4, int CAPA>
 __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_lanes(
     const AniParams* __restrict__ P, const int* __restrict__ species, const float4* __restrict__ nbr, int cap,
-    const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro, const float* __restrict__ radial_grad, int ld_radial,
+    const int* __restrict__ cnt_pos, const float* __restrict__ radial_grad, int ld_radial,
     const int* __restrict__ ids, const float4* __restrict__ leg_force, const float4* __restrict__ centre_force,
     const int* __restrict__ order,     // atoms in cell order, or NULL
     float* __restrict__ pos_grad, int lds_per_wave, int w0, int nw) {
@@ -35,13 +35,16 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_la
     const int wl = order ? xcd_contiguous_wave_id() : wave_global_id();      // this launch covers positions [w0, w0 + nw)
     if (wl >= nw) return;
     const int w = w0 + wl;
+    // Rows and counts are stored by POSITION in this walk (the builders' slot in cell order, or the atom index): the row, its counts
+    // and the atom's id come back in ONE round trip -- the kernel is a chain of four dependent ones otherwise.
+    const float4* row = nbr + (size_t)w * cap;
+    const float4 first = row[min(lane, cap - 1)];          // rows are contiguous (flush_row): requested before the counts are known
+    const int counts = cnt_pos[w];
     int i = order ? order[w] : w;
     if ((unsigned)i >= (unsigned)P->N) i = w;              // (a void grid build leaves no valid order: stay in bounds)
     const int width = P->S * NR;
-    const float4* row = nbr + (size_t)i * cap;
-    const float4 first = row[min(lane, cap - 1)];          // rows are contiguous (flush_row): requested before the counts are known
     int na, nro;
-    clamp_counts(cnt_a[i], cnt_ro[i], cap, CAPA, na, nro);
+    clamp_counts(counts & 0xffff, counts >> 16, cap, CAPA, na, nro);
     const int total = na + nro;
     const float inv_rcr = P->inv_rcr;
     const int col = species[i] * NR;                       // where this atom's species sits in a neighbour's row
