@@ -209,12 +209,7 @@ __global__ __launch_bounds__(1024) void scan_half(int N, const int* __restrict__
     if (threadIdx.x == 0) half_off[N] = carry;
 }
 
-// Looking i up in the rows of its lower-index neighbours: kMirrorBatch rows' ids in flight at a time (unconditional,
-// straight-line loads -- behind a branch per row the compiler waits for each before issuing the next), then two
-// ballots per row.  The kernel is bound by its chain of dependent first-touch loads (the rows were written by another
-// XCD a kernel ago), not by bytes or instructions: measured 33 us for 10 000 atoms against 10 us without the lookups.
-constexpr int kMirrorBatch = 8;
-
+// (the reverse lookup of a pair is described where it happens, below)
 __global__ __launch_bounds__(64) void half_slots(const float4* __restrict__ rows, const int* __restrict__ row_ids,
                                                  const int* __restrict__ cnt, const int* __restrict__ half_off, int cap,
                                                  int pair_cap, int* __restrict__ pid, float* __restrict__ half_r,
@@ -250,46 +245,34 @@ __global__ __launch_bounds__(64) void half_slots(const float4* __restrict__ rows
             }
         }
         lo_before += __popcll(lm);
-        // entries towards a lower index j: slot = first slot of row j + rank of i among j's higher-index neighbours
-        unsigned long long um = __ballot(s < n && !lower);
-        const int my_col = min(lane, cap - 1);
-        while (um) {
-            int src[kMirrorBatch], jj[kMirrorBatch], nj[kMirrorBatch], idt[kMirrorBatch], first_j[kMirrorBatch];
+        // entries towards a lower index j: slot = first slot of row j + rank of i among j's higher-index neighbours.  Every such lane
+        // looks its own pair up: the whole id row of j (64 ids per pass) is requested at once, sixteen 16-byte loads per lane with
+        // nothing between them, so all lookups of the atom cost ONE round trip to memory -- taking the rows eight at a time with the
+        // wave scanning each one together (rounds 1-3) was four dependent round trips for the ~26 lower neighbours of an atom, and
+        // this kernel is nothing but its chain of dependent first-touch loads (33 us for 10 000 atoms against 10 us without lookups).
+        if (s < n && !lower) {
+            const int nj = min(cnt[j], cap), fj = half_off[j];
+            const int4* rid = reinterpret_cast<const int4*>(row_ids + (size_t)j * cap);      // (cap is a multiple of 4)
+            const int pieces = cap >> 2;
+            bool hit = false;
+            int rank = 0;
+            for (int t0 = 0; t0 < nj && !hit; t0 += 64) {
+                int4 v[16];
 #pragma unroll
-            for (int k = 0; k < kMirrorBatch; k++) {
-                src[k] = um ? __ffsll((long long)um) - 1 : -1;
-                um &= um - 1;                                   // (0 stays 0; an unused slot re-reads lane 0's neighbour)
-                jj[k] = __shfl(j, max(src[k], 0), 64);
-            }
+                for (int q = 0; q < 16; q++) v[q] = rid[min((t0 >> 2) + q, pieces - 1)];
 #pragma unroll
-            for (int k = 0; k < kMirrorBatch; k++) {
-                nj[k] = cnt[jj[k]];
-                first_j[k] = half_off[jj[k]];
-                idt[k] = row_ids[(size_t)jj[k] * cap + my_col];
-            }
+                for (int q = 0; q < 16; q++) {
+                    const int id4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
-            for (int k = 0; k < kMirrorBatch; k++) {
-                nj[k] = min(nj[k], cap);
-                // where is i in row jj, and how many higher-index neighbours precede it there (= its rank among jj's slots)
-                bool valid = lane < nj[k];
-                unsigned long long hit = __ballot(valid && idt[k] == i);
-                unsigned long long lowj = __ballot(valid && idt[k] > jj[k]);
-                int lows = 0;
-                for (int t0 = 64; t0 < nj[k] && !hit; t0 += 64) {          // rows longer than a wave (cap > 64): rare
-                    lows += __popcll(lowj);
-                    const int t = t0 + lane;
-                    valid = t < nj[k];
-                    const int id = valid ? row_ids[(size_t)jj[k] * cap + t] : -1;
-                    hit = __ballot(valid && id == i);
-                    lowj = __ballot(valid && id > jj[k]);
-                }
-                const unsigned long long below = (hit & (0ull - hit)) - 1ull;   // the lanes before the first hit
-                const int found = lows + __popcll(lowj & below);
-                if (lane == src[k]) {                           // (an unused slot has src = -1)
-                    my_pid = hit ? min(first_j[k] + found, pair_cap) : pair_cap;
-                    unmatched += hit ? 0 : 1;
+                    for (int c = 0; c < 4; c++) {
+                        const bool open = !hit && t0 + 4 * q + c < nj;          // (before the hit, inside the row)
+                        hit = hit || (open && id4[c] == i);
+                        rank += (open && id4[c] != i && id4[c] > j) ? 1 : 0;
+                    }
                 }
             }
+            my_pid = hit ? min(fj + rank, pair_cap) : pair_cap;
+            unmatched += hit ? 0 : 1;
         }
         if (s < n) pid[(size_t)i * cap + s] = my_pid;
         if (unmatched) atomicAdd(&status[kStUnmatched], 1);
