@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void rows_allpairs(int N, const float* __restri
 template <bool PERIODIC>
 __global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, float cutoff2,
                                                  const CellGrid* __restrict__ grid, const int* __restrict__ cell_start,
-                                                 const int* __restrict__ atom_cell, const float4* __restrict__ sorted_pos,
+                                                 const int* __restrict__ sorted_cell, const float4* __restrict__ sorted_pos,
                                                  float4* __restrict__ rows, int* __restrict__ ids, int cap, int* __restrict__ cnt,
                                                  int* __restrict__ lo_cnt, int* __restrict__ status,
                                                  int* __restrict__ cell_hist) {
@@ -113,32 +113,39 @@ __global__ __launch_bounds__(64) void rows_cells(const float* __restrict__ box, 
     if (PERIODIC) b = load_box(box);
     const float4 me = sorted_pos[blockIdx.x];
     const int i = __float_as_int(me.w) & kIdMask;
-    const int c = atom_cell[i];
+    const int c = sorted_cell[blockIdx.x];                  // (in sorted order, next to the position: no load that waits for the id)
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
     float4* row = rows + (size_t)i * cap;
     int n = 0, n_lo = 0;
-    // the 27-cell stencil as one flat candidate space (celllist.h): full iterations, next batch's load in flight
+    // the 27-cell stencil as one flat candidate space (celllist.h): full iterations, FOUR batches of candidates requested at a
+    // time -- this wave's time is the sum of its dependent round trips to memory (~380 candidates: six batches, one after the
+    // other with one load ahead, were five trips; now two)
     const Stencil st = gather_stencil(g, cell_start, cx, cy, cz);
     const int last = max(st.total - 1, 0);
-    float4 pj = sorted_pos[stencil_slot(st, min(lane, last))];
-    for (int base = 0; base < st.total; base += 64) {
-        const int k = base + lane;
-        const float4 cur = pj;
-        const int next_slot = stencil_slot(st, min(k + 64, last));              // (every lane: ds_bpermute inside)
-        if (base + 64 < st.total) pj = sorted_pos[next_slot];
-        bool keep = false;
-        int j = -1;
-        float dx = 0.f, dy = 0.f, dz = 0.f;
-        if (k < st.total) {
-            j = __float_as_int(cur.w) & kIdMask;
-            if (j != i) {
-                dx = cur.x - me.x; dy = cur.y - me.y; dz = cur.z - me.z;
-                min_image<PERIODIC>(dx, dy, dz, b);
-                keep = dx * dx + dy * dy + dz * dz < cutoff2;
+    constexpr int GROUP = 4;
+    for (int base = 0; base < st.total; base += 64 * GROUP) {
+        float4 pj[GROUP];
+#pragma unroll
+        for (int q = 0; q < GROUP; q++) pj[q] = sorted_pos[stencil_slot(st, min(base + 64 * q + lane, last))];   // (every lane: ds_bpermute inside)
+#pragma unroll
+        for (int q = 0; q < GROUP; q++) {
+            if (base + 64 * q >= st.total) break;               // wave-uniform
+            const int k = base + 64 * q + lane;
+            const float4 cur = pj[q];
+            bool keep = false;
+            int j = -1;
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (k < st.total) {
+                j = __float_as_int(cur.w) & kIdMask;
+                if (j != i) {
+                    dx = cur.x - me.x; dy = cur.y - me.y; dz = cur.z - me.z;
+                    min_image<PERIODIC>(dx, dy, dz, b);
+                    keep = dx * dx + dy * dy + dz * dz < cutoff2;
+                }
             }
+            append(row, ids + (size_t)i * cap, cap, keep, dx, dy, dz, j, n);
+            n_lo += __popcll(__ballot(keep && j > i));
         }
-        append(row, ids + (size_t)i * cap, cap, keep, dx, dy, dz, j, n);
-        n_lo += __popcll(__ballot(keep && j > i));
     }
     if (lane == 0) publish_row(i, n, n_lo, cnt, lo_cnt);
 }
@@ -1529,6 +1536,7 @@ struct nnpops_cfconv_neighbors {
     // cell grid
     CellGrid* d_grid = nullptr;
     int *d_cell_count = nullptr, *d_cell_start = nullptr, *d_atom_cell = nullptr, *d_atom_rank = nullptr;
+    int* d_sorted_cell = nullptr;   // [N] cell of the atom in every sorted slot (rows_cells reads it with the slot's position)
     int *d_unsorted = nullptr, *d_sorted = nullptr;
     float4* d_sorted_pos = nullptr;
     int max_cells = 0;
@@ -1629,6 +1637,7 @@ int nnpops_cfconv_neighbors_create(nnpops_cfconv_neighbors_t* out, int num_atoms
     if ((rc = alloc_half(h))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_atom_cell, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_atom_rank, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_sorted_cell, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_unsorted, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_sorted_pos, (size_t)num_atoms))) return cleanup(rc);
@@ -1645,7 +1654,7 @@ int nnpops_cfconv_neighbors_destroy(nnpops_cfconv_neighbors_t h) {
     dev_free(h->d_hist); dev_free(h->d_bins);
     dev_free(h->d_lo_cnt); dev_free(h->d_half_off); dev_free(h->d_pid); dev_free(h->d_half_r); dev_free(h->d_half_ij); dev_free(h->d_ids);
     dev_free(h->d_grid); dev_free(h->d_cell_count); dev_free(h->d_cell_start); dev_free(h->d_atom_cell);
-    dev_free(h->d_atom_rank); dev_free(h->d_unsorted); dev_free(h->d_sorted); dev_free(h->d_sorted_pos);
+    dev_free(h->d_atom_rank); dev_free(h->d_sorted_cell); dev_free(h->d_unsorted); dev_free(h->d_sorted); dev_free(h->d_sorted_pos);
     delete h;
     return NNPOPS_OK;
 }
@@ -1667,15 +1676,16 @@ int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t h, const float* posi
     // status words are cleared by create() and by check() after it has read them, not per build
     const bool use_cells = N >= 1024 && !h->cells_disabled;
     if (use_cells) {
-        const CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank, h->d_unsorted,
-                             h->d_sorted, h->d_sorted_pos, h->max_cells, h->d_hist, h->d_bins, h->bin_cap};
+        CellBuffers cb{h->d_grid, h->d_cell_count, h->d_cell_start, h->d_atom_cell, h->d_atom_rank, h->d_unsorted,
+                       h->d_sorted, h->d_sorted_pos, h->max_cells, h->d_hist, h->d_bins, h->bin_cap};
+        cb.sorted_cell = h->d_sorted_cell;
         launch_cell_build(h->stream, N, positions, box, per, h->cutoff, nullptr, cb);
         if (per)
             hipLaunchKernelGGL(rows_cells<true>, dim3(N), dim3(64), 0, h->stream, box, c2, h->d_grid, h->d_cell_start,
-                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->d_ids, h->cap, h->d_cnt, h->d_lo_cnt, h->d_status, h->d_hist);
+                               h->d_sorted_cell, h->d_sorted_pos, h->d_rows, h->d_ids, h->cap, h->d_cnt, h->d_lo_cnt, h->d_status, h->d_hist);
         else
             hipLaunchKernelGGL(rows_cells<false>, dim3(N), dim3(64), 0, h->stream, box, c2, h->d_grid, h->d_cell_start,
-                               h->d_atom_cell, h->d_sorted_pos, h->d_rows, h->d_ids, h->cap, h->d_cnt, h->d_lo_cnt, h->d_status, h->d_hist);
+                               h->d_sorted_cell, h->d_sorted_pos, h->d_rows, h->d_ids, h->cap, h->d_cnt, h->d_lo_cnt, h->d_status, h->d_hist);
     } else if (per) {
         hipLaunchKernelGGL(rows_allpairs<true>, dim3(N), dim3(64), 0, h->stream, N, positions, box, c2, h->d_rows, h->d_ids, h->cap, h->d_cnt, h->d_lo_cnt);
     } else {
