@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_la
     const int col = species[i] * NR;                       // where this atom's species sits in a neighbour's row
 
     const float* gi = radial_grad + (size_t)i * ld_radial;
+    const float4 centre = centre_force[i];                 // (requested here, not behind the wave sum at the end: one round trip less)
     for (int q = lane; q < width; q += 64) g_own[q] = gi[q];
     wave_fence();
 
@@ -60,11 +61,43 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_la
         float4 rec = base == 0 ? first : row[min(e, cap - 1)];
         if (!live) rec = make_float4(1.f, 0.f, 0.f, __int_as_float(i));
         const int word = __float_as_int(rec.w), j = word & kIdMask;
-        // everything that depends on the neighbour's id, in flight together
+        // everything that depends on the neighbour's id, in flight together: its gradient row, and (first pass: the angular
+        // neighbours are the first na <= CAPA <= 64 of the row) the pieces of the id rows for the reverse lookup of the angular
+        // legs -- lane l scans piece (l % QL) of the id rows of angular neighbours l / QL + RPP t, one 16-byte load per lane and t,
+        // four t in flight; whoever finds this atom in a neighbour's id row (rows are padded with -1) requests that leg, and the
+        // radial arithmetic below runs while the legs are on their way (the partial forces meet in the wave sum): the kernel is a
+        // chain of dependent round trips, and this order makes it row -> {gradient rows, id rows} -> legs with the arithmetic inside
+        // the last one, where it was row -> gradient rows -> arithmetic -> id rows -> legs.
         const float4* grow = reinterpret_cast<const float4*>(radial_grad + (size_t)j * ld_radial + col);
         float4 gj[NR4];
 #pragma unroll
         for (int c = 0; c < NR4; c++) gj[c] = grow[c];
+        float4 leg[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) leg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (id rows of 64 slots keep the old order -- lookups behind the arithmetic: early they cost 34 spilled registers)
+        constexpr bool EARLY = CAPA == 32;
+        const bool look = base == 0 && na > 0;
+        if (EARLY && look) {
+            int4 idv[4];
+            int jt[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int et = lane / QL + RPP * t;
+                jt[t] = __shfl(j, et & 63, 64);
+                idv[t] = make_int4(-1, -1, -1, -1);
+                if (t < NT && et < na) idv[t] = reinterpret_cast<const int4*>(ids + (size_t)jt[t] * CAPA)[lane % QL];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                int slot = -1;
+                slot = idv[t].x == i ? 0 : slot;
+                slot = idv[t].y == i ? 1 : slot;
+                slot = idv[t].z == i ? 2 : slot;
+                slot = idv[t].w == i ? 3 : slot;
+                if (slot >= 0) leg[t] = leg_force[(size_t)jt[t] * CAPA + 4 * (lane % QL) + slot];
+            }
+        }
         const float r = fast_sqrt(rec.x * rec.x + rec.y * rec.y + rec.z * rec.z);
         const float rinv = fast_rcp(r);
         float sn, cs;
@@ -86,12 +119,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_la
         }
         s = live ? s * P->radial_scale * rinv : 0.f;
         fx -= s * rec.x; fy -= s * rec.y; fz -= s * rec.z;
-        // Reverse lookup of the angular legs, all lanes together: lane l scans piece (l % QL) of the id rows of angular
-        // neighbours l / QL + RPP t -- one 16-byte load per lane and t, four t in flight; whoever finds this atom in a
-        // neighbour's id row (rows are padded with -1) fetches that leg (the partial forces meet in the wave sum).
-        // (Requesting the id rows together with the gradient rows costs 16 more registers and measured the same.)
-        if (base == 0) {                                       // angular neighbours are the first na <= CAPA <= 64 of the row
-            for (int t0 = 0; t0 < NT && t0 * RPP < na; t0 += 4) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) { fx += leg[t].x; fy += leg[t].y; fz += leg[t].z; }
+        if (look) {                                            // id rows of more than four passes (CAPA = 64 with many angular neighbours)
+            for (int t0 = EARLY ? 4 : 0; t0 < NT && t0 * RPP < na; t0 += 4) {
                 int4 idv[4];
                 int jt[4];
 #pragma unroll
@@ -118,10 +149,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_la
     }
     fx = wave_sum_lane63(fx); fy = wave_sum_lane63(fy); fz = wave_sum_lane63(fz);
     if (lane == 63) {
-        if (na >= 2) {
-            const float4 c = centre_force[i];
-            fx += c.x; fy += c.y; fz += c.z;
-        }
+        if (na >= 2) { fx += centre.x; fy += centre.y; fz += centre.z; }
         pos_grad[3 * i] = fx;
         pos_grad[3 * i + 1] = fy;
         pos_grad[3 * i + 2] = fz;
