@@ -20,6 +20,7 @@
 
 using namespace nnpops;
 
+constexpr int kRbwdLatencyAtoms = 4096;  // up to this many atoms the radial backward runs its latency variant (ani_radial_bwd.h: LAT)
 constexpr int kFuseAtoms = 4096;       // systems of up to this many atoms build and run the angular forward in one workgroup (ani_build_forward.h)
 struct nnpops_ani {
     AniParams hp{};                 // host copy of the parameter block
@@ -924,6 +925,8 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
             const int wpg = kWavesPerGroup;
             const bool wide = h->cap_angular == 64;
             auto k = ani_radial_backward_lanes<4, 32>;
+            if (nr4 == 4 && sp.nw <= kRbwdLatencyAtoms) k = wide ? ani_radial_backward_lanes<4, 64, true> : ani_radial_backward_lanes<4, 32, true>;
+            else
             switch (nr4) {
                 case 1: k = wide ? ani_radial_backward_lanes<1, 64> : ani_radial_backward_lanes<1, 32>; break;
                 case 2: k = wide ? ani_radial_backward_lanes<2, 64> : ani_radial_backward_lanes<2, 32>; break;

@@ -20,8 +20,10 @@
 
 namespace nnpops {
 
-template <int NR4, int CAPA>
-__global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_lanes(
+// LAT: systems that fit the chip in one round of waves (a molecule, a small box): registers are free, so every piece of the id
+// rows is requested at once and early -- the wave's time is its chain of dependent round trips, nothing else.
+template <int NR4, int CAPA, bool LAT = false>
+__global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_backward_lanes(
     const AniParams* __restrict__ P, const int* __restrict__ species, const float4* __restrict__ nbr, int cap,
     const int* __restrict__ cnt_pos, const float* __restrict__ radial_grad, int ld_radial,
     const int* __restrict__ ids, const float4* __restrict__ leg_force, const float4* __restrict__ centre_force,
@@ -71,24 +73,26 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_la
         float4 gj[NR4];
 #pragma unroll
         for (int c = 0; c < NR4; c++) gj[c] = grow[c];
-        float4 leg[4];
+        // (id rows of 64 slots keep the old order -- lookups behind the arithmetic: early they cost 34 spilled registers -- unless
+        //  registers are free, LAT)
+        constexpr bool EARLY = CAPA == 32 || LAT;
+        constexpr int IF = LAT ? (NT < 16 ? NT : 16) : 4;     // pieces in flight per lane in the early round
+        float4 leg[IF];
 #pragma unroll
-        for (int t = 0; t < 4; t++) leg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // (id rows of 64 slots keep the old order -- lookups behind the arithmetic: early they cost 34 spilled registers)
-        constexpr bool EARLY = CAPA == 32;
+        for (int t = 0; t < IF; t++) leg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool look = base == 0 && na > 0;
         if (EARLY && look) {
-            int4 idv[4];
-            int jt[4];
+            int4 idv[IF];
+            int jt[IF];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < IF; t++) {
                 const int et = lane / QL + RPP * t;
                 jt[t] = __shfl(j, et & 63, 64);
                 idv[t] = make_int4(-1, -1, -1, -1);
                 if (t < NT && et < na) idv[t] = reinterpret_cast<const int4*>(ids + (size_t)jt[t] * CAPA)[lane % QL];
             }
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < IF; t++) {
                 int slot = -1;
                 slot = idv[t].x == i ? 0 : slot;
                 slot = idv[t].y == i ? 1 : slot;
@@ -119,9 +123,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void ani_radial_backward_la
         s = live ? s * P->radial_scale * rinv : 0.f;
         fx -= s * rec.x; fy -= s * rec.y; fz -= s * rec.z;
 #pragma unroll
-        for (int t = 0; t < 4; t++) { fx += leg[t].x; fy += leg[t].y; fz += leg[t].z; }
+        for (int t = 0; t < IF; t++) { fx += leg[t].x; fy += leg[t].y; fz += leg[t].z; }
         if (look) {                                            // id rows of more than four passes (CAPA = 64 with many angular neighbours)
-            for (int t0 = EARLY ? 4 : 0; t0 < NT && t0 * RPP < na; t0 += 4) {
+            for (int t0 = EARLY ? IF : 0; t0 < NT && t0 * RPP < na; t0 += 4) {
                 int4 idv[4];
                 int jt[4];
 #pragma unroll
