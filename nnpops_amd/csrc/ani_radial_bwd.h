@@ -52,6 +52,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_b
     const int col = species[i] * NR;                       // where this atom's species sits in a neighbour's row
 
     const float* gi = radial_grad + (size_t)i * ld_radial;
+    // (the centre force through the SCALAR cache, requested here: no vector register -- the 65th would cost a wave per SIMD -- and
+    //  no round trip behind the wave sum at the end)
+    const float4 centre = centre_force[__builtin_amdgcn_readfirstlane(i)];
     for (int q = lane; q < width; q += 64) g_own[q] = gi[q];
     wave_fence();
 
@@ -152,10 +155,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_b
     }
     fx = wave_sum_lane63(fx); fy = wave_sum_lane63(fy); fz = wave_sum_lane63(fz);
     if (lane == 63) {
-        if (na >= 2) {
-            const float4 c = centre_force[i];              // (requested up front, with the gradient row, it costs a register the 64 of
-            fx += c.x; fy += c.y; fz += c.z;                //  eight waves per SIMD do not have: 9.8 -> 10.4 us)
-        }
+        if (na >= 2) { fx += centre.x; fy += centre.y; fz += centre.z; }
         pos_grad[3 * i] = fx;
         pos_grad[3 * i + 1] = fy;
         pos_grad[3 * i + 2] = fz;
