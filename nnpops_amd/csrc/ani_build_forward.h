@@ -139,7 +139,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
             }
             if (lane == 0) {
                 out.cnt_a[i] = na; out.cnt_ro[i] = nro;
-                out.cnt_pos[slot_id] = min(na, 0xffff) | (min(nro, 0xffff) << 16);
+                out.cnt_pos[slot_id] = pack_cnt_pos(na, nro, in.use_cells ? (__float_as_int(me.w) >> kTagShift) : in.species[i]);
                 shared[0] = na; shared[1] = nro;
                 if (na > capA || na + nro > cap) atomicOr(&out.status[kStatOverflow], 1);      // (ani_kernels.h: builders flag their own overflow)
                 else if (na > (int)P->class_tile[i]) atomicOr(&out.status[kStatOverflow], 8);

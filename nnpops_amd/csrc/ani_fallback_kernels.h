@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_radial_backward(const
 
     int na, nro;
     const int counts = cnt_pos[w];
-    clamp_counts(counts & 0xffff, counts >> 16, cap, cap_angular, na, nro);
+    int raw_a, raw_ro, packed_species;
+    unpack_cnt_pos(counts, raw_a, raw_ro, packed_species);
+    clamp_counts(raw_a, raw_ro, cap, cap_angular, na, nro);
     const int total = na + nro;
     const float4* row = nbr + (size_t)w * cap;
     const float inv_rcr = P->inv_rcr;

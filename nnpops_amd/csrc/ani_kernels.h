@@ -179,6 +179,12 @@ static __global__ __launch_bounds__(256) void ani_row_stats(int N, const int* __
 // Clamp the per-atom counts so that nobody indexes outside a row even after an overflow (results of
 // an overflowed compute are garbage and reported through nnpops_ani_check).  Builders and consumers
 // use the same clamp.
+// cnt_pos word of an atom (by position of the radial backward's walk): angular count (9 bits), species (7), radial-only count (16)
+__device__ __forceinline__ int pack_cnt_pos(int na, int nro, int species) { return min(na, 0x1ff) | ((species & 0x7f) << 9) | (min(nro, 0xffff) << 16); }
+__device__ __forceinline__ void unpack_cnt_pos(int word, int& na, int& nro, int& species) {
+    na = word & 0x1ff; species = (word >> 9) & 0x7f; nro = (int)((unsigned)word >> 16);
+}
+
 __device__ __forceinline__ void clamp_counts(int raw_a, int raw_ro, int cap, int cap_angular, int& na, int& nro) {
     na = max(0, min(raw_a, min(cap, cap_angular)));
     nro = max(0, min(raw_ro, cap - na));
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     }
     if (lane == 0) {
         cnt_a[i] = na; cnt_ro[i] = nro;
-        cnt_pos[i] = min(na, 0xffff) | (min(nro, 0xffff) << 16);
+        cnt_pos[i] = pack_cnt_pos(na, nro, species[i]);
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     }
     if (lane == 0) {
         cnt_a[i] = na; cnt_ro[i] = nro;
-        cnt_pos[slot_id] = min(na, 0xffff) | (min(nro, 0xffff) << 16);
+        cnt_pos[slot_id] = pack_cnt_pos(na, nro, __float_as_int(me.w) >> kTagShift);
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);

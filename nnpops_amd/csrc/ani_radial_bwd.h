@@ -46,10 +46,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_b
     if ((unsigned)i >= (unsigned)P->N) i = w;              // (a void grid build leaves no valid order: stay in bounds)
     const int width = P->S * NR;
     int na, nro;
-    clamp_counts(counts & 0xffff, counts >> 16, cap, CAPA, na, nro);
+    int raw_a, raw_ro, my_species;                         // (the species rides in the same word: the neighbours' gradient rows are
+    unpack_cnt_pos(counts, raw_a, raw_ro, my_species);     //  addressed with it, and species[i] would be one more dependent round trip)
+    clamp_counts(raw_a, raw_ro, cap, CAPA, na, nro);
     const int total = na + nro;
     const float inv_rcr = P->inv_rcr;
-    const int col = species[i] * NR;                       // where this atom's species sits in a neighbour's row
+    const int col = my_species * NR;                       // where this atom's species sits in a neighbour's row
 
     const float* gi = radial_grad + (size_t)i * ld_radial;
     // (the centre force through the SCALAR cache, requested here: no vector register -- the 65th would cost a wave per SIMD -- and
