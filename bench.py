@@ -479,7 +479,11 @@ def run_aev(args, R):
     if calibrated:
         o_fwd = min(max(raw["neighbors"] + raw["angular_forward"] - mrg["neighbors"], 0.0), event_overhead)
         o_bwd = min(max(raw["angular_backward"] + raw["radial_backward"] - mrg["angular_backward"], 0.0), event_overhead)
-        overhead = {"neighbors": o_fwd, "angular_forward": o_fwd, "angular_backward": o_bwd, "radial_backward": o_bwd}
+        # (what a bracket adds is a property of the event mechanism, not of the pair of kernels it was measured on: the two estimates
+        #  are pooled -- the larger one, the forward pair's comes out low whenever its merged bracket caught a slow step -- and used for
+        #  all four brackets)
+        o_all = max(o_fwd, o_bwd)
+        overhead = {"neighbors": o_all, "angular_forward": o_all, "angular_backward": o_all, "radial_backward": o_all}
         kern = {k: 0.0 for k in kern_all}
         for k in ROOFLINE_KERNELS:
             kern[k] = max(raw[k] - overhead[k], 1e-9)
