@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_b
     const int lane = lane_id();
     const int wl = order ? xcd_contiguous_wave_id() : wave_global_id();      // this launch covers positions [w0, w0 + nw)
     if (wl >= nw) return;
-    const int w = w0 + wl;
+    const int w = __builtin_amdgcn_readfirstlane(w0 + wl);         // (wave-uniform: counts and atom id through the scalar cache)
     // Rows and counts are stored by POSITION in this walk (the builders' slot in cell order, or the atom index): the row, its counts
     // and the atom's id come back in ONE round trip -- the kernel is a chain of four dependent ones otherwise.
     const float4* row = nbr + (size_t)w * cap;
