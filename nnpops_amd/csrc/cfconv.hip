@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void half_slots(const float4* __restrict__ rows
                                                  int2* __restrict__ half_ij, int* __restrict__ status, int N,
                                                  const float4* __restrict__ sorted_pos) {
     const int lane = lane_id();
-    const int k0 = xcd_contiguous_wave_id();               // atoms in cell order when there is one: the rows looked up are L2-hot
+    const int k0 = __builtin_amdgcn_readfirstlane(xcd_contiguous_wave_id());      // atoms in cell order when there is one: the rows looked up are L2-hot (wave-uniform: scalar loads)
     if (k0 >= N) return;
     const int i = sorted_pos ? __float_as_int(sorted_pos[k0].w) & kIdMask : k0;
     if (i >= N) return;
@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(256) void cfconv_gather(int N, int W, const float4*
     const int lane = lane_id();
     // atoms in cell order, an XCD taking a contiguous part of it: both ends of a pair then read its filter row through
     // the same L2, close in time
-    const int k = xcd_contiguous_wave_id();
+    const int k = __builtin_amdgcn_readfirstlane(xcd_contiguous_wave_id());      // (wave-uniform: the atom's id and count through the scalar cache)
     if (k >= N) return;
     const int i = sorted_pos ? __float_as_int(sorted_pos[k].w) & kIdMask : k;
     if (i >= N) return;                                     // (a grid that could not be built: check() reports it)
