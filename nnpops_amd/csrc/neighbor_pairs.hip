@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void pairs_cells_stage(int N, const T* __restr
                                                          const int* __restrict__ sorted_atom, const float4* __restrict__ sorted_pos,
                                                          int* __restrict__ st_col, Staged<T>* __restrict__ st_rec,
                                                          int* __restrict__ row_count, int* __restrict__ ticket) {
-    const int row = wave_global_id();
+    const int row = __builtin_amdgcn_readfirstlane(wave_global_id());      // (wave-uniform: the row header through the scalar cache)
     if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;                  // the scan's ticket counter (workspace is not zeroed)
     if (row >= N) return;
     const CellGrid g = *grid;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void pairs_cells_emit(int N, const T* __restri
             distances[k] = nan;
         }
     }
-    const int row = wave_global_id();
+    const int row = __builtin_amdgcn_readfirstlane(wave_global_id());      // (wave-uniform: the row header through the scalar cache)
     if (row >= N) return;
     const int lane = lane_id();
     const int n = row_count[row];
