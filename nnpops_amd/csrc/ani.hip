@@ -20,7 +20,7 @@
 
 using namespace nnpops;
 
-constexpr int kRbwdLatencyAtoms = 4096;  // up to this many atoms the radial backward runs its latency variant (ani_radial_bwd.h: LAT)
+constexpr int kRbwdLatencyAtoms = 8192;  // up to this many atoms the radial backward runs its latency variant (ani_radial_bwd.h: LAT)
 constexpr int kFuseAtoms = 4096;       // systems of up to this many atoms build and run the angular forward in one workgroup (ani_build_forward.h)
 struct nnpops_ani {
     AniParams hp{};                 // host copy of the parameter block
