@@ -246,6 +246,20 @@ class AniSymmetryFunctions:
         _check(self._lib.nnpops_ani_describe(self._h, buf, 512))
         return dict(word.split("=", 1) for word in buf.value.decode().split())
 
+    def overflow_word(self):
+        """The builders' sticky overflow word (bit 0 rows, 1 box too small for the grid, 2 cell bins, 3 an atom outgrew its backward
+        class), read from the device (blocks on the handle's stream's device)."""
+        addr = C.c_void_p()
+        _check(self._lib.nnpops_ani_overflow_word(self._h, C.byref(addr)))
+        word = C.c_int(0)
+        torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")                         # (the runtime torch has loaded already)
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(C.byref(word), addr, 4, 2)          # hipMemcpyDeviceToHost
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy of the overflow word failed ({rc})")
+        return word.value
+
     def set_timing_merge(self, merge):
         """True: one bracket around build + angular forward (reported as "neighbors") and one around the two backward kernels (reported as
         "angular_backward") instead of the four single ones: single + single - merged = what a bracket costs, measured in place."""

@@ -80,7 +80,7 @@ struct nnpops_ani {
     int fwd_atoms_per_group = 1;    // > 1: every wave / workgroup walks that many atoms (amortises its prologue)
     int* d_cnt_a = nullptr;         // [N]
     int* d_cnt_ro = nullptr;        // [N]
-    int* d_status = nullptr;        // [kStatWords]
+    int* d_status = nullptr;        // [kStatAlloc]: check()'s kStatWords words, then the class launches' flag (ani_kernels.h)
     int* h_status = nullptr;        // pinned, device-visible host words {stamp, overflow} (nnpops_ani_check_begin / _end)
     int* h_status_dev = nullptr;    // the device's address of the same words
     int check_stamp = 0;
@@ -122,6 +122,7 @@ struct nnpops_ani {
     int bwd_class_atoms = 16384;             // systems of fewer atoms take one backward launch ($NNPOPS_ANI_BWD_CLASS_ATOMS)
     int cell_atoms = 1800;          // systems of at least this many atoms search their neighbours through the cell grid ($NNPOPS_ANI_CELL_ATOMS)
     int lpt = 2;                    // $NNPOPS_ANI_LPT: 0 off, 1 only where there is no cell order, 2 (default) also instead of the cell order
+    int backprop_stamp = 0;         // counts backprop() calls (never 0): what the class launches write to the class flag (ani_angular_bwd.h)
     unsigned timing_mask = 0;       // bit k: kernel id k is bracketed by events
     int timing_every = 1;           // ... on every timing_every-th launch
     bool timing_merge = false;      // nnpops_ani_set_timing_merge: ONE bracket around neighbour build + angular forward (reported as the
@@ -319,8 +320,9 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const bool by_class = h->bwd_by_class && !h->bwd_classes.empty() && sp.ang_order == h->d_work_order && sp.w0 == 0 && sp.nw == h->hp.N;
         const nnpops_ani::BwdClass* classes = by_class ? h->bwd_classes.data() : &whole;
         const int nclasses = by_class ? (int)h->bwd_classes.size() : 1;
-        for (int c = 0; c < nclasses; c++) {
-        const int tile = std::min(classes[c].tile, h->cap_angular), cw0 = classes[c].w0, cnw = classes[c].nw;
+        for (int c = 0; c < nclasses + (by_class ? 1 : 0); c++) {
+        const nnpops_ani::BwdClass& cl = c < nclasses ? classes[c] : whole;
+        const int tile = std::min(cl.tile, h->cap_angular), cw0 = cl.w0, cnw = cl.nw;
         if (cnw <= 0) continue;
         int mode = h->backward_kernel;
         // Dense systems (64 or more record slots): the pair matrix is 27 KB per atom and only 6 atoms fit a CU -- six waves
@@ -329,12 +331,12 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         // (round 4: what decides is the work per atom, not the LDS -- with the classes above every class of the conformer batch, the
         //  32-slot one included, is faster with two waves per atom: 304 us in one launch, 275 by class with this rule on LDS, 246
         //  with two waves everywhere; the 153-triple atoms of a liquid stay with one wave, 15.8 against 25 us)
-        if (mode == 1 && !h->backward_forced && (classes[c].two_waves || ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, false) > 16 * 1024)) mode = 3;
+        if (mode == 1 && !h->backward_forced && (cl.two_waves || ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, false) > 16 * 1024)) mode = 3;
         if (!vec_ok && (mode == 1 || mode == 3)) mode++;
         const bool glds = mode == 2 || mode == 4;
         const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, glds) + 15) & ~(size_t)15;
         void (*k)(const AniParams*, const AngularConsts, int, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
-                  float4*, float4*, int, int, int, const int*, int, int) =
+                  float4*, float4*, int, int, int, const int*, int, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
                          : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, 1>
                                                                                        : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
@@ -349,9 +351,13 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
-        hipLaunchKernelGGL(k, dim3(div_up(cnw, apg)), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, tile, h->d_recA, h->d_recB, h->d_tri,
+        // (c == nclasses: the clean-up launch behind the classes -- every atom, full-size pair matrix, a grid the chip holds at once;
+        //  it returns at once unless a class launch left an atom out: ani_angular_bwd.h)
+        const int class_mode = !by_class ? 0 : c < nclasses ? 1 : 2;
+        const int groups = class_mode == 2 ? std::min(div_up(cnw, apg), 1024) : div_up(cnw, apg);
+        hipLaunchKernelGGL(k, dim3(groups), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, tile, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
-                           sp.ang_order, cw0, cnw);
+                           sp.ang_order, cw0, cnw, class_mode | (h->backprop_stamp << 2));
         }
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
@@ -395,7 +401,7 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, cons
         auto k = ani_angular_backward_pair<TA, 4, 4, 4, 1, false, true>;
         if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
         hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, h->hp.NB, (int)lb, nullptr, 0, N);
+                           h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, h->hp.NB, (int)lb, nullptr, 0, N, 0);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
@@ -644,7 +650,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_cnt_ro, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_pos, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_centre_force, (size_t)num_atoms))) return cleanup(rc);
-    if ((rc = dev_alloc(&h->d_status, (size_t)kStatWords))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_status, (size_t)kStatAlloc))) return cleanup(rc);
     if ((rc = alloc_rows(h))) return cleanup(rc);
     h->max_cells = num_atoms + 4096;
     if ((rc = dev_alloc(&h->d_grid, 1))) return cleanup(rc);
@@ -665,6 +671,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_class_tile, (size_t)num_atoms))) return cleanup(rc);
     if (hipMemset(h->d_class_tile, 255, (size_t)num_atoms) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
     hp.class_tile = h->d_class_tile;
+    hp.class_flag = h->d_status + kStatClassFlag;
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASSES")) h->bwd_by_class = std::atoi(e) != 0;
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_MIN")) h->bwd_class_min = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_ATOMS")) h->bwd_class_atoms = std::max(0, std::atoi(e));
@@ -713,7 +720,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     }
     if (hipMemcpy(h->d_params, &hp, sizeof(AniParams), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_species, atom_species, sizeof(int32_t) * num_atoms, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(h->d_status, 0, sizeof(int) * kStatWords) != hipSuccess ||
+        hipMemset(h->d_status, 0, sizeof(int) * kStatAlloc) != hipSuccess ||
         hipMemset(h->d_cnt_a, 0, sizeof(int) * num_atoms) != hipSuccess ||
         hipMemset(h->d_cnt_ro, 0, sizeof(int) * num_atoms) != hipSuccess || hipMemset(h->d_cnt_pos, 0, sizeof(int) * num_atoms) != hipSuccess)
         return cleanup(fail(NNPOPS_ERR_HIP, "parameter upload failed: %s", hipGetErrorString(hipGetLastError())));
@@ -903,6 +910,7 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     const int nspans = make_spans(h, spans);
     int rc = fork_streams(h, spans, nspans);
     if (rc != NNPOPS_OK) return rc;
+    h->backprop_stamp = h->backprop_stamp >= 0x1fffffff ? 1 : h->backprop_stamp + 1;
     KernelTimer merged_timer(h, NNPOPS_ANI_K_ANGULAR_BWD, spans[0].stream, /*merged=*/true);      // (spans the radial backward below)
     for (int q = 0; q < nspans; q++) {
         rc = dispatch_angular(h, false, angular_deriv, nullptr, spans[q]);
@@ -1105,12 +1113,14 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
                      h->tile * (h->tile + 1) + h->tile * (h->tile - 1) / 2 >= h->cap_angular * 4 + 12;
     if (max_radial_neighbors) *max_radial_neighbors = st[kStatMaxRow];
     if (max_angular_neighbors) *max_angular_neighbors = st[kStatMaxAngular];
-    if (st[kStatOverflow] == 8) {         // nothing overflowed, but an atom outgrew its backward class: regrouped above
-        h->computed = false;
-        if (!want_order)                   // (no order was built: lift every limit)
+    if (st[kStatOverflow] == 8) {         // nothing overflowed, but an atom outgrew its backward class: regrouped above.  The evaluation
+                                          // itself stands (the clean-up launch of the backward takes such atoms, ani_angular_bwd.h): no
+                                          // recompute, the new classes only make the next backward launches cheaper again.
+        if (!want_order) {                 // (no order was built: lift every limit)
             NNPOPS_HIP_TRY(hipMemset(h->d_class_tile, 255, (size_t)h->hp.N));
-        if (!want_order) h->bwd_classes.clear();
-        return fail(NNPOPS_ERR_CAPACITY, "an atom outgrew the pair-matrix class of its backward launch; classes rebuilt, call compute() again");
+            h->bwd_classes.clear();
+        }
+        return NNPOPS_OK;
     }
     if (st[kStatOverflow] & 4) {          // a cell holds more atoms than a bin of the two-kernel grid build: grow the bins
         const int old_bin = h->bin_cap;

@@ -116,8 +116,19 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, int tile, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
     const float* __restrict__ angular_grad, int ld_angular, float4* __restrict__ leg_force, float4* __restrict__ centre_force,
-    int vec_ok, int NB, int lds_per_atom, const int* __restrict__ order, int w0, int nw) {     // positions [w0, w0 + nw) of `order`
+    int vec_ok, int NB, int lds_per_atom, const int* __restrict__ order, int w0, int nw,     // positions [w0, w0 + nw) of `order`
+    int class_word) {      // class_mode | stamp << 2
+    // class_mode (launches by class of atoms, nnpops_ani_check): 0 -- one launch for everybody, `tile` covers every record slot;
+    // 1 -- the launch of one class: an atom that has outgrown the class since check() (more angular neighbours than `tile`) is LEFT
+    // OUT here -- the launch says so by writing this backprop()'s stamp to class_flag -- and evaluated by the launch of mode 2, which
+    // runs behind the classes with the full-size pair matrix, returns at once unless the flag carries the stamp, and takes exactly
+    // the atoms the classes left out.  Forces are right whether or not anybody calls check() between the frames (graph replays,
+    // check intervals > 1: a replayed stamp keeps the clean-up launch on from the first outgrown atom on, which is only slower).
+    // (flag and per-atom class limits through the parameter block -- P->class_flag, P->class_tile: read by class launches only;
+    //  one kernel argument instead of four: this kernel spills scalar registers as it is)
     constexpr int BLK = NFRP * NFZP;
+    const int class_mode = class_word & 3, stamp = class_word >> 2;
+    if (class_mode == 2 && *P->class_flag != stamp) return;
     constexpr int NT = 64 * WPA;                               // lanes of the workgroup
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = lane_id();
@@ -191,7 +202,12 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         }
         int n, nro;
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
-        n = min(n, tile);                                      // (an atom that outgrew its class was flagged by the builder; stay inside the LDS)
+        if (class_mode == 1 && n > tile) {                     // outgrew its class: the clean-up launch evaluates it (uniform for the workgroup)
+            if (role == 0 && lane == 0) *P->class_flag = stamp;
+            continue;
+        }
+        if (class_mode == 2 && n <= (int)P->class_tile[i]) continue;   // clean-up launch: its class evaluated it
+        n = min(n, tile);                                      // (tile >= capA outside class launches: a no-op)
         if (n < 2) {                                           // no triples (uniform for the workgroup): a lone leg carries no force
             if (n == 1 && role == 0 && lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         for (int base = role * 64; base < T; base += NT) {
             const int t = base + lane;
             const int next_word = (t + NT < T) ? tri[t + NT] : 0;
-            if (t < T && ((word >> 8) & 0xff) < tile) {        // (the second test only fails for an atom that outgrew its class: its list is laid out for more slots)
+            if (t < T) {
                 const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;
                 float ap, aq, bt;
                 if constexpr (GENERIC) {

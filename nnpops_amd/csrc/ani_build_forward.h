@@ -142,7 +142,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
                 out.cnt_pos[slot_id] = pack_cnt_pos(na, nro, in.use_cells ? (__float_as_int(me.w) >> kTagShift) : in.species[i]);
                 shared[0] = na; shared[1] = nro;
                 if (na > capA || na + nro > cap) atomicOr(&out.status[kStatOverflow], 1);      // (ani_kernels.h: builders flag their own overflow)
-                else if (na > (int)P->class_tile[i]) atomicOr(&out.status[kStatOverflow], 8);
+                else if (P->class_tile[i] != 255 && na > (int)P->class_tile[i]) atomicOr(&out.status[kStatOverflow], 8);
             }
         }
         __syncthreads();

@@ -121,6 +121,7 @@ struct AniParams {
     int* bucket_offsets;             // [N][NB + 1] device array the builders fill: offsets of the buckets in an atom's triple list
     const unsigned char* class_tile; // [N] pair-matrix edge of the backward launch this atom was put in by check() (255: no limit);
                                      //     a builder that finds more angular neighbours than that flags kStatOverflow bit 3
+    int* class_flag;                 // the backward's class launches write their stamp here when they leave an atom out (ani_angular_bwd.h)
     // matrix-core forward kernel (ani_angular_mfma.h)
     int m_of_c[kMaxAngularFns];      // canonical slot a*NFZP+z -> function m, -1 for padding slots
     int fwd_split;                   // K: every species pair that can occur is shared by K quads (1, 2, 4 or 8)
@@ -144,7 +145,8 @@ struct AngularConsts {
 };
 
 // status words reported by nnpops_ani_check
-enum { kStatOverflow = 0, kStatMaxRow = 1, kStatMaxAngular = 2, kStatWords = 4 };
+enum { kStatOverflow = 0, kStatMaxRow = 1, kStatMaxAngular = 2, kStatWords = 4,
+       kStatClassFlag = 4, kStatAlloc = 8 };      // (word 4 is not one of check()'s: the class launches' flag, ani_angular_bwd.h; never cleared)
 
 __host__ __device__ inline int triples_capacity(int capA) { return capA * (capA - 1) / 2; }
 
@@ -193,16 +195,23 @@ __device__ __forceinline__ void clamp_counts(int raw_a, int raw_ro, int cap, int
 // =============================================================================================
 // Triple enumeration helpers (used by the builders; the consumers just read the word lists).
 // =============================================================================================
-// (p, q) with p < q of the t-th pair in row-major order of the strict upper triangle of an n x n grid
-__device__ __forceinline__ void decode_pair(int t, int n, int& p, int& q) {
-    const float w = (float)(2 * n - 1);
-    int pp = (int)((w - fast_sqrt(fmaxf(w * w - 8.0f * (float)t, 0.f))) * 0.5f);
-    pp = max(0, min(pp, n - 2));
-    // offset(p) = p*(2n-p-1)/2 ; one fix-up step each way covers the rounding of the fast sqrt
-    if (__mul24(pp + 1, 2 * n - pp - 2) / 2 <= t) pp++;
-    if (__mul24(pp, 2 * n - pp - 1) / 2 > t) pp--;
-    p = pp;
-    q = t - __mul24(pp, 2 * n - pp - 1) / 2 + pp + 1;
+// The pairs p < q of n sorted slots as a rectangle without a square root (round 5): row p of the strict upper triangle holds
+// n - 1 - p pairs, so rows R and n - 1 - R together hold n - 1 -- fold the triangle into ceil(n / 2) rows of n - 1 columns:
+//     t -> (R, C) = divmod(t, n - 1);   C < n - 1 - R:  pair (R, R + 1 + C);   else:  pair (n - 1 - R, C + 1)
+// Every pair appears exactly once; for odd n the middle row pairs with itself and its second half is void (valid = false).  The
+// quotient comes from one multiplication by 1 / (n - 1): exact for every t < 2^15, n <= 256 (the error of the product is below
+// 2e-5 where the nearest quotient boundary is 0.5 / 255 away).  ~9 vector instructions where the row-major decode with its square
+// root, two correction steps and two 24-bit products took ~25; the ORDER in which a wave meets the pairs is irrelevant: every pair
+// computes its own place in the bucket-major list.
+__device__ __forceinline__ int folded_pair_count(int n) { return __mul24((n + 1) >> 1, n - 1); }
+__device__ __forceinline__ bool decode_pair_folded(int t, int n, float inv_nm1, int& p, int& q) {
+    const int R = (int)(((float)t + 0.5f) * inv_nm1);
+    const int C = t - __mul24(R, n - 1);
+    const int mirror = n - 1 - R;
+    const bool first = C < mirror;
+    p = first ? R : mirror;
+    q = C + 1 + (first ? R : 0);
+    return first || mirror != R;
 }
 
 // Per-atom species bookkeeping in LDS (ints), sized by the actual species / bucket counts.
@@ -354,9 +363,11 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     // binary search over the bucket offsets and a division or a square root per lane (~100 vector instructions per batch
     // of 64 against ~45).  Same list, scattered 4-byte stores inside the atom's own few cache lines.
     wave_fence();                                              // (G.ssp, G.boff)
-    for (int t = lane; t < T; t += 64) {
+    const int E = T > 0 ? folded_pair_count(n) : 0;            // (n <= 1: no pairs, and no 1 / (n - 1))
+    const float inv_nm1 = __builtin_amdgcn_rcpf((float)max(n - 1, 1));
+    for (int t = lane; t < E; t += 64) {
         int p, q;
-        decode_pair(t, n, p, q);
+        if (!decode_pair_folded(t, n, inv_nm1, p, q)) continue;
         const int A = G.ssp[p], B = G.ssp[q];                  // A <= B: the slots are sorted by species
         const int bucket = __mul24(A, S) - __mul24(A, A - 1) / 2 + (B - A);        // upper-triangular row-major, as AniParams::bkt_a / bkt_b
         const int ia = p - G.gs[A], ib = q - G.gs[B], gb = G.gn[B];
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
-        else if (na > (int)P->class_tile[i]) atomicOr(&status[kStatOverflow], 8);     // outgrew its backward class: check() regroups
+        else if (P->class_tile[i] != 255 && na > (int)P->class_tile[i]) atomicOr(&status[kStatOverflow], 8);     // outgrew its backward class: check() regroups
     }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
         // (an atom that outgrew its row or its records says so itself: check() then needs no pass over the counts to
         //  know that nothing overflowed; an atomic only in that rare case)
         if (na > capA || na + nro > cap) atomicOr(&status[kStatOverflow], 1);
-        else if (na > (int)P->class_tile[i]) atomicOr(&status[kStatOverflow], 8);     // outgrew its backward class: check() regroups
+        else if (P->class_tile[i] != 255 && na > (int)P->class_tile[i]) atomicOr(&status[kStatOverflow], 8);     // outgrew its backward class: check() regroups
     }
     int n, nro_c;
     clamp_counts(na, nro, cap, capA, n, nro_c);

@@ -661,3 +661,17 @@ def test_backward_classes_regroup_when_an_atom_outgrows_its_class(monkeypatch):
             assert np.abs(grad - ref).max() <= 1e-4 * np.abs(ref).max(), classes
     for (_, _, _, g1), (_, _, _, g0) in zip(results["1"], results["0"]):
         assert np.array_equal(g1, g0)                                 # same kernel arithmetic per atom, whatever the launch it ran in
+    # ... and WITHOUT any check between the frames (graph replays, check intervals > 1: ADVICE r04): classes cut for frame A, frame B
+    # evaluated unchecked -- the atoms that outgrew their class are taken by the clean-up launch behind the classes, bit 3 of the
+    # overflow word says that it happened
+    monkeypatch.setenv("NNPOPS_ANI_BWD_CLASSES", "1")
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=False)
+    sym.set_molecules(offsets)
+    sym.compute(torch.tensor(frame_a, device=dev), None)              # (checked: capacities fitted, classes cut for frame A)
+    assert int(sym.describe()["classes"]) >= 2, sym.describe()
+    tp = torch.tensor(frame_b, device=dev)
+    radial, angular = sym.compute(tp, None, check=False)
+    _, wr, wa, checked = results["0"][1]
+    grad = sym.backprop(torch.tensor(wr, device=dev), torch.tensor(wa, device=dev)).cpu().numpy()
+    assert sym.overflow_word() & 8                                    # an atom did outgrow its class (the builders say so) ...
+    assert np.array_equal(grad, checked)                              # ... and its forces are those of the checked evaluation

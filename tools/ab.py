@@ -24,15 +24,31 @@ def main():
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--water", action="store_true", help="a water box (2 species present) instead of 7 uniform species")
+    ap.add_argument("--workload", default="box", choices=["box", "latency", "block", "batch"],
+                    help="box: periodic liquid of --atoms atoms; latency: the 50-atom conformer of BASELINE config 1; block / batch: 128 / "
+                         "1 024 conformers of config 4 in one batched handle")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    if args.water:
+    offsets = None
+    if args.workload == "latency":
+        pos, species = workloads.conformer(50, seed=0)
+        box = None
+    elif args.workload in ("block", "batch"):
+        import bench
+        sizes = bench.conformer_sizes()[:128 if args.workload == "block" else 1024]
+        mols = [workloads.conformer(sizes[m], seed=1000 + m) for m in range(len(sizes))]
+        pos = np.concatenate([m[0] for m in mols]).astype(np.float32)
+        species = np.concatenate([m[1] for m in mols]).astype(np.int32)
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        box = None
+    elif args.water:
         pos, species, box = workloads.water_box(args.atoms // 3, seed=1)
     else:
         pos, species, box = workloads.random_box(args.atoms, density=0.1, seed=100, n_species=7)
     n = len(species)
     rf, af = workloads.ani2x_functions()
-    tpos, tbox = torch.tensor(pos, device=dev), torch.tensor(box, device=dev)
+    tpos = torch.tensor(pos, device=dev)
+    tbox = torch.tensor(box, device=dev) if box is not None else None
     handles = []
     from nnpops_amd import capi
     product = capi.lib()
@@ -52,7 +68,9 @@ def main():
                     capi._lib = other
                 else:
                     os.environ[k] = val
-        sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=True)
+        sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=box is not None)
+        if offsets is not None:
+            sym.set_molecules(offsets)
         capi._lib = product
         os.environ.clear(); os.environ.update(saved)
         radial = torch.empty((n, sym.radial_width), device=dev)
@@ -60,6 +78,7 @@ def main():
         g_r, g_a = torch.randn_like(radial), torch.randn_like(angular)
         grad = torch.empty((n, 3), device=dev)
         sym.compute(tpos, tbox, radial, angular, check=True)
+        sym.compute(tpos, tbox, radial, angular, check=True)   # (a schedule the first check prepared is in place from the next compute on)
         handles.append((v, sym, radial, angular, g_r, g_a, grad))
     results = {v: [] for v in args.variants}
     walls = {v: [] for v in args.variants}

@@ -24,8 +24,8 @@ PM = "nnpops_probe_mask"
 PATCHES = {
     "ani_kernels.h": [
         ("constexpr int kMaxRadialFns = 64;\n", "static __device__ int nnpops_probe_mask;\nconstexpr int kMaxRadialFns = 64;\n", 1),
-        ("    for (int t = lane; t < T; t += 64) {\n        int p, q;\n        decode_pair(t, n, p, q);\n",
-         f"    if (!({PM} & 1))\n    for (int t = lane; t < T; t += 64) {{\n        int p, q;\n        decode_pair(t, n, p, q);\n", 1),
+        ("    for (int t = lane; t < E; t += 64) {\n        int p, q;\n",
+         f"    if (!({PM} & 1))\n    for (int t = lane; t < E; t += 64) {{\n        int p, q;\n", 1),
         ("    flush_row(row, stage, cap, na, nro);\n    radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);\n    finalize_angular(",
          f"    if (!({PM} & 8)) flush_row(row, stage, cap, na, nro);\n    if (!({PM} & 2)) radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);\n"
          f"    if (!({PM} & 4)) finalize_angular(", 2),
