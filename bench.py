@@ -250,6 +250,100 @@ def measure_counters(atoms):
     return traffic, insts, (traced or {})
 
 
+def side_traffic(args, R, workload, scope, extra=()):
+    """HBM bytes of the kernels a side line's roofline is about, measured in this run like the headline's: two rocprofv3 passes
+    (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE, nothing else) over three steps of `bench.py --workload <workload>`.
+    scope = [(kernel-name fragment, launches per step)] (launches None: as many as the profile shows per launch of the FIRST
+    fragment's kernel, which runs once per step); -> (bytes per step over the scope, {fragment: bytes per launch}) or
+    (None, None) when rocprofv3 is missing, a pass fails, --no-pmc was given or this is a multi-rank run.
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB per dispatch (gfx950: FETCH_SIZE reports half the bytes of wide reads,
+    MI355X_MICROARCH.md)."""
+    if getattr(args, "no_pmc", False) or R.world > 1:
+        return None, None
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None
+    workdir = tempfile.mkdtemp(prefix="nnpops_side_pmc_")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(workdir, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", counter, "--output-format", "rocpd", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc",
+                   "--no-shard8", *extra]
+            subprocess.run(cmd, cwd=workdir, env=dict(os.environ, TMPDIR=workdir), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=240, check=True)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None, None
+            rows = sqlite3.connect(dbs[0]).execute(
+                "select k.name, sum(p.counter_value), count(distinct k.dispatch_id) from pmc_events p join kernels k "
+                "on k.dispatch_id = p.dispatch_id where p.counter_name = ? group by k.name", (counter,)).fetchall()
+            for name, total, ndisp in rows:
+                for frag, _ in scope:
+                    if frag in name:
+                        slot = per.setdefault(frag, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                        slot[counter][0] += total
+                        slot[counter][1] += ndisp
+    except Exception:
+        return None, None
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    by_kernel, step_bytes = {}, 0.0
+    for frag, launches in scope:
+        if frag not in per or per[frag]["FETCH_SIZE"][1] == 0 or per[frag]["WRITE_SIZE"][1] == 0:
+            return None, None
+        f, w = per[frag]["FETCH_SIZE"], per[frag]["WRITE_SIZE"]
+        b = (2.0 * f[0] / f[1] + w[0] / w[1]) * 1024.0
+        by_kernel[frag] = int(b)
+        if launches is None:
+            launches = f[1] / max(per[scope[0][0]]["FETCH_SIZE"][1], 1)
+        step_bytes += launches * b
+    return int(step_bytes), by_kernel
+
+
+SIDE_TRAFFIC_SOURCE = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this run over three steps of the same workload: "
+                       "(2 * FETCH_SIZE + WRITE_SIZE) KiB per launch, summed over the kernels of the scope")
+
+
+def launch_floor_us(dev, launches=3, reps=2000):
+    """What `launches` back-to-back launches of a kernel that does nothing cost on this device and runtime, eagerly and replayed as
+    one HIP graph (us per group of launches): the floor under a latency-bound step."""
+    import torch
+    x = torch.zeros(64, device=dev)
+
+    def group():
+        for _ in range(launches):
+            x.add_(0.0)
+    for _ in range(50):
+        group()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        group()
+    torch.cuda.synchronize()
+    eager = 1e6 * (time.perf_counter() - t0) / reps
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        group()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        group()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    return round(eager, 2), round(1e6 * (time.perf_counter() - t0) / reps, 2)
+
+
 # =============================================================================================
 # process group / self-spawn
 # =============================================================================================
@@ -588,7 +682,7 @@ def run_latency(args, R):
     for _ in range(50):
         step()
     torch.cuda.synchronize()
-    k = 2000
+    k = 2000 if args.steps >= 20 else 20               # (the counter passes of this very workload run three steps: side_traffic)
     t0 = time.perf_counter()
     for _ in range(k):
         step()
@@ -648,11 +742,24 @@ def run_latency(args, R):
         ligand = {"molecule": "1hvj ligand, 115 atoms (reference src/pytorch/molecules/1hvj_ligand.mol2, geometry from tests/golden/molecules_ref.npz)",
                   "eager_us": round(ligand_us, 2), "max_abs_aev_error_vs_reference_cpu": err_aev,
                   "max_force_error_over_largest_force_vs_reference_cpu": err_grad}
+    floor_eager, floor_graph = launch_floor_us(dev, launches=3)
+    step_traffic, traffic_by_kernel = side_traffic(args, R, "latency", [("ani_build_forward", 1), ("ani_angular_backward_pair", 1),
+                                                                        ("ani_radial_backward_lanes", 1)])
     out = {"metric": "ANI-2x AEV forward+backward latency, 50-atom molecule in vacuum", "value": round(min(eager_us, graph_us), 2),
            "unit": "us/eval", "higher_is_better": False, "eager_us": round(eager_us, 2), "hip_graph_us": round(graph_us, 2),
            "algorithmic_bytes": 50 * (16 + 2 * 1008 * 4 + 12), "ligand_1hvj": ligand,
-           "hip_graph_note": "a graph replay has a fixed cost of ~10-16 us on this runtime (MI355X_MICROARCH.md, graph-replay-floor): three "
-                             "kernels of 5-15 us each are cheaper launched eagerly, the host stays ahead of the device",
+           # a latency-bound line: no bandwidth or matrix peak applies to 0.4 MB in three dependent launches -- what bounds it is the
+           # launch floor of this device and runtime, measured here with three launches of a kernel that does nothing
+           "roofline": {"bound": "latency", "kernel": "ani_build_forward + ani_angular_backward_pair + ani_radial_backward_lanes",
+                        "launches": 3, "floor_us": floor_eager, "floor_us_as_hip_graph": floor_graph,
+                        "achieved": round(min(eager_us, graph_us), 2), "peak": floor_eager, "unit": "us",
+                        "frac": round(floor_eager / max(min(eager_us, graph_us), 1e-9), 5),
+                        "traffic": step_traffic, "traffic_by_kernel": traffic_by_kernel,
+                        "traffic_source": SIDE_TRAFFIC_SOURCE if step_traffic is not None else None,
+                        "algorithmic_bytes_per_launch": 50 * (16 + 2 * 1008 * 4 + 12)},
+           "hip_graph_note": "three EMPTY launches replayed as one HIP graph cost floor_us_as_hip_graph against floor_us eagerly (roofline "
+                             "object, measured in this run): the replay's own fixed cost is what the graph figure of this line carries over the "
+                             "eager one -- the host stays ahead of a device that needs ~25 us per evaluation, so eager launches cost the step nothing",
            "config": {"workload": "BASELINE config 1: 50-atom conformer (seed 0), non-periodic, all-pairs neighbour search, "
                                   "3 launches per evaluation (fused build + forward, two backward kernels); latency-bound (0.4 MB of algorithmic traffic)"}}
     if not args.no_cpu_baseline:
@@ -731,6 +838,9 @@ def run_neighbors(args, R):
     nb_bytes = n * 12 + found * 24                      # positions in, (2 ints + 3 floats + 1 float) per pair out
     ang_bytes = n * 16 + n * sym.angular_width * 4
     aev_bytes = n * (16 + 2 * (sym.radial_width + sym.angular_width) * 4 + 12)
+    # HBM bytes of the getNeighborPairs launches (this line's roofline), counters of this run
+    nb_traffic, nb_by_kernel = side_traffic(args, R, "neighbors", [("pairs_cells_stage", 1), ("pairs_cells_emit", 1), ("scan_rows", 1),
+                                                                  ("zero_words", 1), ("bin_atoms", 1), ("order_binned", 1)])
     out = {
         "metric": "getNeighborPairs + ANI-2x AEV forward+backward evaluations/sec, 100k-atom periodic box, cutoff 5.2 A",
         "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
@@ -743,7 +853,8 @@ def run_neighbors(args, R):
         "kernels_us": {k: round(v, 1) for k, v in kt.items()},
         "roofline": {"bound": "hbm", "kernel": "getNeighborPairs (3 launches + cell grid)", "achieved": round(nb_bytes / (t_nb * 1e-3) / 1e9, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb_bytes / (t_nb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                     "traffic": None, "algorithmic_bytes_per_launch": nb_bytes,
+                     "traffic": nb_traffic, "traffic_by_kernel": nb_by_kernel,
+                     "traffic_source": SIDE_TRAFFIC_SOURCE if nb_traffic is not None else None, "algorithmic_bytes_per_launch": nb_bytes,
                      "angular_forward": {"algorithmic_bytes": ang_bytes, "us": round(kt.get("angular_forward", 0.0), 1),
                                          "achieved": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3, 2),
                                          "frac": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3 / HBM_PEAK_GBS, 5)},
@@ -906,6 +1017,9 @@ def run_torchani(args, R):
                             "four layers in one workgroup, activations in LDS / registers)",
                    "gemm": "gemm_h2 (batched_nn.hip: one split-fp16 GEMM per layer and species, fused activations)",
                    "grouped": "BatchedNN GEMMs (hipBLASLt via torch.matmul)", "reference": "BatchedLinear on per-atom replicated weights"}[args.nn_layout]
+    # HBM bytes of the network launches (this line's roofline is about them), counters of this run
+    nn_traffic, nn_by_kernel = (side_traffic(args, R, "torchani", [("mlp_forward", 1), ("mlp_sum_members", 1)])
+                                if args.nn_layout == "fused" else (None, None))
     out = {
         "metric": "OptimizedTorchANI energy+forces evaluations/sec, 2001-atom periodic water box, 8 models, fp32",
         "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
@@ -924,7 +1038,8 @@ def run_torchani(args, R):
         "ms_per_step_as_hip_graph_with_dense_networks": (round(dense_graph_ms, 4) if dense_graph_ms is not None else None),
         "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",
-                     "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": None,
+                     "frac": round(tflops / FP32_MATRIX_PEAK, 5), "traffic": nn_traffic, "traffic_by_kernel": nn_by_kernel,
+                     "traffic_source": SIDE_TRAFFIC_SOURCE if nn_traffic is not None else None,
                      "issued": ({"instruction": "v_mfma_f32_16x16x32_f16, 3 products per fp32 product, over the live AEV columns only",
                                  "tflops": round(tflops_issued, 2), "peak": F16_DENSE_PEAK,
                                  "frac": round(tflops_issued / F16_DENSE_PEAK, 5)} if split else None),
@@ -1108,6 +1223,9 @@ def run_conformers(args, R):
         return None
     atoms_total = int(offsets_all[-1])
     step_bytes = atoms_total * (16 + 2 * 1008 * 4 + 12)
+    # HBM bytes of one batch step (every launch of the step), counters of this run
+    conf_traffic, conf_by_kernel = side_traffic(args, R, "conformers", [("ani_radial_backward_lanes", 1), ("ani_neighbors_allpairs", 1),
+                                                                       ("ani_angular_forward_mfma", 1), ("ani_angular_backward_pair", None)])
     out = {
         "metric": "AEV+forces evaluations/sec of a 1024-conformer batch (ANI-2x, ~60 atoms each)",
         "value": round(steps / elapsed, 3), "unit": "batch evals/s", "n_gpus": world, "steps": steps,
@@ -1119,7 +1237,8 @@ def run_conformers(args, R):
                    "atoms_total": atoms_total, "atoms_this_rank": n},
         "roofline": {"bound": "hbm", "kernel": "whole step (5 launches per GPU)", "achieved": round(step_bytes / elapsed * steps / 1e9, 2),
                      "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(step_bytes / elapsed * steps / 1e9 / (HBM_PEAK_GBS * world), 5),
-                     "traffic": None, "algorithmic_bytes_per_launch": step_bytes},
+                     "traffic": conf_traffic, "traffic_by_kernel": conf_by_kernel,
+                     "traffic_source": SIDE_TRAFFIC_SOURCE if conf_traffic is not None else None, "algorithmic_bytes_per_launch": step_bytes},
     }
     if world == 1 and not args.no_shard8:
         # What one GPU of an 8-GPU node would run: every block of shard_molecules(sizes, 8) timed alone on THIS device
@@ -1224,6 +1343,13 @@ def run_cfconv(args, R):
     flops_fwd = 2.0 * (G * W + W * W) * pairs            # per half pair
     split = os.environ.get("NNPOPS_CFCONV_SPLIT", "1") != "0" and os.environ.get("NNPOPS_CFCONV_HALF", "1") != "0"
     tflops = flops_fwd / (tf * 1e-3) / 1e12
+    # HBM bytes of the FORWARD kernels (this line's roofline is the forward of one layer) and of the backward ones, counters of this run;
+    # the kernels of the two directions differ in a template argument (the mangled name of cfconv_filters_h2 carries ...Lb0E / ...Lb1E
+    # for BWD behind the two integers, cfconv_gather prints <false / <true)
+    fw_names = ("cfconv_filters_h2ILi0ELi8ELb0", "cfconv_gather<false") if split else ("cfconv_filters_mfmaILi0ELi8ELb0", "cfconv_gather<false")
+    bw_names = ("cfconv_filters_h2ILi0ELi8ELb1", "cfconv_gather<true") if split else ("cfconv_filters_mfmaILi0ELi8ELb1", "cfconv_gather<true")
+    cf_traffic, cf_by_kernel = side_traffic(args, R, "cfconv", [(fw_names[0], 1), (fw_names[1], 1)])
+    cf_bwd_traffic, cf_bwd_by_kernel = side_traffic(args, R, "cfconv", [(bw_names[0], 1), (bw_names[1], 1)]) if cf_traffic is not None else (None, None)
     out_json = {
         "metric": "CFConv build+forward+backward evaluations/sec, W=128 G=50 cutoff 5 A, 10k-atom periodic box",
         "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
@@ -1235,7 +1361,11 @@ def run_cfconv(args, R):
         "phases_ms": {"build": round(tb, 4), "forward": round(tf, 4), "backward": round(tbw, 4)},
         "roofline": {"bound": "mfma", "kernel": ("cfconv_filters_h2" if split else "cfconv_filters_mfma") + " + cfconv_gather (forward)",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s", "frac": round(tflops / FP32_MATRIX_PEAK, 5),
-                     "traffic": None,
+                     "traffic": cf_traffic, "traffic_by_kernel": cf_by_kernel,
+                     "traffic_source": SIDE_TRAFFIC_SOURCE if cf_traffic is not None else None,
+                     "backward": {"traffic": cf_bwd_traffic, "traffic_by_kernel": cf_bwd_by_kernel,
+                                  "algorithmic_bytes": int(n * W * 4 * 3 + n * 24 + pairs * 24)},
+                     "algorithmic_bytes_per_launch": int(n * W * 4 * 2 + pairs * 24),
                      "issued": ({"instruction": "v_mfma_f32_16x16x32_f16, 3 products per fp32 product", "tflops": round(3 * tflops, 2),
                                  "peak": F16_DENSE_PEAK, "frac": round(3 * tflops / F16_DENSE_PEAK, 5)} if split else None),
                      "note": "algorithmic flops (half-pair count) / measured forward time (filters kernel + gather kernel); `frac` is "

@@ -13,8 +13,10 @@
 //   torch.ops.NNPOpsBatchedNN.BatchedLinear               (reference src/pytorch/BatchedNN.cpp:48-50)
 //
 // Differences that are deliberate:
-//   * there is no CPU implementation: a CPU tensor raises (the reference's CPU path is the oracle of this
-//     repository, not part of the product);
+//   * the AEV / CFConv / BatchedNN ops have no CPU implementation: a CPU tensor raises (the reference's CPU path is the
+//     oracle of this repository, not part of the product).  The two ops for which the reference itself registers a CPU
+//     kernel at the dispatcher -- neighbors::getNeighborPairs and pme::pme_direct -- do have a CPU key here (plain C++
+//     loops pinned to the reference's CPU ops by fixtures, tests/test_neighbors_cpu_key.py, tests/test_pme_cpu.py);
 //   * outputs are fresh tensors on every call (the reference re-returns the same storage,
 //     SymmetryFunctions.cpp:136-138,157) -- no caller can observe the difference except by aliasing bugs;
 //   * CFConv honours the current stream (the reference leaves that commented out, CFConv.cpp:167-170).

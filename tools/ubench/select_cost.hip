@@ -34,7 +34,6 @@ __global__ __launch_bounds__(256) void spin(float* out, float a, float b, int n)
                 if (KIND == 5) asm volatile("v_max_f32 %0, %1, %0" : "+v"(x[k]) : "v"(a));
                 if (KIND == 6) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(q[k]) : "v"(q[(k + 1) & 7]), "v"(q[(k + 2) & 7]));
                 if (KIND == 7) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sacc) : "v"(x[k]));
-                if (KIND == 8) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(x[k]) : "s"(sacc));
                 if (KIND == 9) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x[k]));
                 if (KIND == 10) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(q[k]) : "v"(q[(k + 1) & 7]));
                 if (KIND == 11) asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(q[k]) : "v"(q[(k + 1) & 7]));
@@ -101,7 +100,6 @@ int main() {
     run<21>("v_and_b32", out);
     run<20>("v_lshl_add_u32", out);
     run<7>("v_readlane_b32", out);
-    run<8>("v_writelane_b32", out);
     run<9>("v_mov_b32_dpp row_shr", out);
     run<29>("v_max_i32_dpp row_shr", out);
     run<18>("v_mbcnt_lo", out);
