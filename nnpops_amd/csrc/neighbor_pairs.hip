@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64) void pairs_allpairs(int N, const T* __restrict_
 // row to its final offset -- no second distance computation.  A row with more than kStageCap pairs, or a box
 // too small for the stencil, is only counted by STAGE and recomputed by EMIT (walk_row with MODE = kEmit).
 constexpr int kStageCap = 64;
+constexpr int kPairsFineBinnedAtoms = 16384;    // with half-width cells the two-launch grid build (<= 8 192 cells) serves systems up to here
 constexpr int kCellThreshold = 8192;        // below this the N^2/2 scan is cheaper than building a grid
 enum { kStage = 0, kEmit = 1 };
 
@@ -202,8 +203,14 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
     const int c = atom_cell[row];
     int cx, cy, cz;
     split_cell(g, c, cx, cy, cz);                          // (no integer division; exact: celllist.h)
-    // only partners with a smaller id: the prefix of every stencil cell (celllist.h), half the candidates of the full walk
-    const WideStencil st = gather_prefix_stencil_wide(g, cell_start, sorted_atom, cx, cy, cz, row);
+    // Full-width cells (3 x 3 x 3): only partners with a smaller id -- the prefix of every stencil cell (celllist.h), half the
+    // candidates of the full walk, at the price of 27 binary searches: four or five DEPENDENT loads in a kernel whose waves do
+    // little else than wait for loads (12 occupancy rounds of ~6.5 us at 100 000 atoms: position -> cell -> cell starts -> search
+    // -> candidates -> staged stores).  Half-width cells (5 x 5 x 5, round 5): the stencil holds 58 % of the volume, so walking ALL
+    // of it and dropping the candidates with a larger id (`active` above) tests about as many as the prefixes of the coarse grid
+    // did -- with no search: the chain is four round trips.
+    const WideStencil st = g.m == 2 ? gather_wide_stencil(g, cell_start, cx, cy, cz)
+                                    : gather_prefix_stencil_wide(g, cell_start, sorted_atom, cx, cy, cz, row);
     __shared__ int strips[4][64];                                          // (256-thread blocks: one strip per wave)
     int* strip = strips[threadIdx.x >> 6];
     int carry = 0;
@@ -470,6 +477,7 @@ struct Workspace {
     void* st_rec;         // [N][kStageCap] Staged<T> (sized for double)
     int* hist;            // [kHistWords] two-launch grid build (periodic systems of up to kPairsBinnedAtoms atoms), zeroed by every call
     int* bins;            // [kBinnedCells][kPairsBinCap]
+    int* tile_total;      // [max_cells / kScanTile + 2] partial sums of the tiled cell scan (grids of more than 8 192 cells)
     int max_cells;
 };
 
@@ -499,6 +507,7 @@ size_t carve(Workspace* w, char* base, int N) {
     const bool binned = staged && N <= kPairsBinnedAtoms;
     tmp.hist = (int*)take(binned ? sizeof(int) * kHistWords : 0);
     tmp.bins = (int*)take(binned ? sizeof(int) * (size_t)kBinnedCells * kPairsBinCap : 0);
+    tmp.tile_total = (int*)take(sizeof(int) * ((size_t)max_cells / kScanTile + 2));
     if (w) *w = tmp;
     return off;
 }
@@ -553,12 +562,18 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
         // (the grid also emits cell-ordered positions; they land in scratch this op does not otherwise use)
         CellBuffers cb{w.grid, w.cell_count, w.cell_start, w.atom_cell, w.atom_rank, w.unsorted_atom, w.sorted_atom,
                        w.sorted_pos, w.max_cells};
+        cb.tile_total = w.tile_total;
         // A periodic system of up to kPairsBinnedAtoms atoms takes the two-launch grid of the stateful handles (celllist.h:
         // bin_atoms + order_binned) behind ONE memset of its 32 KiB histogram -- three launches where grid_setup / assign_cells /
         // scan_cells / fill_cells / order_cells are five (round 4; the workspace is the caller's and arrives dirty, so the
         // histogram cannot be left clean by the previous call as the handles do).  A cell with more than kPairsBinCap atoms
         // (nine times liquid density at the usual cell size) clears grid.ok: every row then scans all columns -- correct, slow.
-        if (periodic && N <= kPairsBinnedAtoms) {
+        // Half-width cells where they fit (walk_row: no binary searches).  The two-launch build holds at most kBinnedCells cells:
+        // at liquid density a half-cutoff grid of that size is ~14 000 atoms, so larger systems take the five-launch build (its
+        // scan is tiled) -- the grid costs ~6 us more there and pairs_cells_stage ~35 us less (100 000 atoms).
+        const bool fine = !(std::getenv("NNPOPS_PAIRS_FINE_GRID") && std::atoi(std::getenv("NNPOPS_PAIRS_FINE_GRID")) == 0);
+        cb.fine = fine ? 1 : 0;
+        if (periodic && N <= (fine ? kPairsFineBinnedAtoms : kPairsBinnedAtoms)) {
             hipLaunchKernelGGL(zero_words, dim3(div_up(kHistWords, 256)), dim3(256), 0, stream, (long long)kHistWords, w.hist);
             cb.hist = w.hist; cb.bins = w.bins; cb.bin_cap = kPairsBinCap;
         }
