@@ -248,7 +248,17 @@ int alloc_rows(nnpops_ani* h) {
     if ((rc = dev_alloc(&h->d_recB, (size_t)h->hp.N * h->cap_angular))) return rc;
     if ((rc = dev_alloc(&h->d_ids, (size_t)h->hp.N * h->cap_angular))) return rc;
     if ((rc = dev_alloc(&h->d_leg_force, (size_t)h->hp.N * h->cap_angular))) return rc;
-    return dev_alloc(&h->d_tri, (size_t)h->hp.N * triples_capacity(h->cap_angular));
+    if ((rc = dev_alloc(&h->d_tri, (size_t)h->hp.N * triples_capacity(h->cap_angular)))) return rc;
+    {   // the walk of the builders' triple loop follows the footprint of the lists (ani_kernels.h: decode_pair_folded)
+        int row_major = (size_t)h->hp.N * triples_capacity(h->cap_angular) * sizeof(int) > ((size_t)256 << 20) ? 1 : 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_TRI_ROW_MAJOR")) row_major = std::atoi(e) != 0;
+        if (row_major != h->hp.tri_row_major && h->d_params) {
+            h->hp.tri_row_major = row_major;
+            NNPOPS_HIP_TRY(hipMemcpy(h->d_params, &h->hp, sizeof(AniParams), hipMemcpyHostToDevice));
+        }
+        h->hp.tri_row_major = row_major;
+    }
+    return NNPOPS_OK;
 }
 
 // A contiguous stretch of the atoms, in cell order when the build used the cell grid (order = sorted atom ids) or in index
@@ -317,10 +327,13 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         // One launch per class of atoms (by their number of angular neighbours, nnpops_ani_check), each with the pair matrix its
         // atoms need; without classes -- no work order yet, several spans, $NNPOPS_ANI_BWD_CLASSES=0 -- one launch at full size.
         nnpops_ani::BwdClass whole{h->cap_angular, sp.w0, sp.nw, h->bwd_two_waves};
-        const bool by_class = h->bwd_by_class && !h->bwd_classes.empty() && sp.ang_order == h->d_work_order && sp.w0 == 0 && sp.nw == h->hp.N;
+        // (class launches take the kernels that read the gradient blocks through the L1 -- the ones with a CLASSES instantiation)
+        const bool by_class = h->bwd_by_class && !h->bwd_classes.empty() && sp.ang_order == h->d_work_order && sp.w0 == 0 && sp.nw == h->hp.N &&
+                              vec_ok && h->backward_kernel == 1 && !h->occ6;
         const nnpops_ani::BwdClass* classes = by_class ? h->bwd_classes.data() : &whole;
         const int nclasses = by_class ? (int)h->bwd_classes.size() : 1;
-        for (int c = 0; c < nclasses + (by_class ? 1 : 0); c++) {
+        static const bool debug_no_cleanup = std::getenv("NNPOPS_ANI_DEBUG_NO_CLEANUP") != nullptr;      // (timing experiments only: forces are wrong for outgrown atoms)
+        for (int c = 0; c < nclasses + (by_class && !debug_no_cleanup ? 1 : 0); c++) {
         const nnpops_ani::BwdClass& cl = c < nclasses ? classes[c] : whole;
         const int tile = std::min(cl.tile, h->cap_angular), cw0 = cl.w0, cnw = cl.nw;
         if (cnw <= 0) continue;
@@ -348,16 +361,28 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             if (h->fwd_literal && h->bwd_literal && h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4 && !h->occ6 && (mode == 1 || mode == 3))
                 k = mode == 1 ? ani_angular_backward_pair<TA, 8, 4, 5, 1, false, false, 2> : ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2>;
         }
+        if (by_class && c < nclasses) {                        // (mode is 1 or 3 here) the launch of a class
+            const bool uni = h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP;
+            k = mode == 1 ? (uni ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, 1, 1> : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, 0, 1>)
+                          : (uni ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false, false, 1, 1> : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false, false, 0, 1>);
+            if constexpr (NFRP == 8 && NFZP == 4) {
+                if (h->fwd_literal && h->bwd_literal && uni && h->hp.nFR == 8 && h->hp.nFZ == 4)
+                    k = mode == 1 ? ani_angular_backward_pair<TA, 8, 4, 5, 1, false, false, 2, 1> : ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 1>;
+            }
+        } else if (by_class) {                                 // the clean-up launch: one instantiation per wave count will do (its speed does not matter)
+            k = mode == 1 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, 0, 2> : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false, false, 0, 2>;
+        }
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
-        // (c == nclasses: the clean-up launch behind the classes -- every atom, full-size pair matrix, a grid the chip holds at once;
+        // (c == nclasses: the clean-up launch behind the classes -- every atom, full-size pair matrix, one workgroup per CU: 4.5 us when it has
+        //  nothing to do;
         //  it returns at once unless a class launch left an atom out: ani_angular_bwd.h)
         const int class_mode = !by_class ? 0 : c < nclasses ? 1 : 2;
-        const int groups = class_mode == 2 ? std::min(div_up(cnw, apg), 1024) : div_up(cnw, apg);
+        const int groups = class_mode == 2 ? std::min(div_up(cnw, apg), 256) : div_up(cnw, apg);
         hipLaunchKernelGGL(k, dim3(groups), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, tile, h->d_recA, h->d_recB, h->d_tri,
                            h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
-                           sp.ang_order, cw0, cnw, class_mode | (h->backprop_stamp << 2));
+                           sp.ang_order, cw0, cnw, h->backprop_stamp);
         }
     } else {
         auto k = ani_angular_backward<TA, NFRP, NFZP>;
@@ -649,7 +674,8 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_cnt_a, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_ro, (size_t)num_atoms))) return cleanup(rc);
     if ((rc = dev_alloc(&h->d_cnt_pos, (size_t)num_atoms))) return cleanup(rc);
-    if ((rc = dev_alloc(&h->d_centre_force, (size_t)num_atoms))) return cleanup(rc);
+    if ((rc = dev_alloc(&h->d_centre_force, (size_t)num_atoms + 1))) return cleanup(rc);      // (+ the class launches' flag word, ani_angular_bwd.h)
+    if (hipMemset(h->d_centre_force + num_atoms, 0, sizeof(float4)) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
     if ((rc = dev_alloc(&h->d_status, (size_t)kStatAlloc))) return cleanup(rc);
     if ((rc = alloc_rows(h))) return cleanup(rc);
     h->max_cells = num_atoms + 4096;
@@ -671,7 +697,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     if ((rc = dev_alloc(&h->d_class_tile, (size_t)num_atoms))) return cleanup(rc);
     if (hipMemset(h->d_class_tile, 255, (size_t)num_atoms) != hipSuccess) return cleanup(fail(NNPOPS_ERR_HIP, "memset failed"));
     hp.class_tile = h->d_class_tile;
-    hp.class_flag = h->d_status + kStatClassFlag;
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASSES")) h->bwd_by_class = std::atoi(e) != 0;
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_MIN")) h->bwd_class_min = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("NNPOPS_ANI_BWD_CLASS_ATOMS")) h->bwd_class_atoms = std::max(0, std::atoi(e));
@@ -910,7 +935,7 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     const int nspans = make_spans(h, spans);
     int rc = fork_streams(h, spans, nspans);
     if (rc != NNPOPS_OK) return rc;
-    h->backprop_stamp = h->backprop_stamp >= 0x1fffffff ? 1 : h->backprop_stamp + 1;
+    h->backprop_stamp = h->backprop_stamp >= 0x3fffffff ? 1 : h->backprop_stamp + 1;      // (as a float's bits: never a NaN pattern, never 0)
     KernelTimer merged_timer(h, NNPOPS_ANI_K_ANGULAR_BWD, spans[0].stream, /*merged=*/true);      // (spans the radial backward below)
     for (int q = 0; q < nspans; q++) {
         rc = dispatch_angular(h, false, angular_deriv, nullptr, spans[q]);

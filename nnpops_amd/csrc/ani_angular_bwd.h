@@ -111,24 +111,31 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 // global memory in the caller's order (GLDS must be false, NFRP / NFZP are not used).
 // UNI: one eta for every radial factor, one zeta for every angular factor, no padded factor slots (ani_angular_mfma.h):
 // 20 fewer wave-uniform constants in scalar registers.
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, int UNI = 0>
+// CLASSES: 1 -- the instantiation the launches by class of atoms use, 2 -- the clean-up launch behind them (class_word below); 0 -- the
+// class logic is not compiled in.  This kernel spills scalar registers as it is, and every value kept alive across the atom costs
+// time (measured on the 1 024-conformer batch: the three class launches 233 -> 243 us with the flag's address, the stamp and the
+// per-atom limits all alive in one instantiation): a class launch keeps ONE extra scalar (the stamp) and finds the flag behind the
+// last centre force, the clean-up launch -- whose speed does not matter -- carries the rest.
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, int UNI = 0, int CLASSES = 0>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
     const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, int tile, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
     const float* __restrict__ angular_grad, int ld_angular, float4* __restrict__ leg_force, float4* __restrict__ centre_force,
     int vec_ok, int NB, int lds_per_atom, const int* __restrict__ order, int w0, int nw,     // positions [w0, w0 + nw) of `order`
-    int class_word) {      // class_mode | stamp << 2
-    // class_mode (launches by class of atoms, nnpops_ani_check): 0 -- one launch for everybody, `tile` covers every record slot;
+    int class_word) {      // this backprop()'s stamp (CLASSES != 0)
+    // CLASSES (launches by class of atoms, nnpops_ani_check): 0 -- one launch for everybody, `tile` covers every record slot;
     // 1 -- the launch of one class: an atom that has outgrown the class since check() (more angular neighbours than `tile`) is LEFT
     // OUT here -- the launch says so by writing this backprop()'s stamp to class_flag -- and evaluated by the launch of mode 2, which
     // runs behind the classes with the full-size pair matrix, returns at once unless the flag carries the stamp, and takes exactly
     // the atoms the classes left out.  Forces are right whether or not anybody calls check() between the frames (graph replays,
     // check intervals > 1: a replayed stamp keeps the clean-up launch on from the first outgrown atom on, which is only slower).
-    // (flag and per-atom class limits through the parameter block -- P->class_flag, P->class_tile: read by class launches only;
-    //  one kernel argument instead of four: this kernel spills scalar registers as it is)
+    // (the flag is the word behind the last centre force, centre_force[N].x; the per-atom limits of the clean-up launch come through the
+    //  parameter block, P->class_tile)
     constexpr int BLK = NFRP * NFZP;
-    const int class_mode = class_word & 3, stamp = class_word >> 2;
-    if (class_mode == 2 && *P->class_flag != stamp) return;
+    const int stamp = class_word;
+    if constexpr (CLASSES == 2) {
+        if (__float_as_int(centre_force[C.N].x) != stamp) return;
+    }
     constexpr int NT = 64 * WPA;                               // lanes of the workgroup
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = lane_id();
@@ -202,11 +209,15 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         }
         int n, nro;
         clamp_counts(cnt_a[i], cnt_ro[i], cap, capA, n, nro);
-        if (class_mode == 1 && n > tile) {                     // outgrew its class: the clean-up launch evaluates it (uniform for the workgroup)
-            if (role == 0 && lane == 0) *P->class_flag = stamp;
-            continue;
+        if constexpr (CLASSES == 1) {
+            if (n > tile) {                                    // outgrew its class: the clean-up launch evaluates it (uniform for the workgroup)
+                if (role == 0 && lane == 0) centre_force[C.N].x = __int_as_float(stamp);
+                continue;
+            }
         }
-        if (class_mode == 2 && n <= (int)P->class_tile[i]) continue;   // clean-up launch: its class evaluated it
+        if constexpr (CLASSES == 2) {
+            if (n <= (int)P->class_tile[i]) continue;          // its class evaluated it
+        }
         n = min(n, tile);                                      // (tile >= capA outside class launches: a no-op)
         if (n < 2) {                                           // no triples (uniform for the workgroup): a lone leg carries no force
             if (n == 1 && role == 0 && lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);

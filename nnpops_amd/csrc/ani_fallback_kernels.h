@@ -18,18 +18,7 @@
 
 namespace nnpops {
 
-// (p, q) with p < q of the t-th pair in row-major order of the strict upper triangle of an n x n grid (the main kernels use the
-// folded enumeration of ani_kernels.h: decode_pair_folded)
-__device__ __forceinline__ void decode_pair(int t, int n, int& p, int& q) {
-    const float w = (float)(2 * n - 1);
-    int pp = (int)((w - fast_sqrt(fmaxf(w * w - 8.0f * (float)t, 0.f))) * 0.5f);
-    pp = max(0, min(pp, n - 2));
-    // offset(p) = p*(2n-p-1)/2 ; one fix-up step each way covers the rounding of the fast sqrt
-    if (__mul24(pp + 1, 2 * n - pp - 2) / 2 <= t) pp++;
-    if (__mul24(pp, 2 * n - pp - 1) / 2 > t) pp--;
-    p = pp;
-    q = t - __mul24(pp, 2 * n - pp - 1) / 2 + pp + 1;
-}
+__device__ __forceinline__ void decode_pair(int t, int n, int& p, int& q) { decode_pair_row_major(t, n, p, q); }
 
 // =============================================================================================
 // Radial backward + gather of the angular forces (owner computes; the only writer of

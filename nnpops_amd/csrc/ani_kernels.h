@@ -121,7 +121,7 @@ struct AniParams {
     int* bucket_offsets;             // [N][NB + 1] device array the builders fill: offsets of the buckets in an atom's triple list
     const unsigned char* class_tile; // [N] pair-matrix edge of the backward launch this atom was put in by check() (255: no limit);
                                      //     a builder that finds more angular neighbours than that flags kStatOverflow bit 3
-    int* class_flag;                 // the backward's class launches write their stamp here when they leave an atom out (ani_angular_bwd.h)
+    int tri_row_major;               // builders walk the pairs of an atom row-major (1) or as a folded rectangle (0): decode_pair_folded
     // matrix-core forward kernel (ani_angular_mfma.h)
     int m_of_c[kMaxAngularFns];      // canonical slot a*NFZP+z -> function m, -1 for padding slots
     int fwd_split;                   // K: every species pair that can occur is shared by K quads (1, 2, 4 or 8)
@@ -145,8 +145,7 @@ struct AngularConsts {
 };
 
 // status words reported by nnpops_ani_check
-enum { kStatOverflow = 0, kStatMaxRow = 1, kStatMaxAngular = 2, kStatWords = 4,
-       kStatClassFlag = 4, kStatAlloc = 8 };      // (word 4 is not one of check()'s: the class launches' flag, ani_angular_bwd.h; never cleared)
+enum { kStatOverflow = 0, kStatMaxRow = 1, kStatMaxAngular = 2, kStatWords = 4, kStatAlloc = 8 };
 
 __host__ __device__ inline int triples_capacity(int capA) { return capA * (capA - 1) / 2; }
 
@@ -203,7 +202,23 @@ __device__ __forceinline__ void clamp_counts(int raw_a, int raw_ro, int cap, int
 // 2e-5 where the nearest quotient boundary is 0.5 / 255 away).  ~9 vector instructions where the row-major decode with its square
 // root, two correction steps and two 24-bit products took ~25; the ORDER in which a wave meets the pairs is irrelevant: every pair
 // computes its own place in the bucket-major list.
+// Which walk a handle takes is decided by where the lists go: while everything a build writes stays inside the 256 MiB Infinity
+// Cache the builders are bound by instruction issue and the cheaper decode wins (10 000-atom liquid 19.9 -> 19.1 us, a 7 600-atom
+// block of conformers 18.3 -> 16.4 us); the 1 024-conformer batch writes 490 MB of list capacity, is bound by its stores, and loses
+// 4 % with the folded walk (two rows of different species per wave: the 4-byte stores of one instruction touch more lines) --
+// AniParams::tri_row_major, set by the host from N x capacity (ani.hip: alloc_rows).
 __device__ __forceinline__ int folded_pair_count(int n) { return __mul24((n + 1) >> 1, n - 1); }
+// (p, q) with p < q of the t-th pair in row-major order of the strict upper triangle of an n x n grid
+__device__ __forceinline__ void decode_pair_row_major(int t, int n, int& p, int& q) {
+    const float w = (float)(2 * n - 1);
+    int pp = (int)((w - fast_sqrt(fmaxf(w * w - 8.0f * (float)t, 0.f))) * 0.5f);
+    pp = max(0, min(pp, n - 2));
+    // offset(p) = p*(2n-p-1)/2 ; one fix-up step each way covers the rounding of the fast sqrt
+    if (__mul24(pp + 1, 2 * n - pp - 2) / 2 <= t) pp++;
+    if (__mul24(pp, 2 * n - pp - 1) / 2 > t) pp--;
+    p = pp;
+    q = t - __mul24(pp, 2 * n - pp - 1) / 2 + pp + 1;
+}
 __device__ __forceinline__ bool decode_pair_folded(int t, int n, float inv_nm1, int& p, int& q) {
     const int R = (int)(((float)t + 0.5f) * inv_nm1);
     const int C = t - __mul24(R, n - 1);
@@ -363,11 +378,14 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
     // binary search over the bucket offsets and a division or a square root per lane (~100 vector instructions per batch
     // of 64 against ~45).  Same list, scattered 4-byte stores inside the atom's own few cache lines.
     wave_fence();                                              // (G.ssp, G.boff)
-    const int E = T > 0 ? folded_pair_count(n) : 0;            // (n <= 1: no pairs, and no 1 / (n - 1))
+    // (P->tri_row_major: the handle asks for the row-major walk -- see AniParams)
+    const bool row_major = P->tri_row_major != 0;
+    const int E = T <= 0 ? 0 : row_major ? T : folded_pair_count(n);      // (n <= 1: no pairs, and no 1 / (n - 1))
     const float inv_nm1 = __builtin_amdgcn_rcpf((float)max(n - 1, 1));
     for (int t = lane; t < E; t += 64) {
         int p, q;
-        if (!decode_pair_folded(t, n, inv_nm1, p, q)) continue;
+        if (row_major) decode_pair_row_major(t, n, p, q);
+        else if (!decode_pair_folded(t, n, inv_nm1, p, q)) continue;
         const int A = G.ssp[p], B = G.ssp[q];                  // A <= B: the slots are sorted by species
         const int bucket = __mul24(A, S) - __mul24(A, A - 1) / 2 + (B - A);        // upper-triangular row-major, as AniParams::bkt_a / bkt_b
         const int ia = p - G.gs[A], ib = q - G.gs[B], gb = G.gn[B];

@@ -51,14 +51,13 @@ PATCHES = {
          f"        if ({PM} & 32768) return;\n        if constexpr (DYN) {{\n            // the quads of a bucket are consecutive and inside one wave", 1),
     ],
     "ani_angular_bwd.h": [
-        ("            if (t < T && ((word >> 8) & 0xff) < tile) {",
-         f"            if (t < T && ((word >> 8) & 0xff) < tile && !({PM} & 512)) {{", 1),
+        ("            if (t < T) {\n                const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;",
+         f"            if (t < T && !({PM} & 512)) {{\n                const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;", 1),
         ("        if (role == 0) {\n            float cx = 0.f, cy = 0.f, cz = 0.f;\n",
          f"        if (role == 0 && !({PM} & 1024)) {{\n            float cx = 0.f, cy = 0.f, cz = 0.f;\n", 1),
     ],
     "ani_radial_bwd.h": [
-        ("        if (base == 0) {                                       // angular neighbours are the first na <= CAPA <= 64 of the row\n",
-         f"        if (base == 0 && !({PM} & 2048)) {{\n", 1),
+        ("        const bool look = base == 0 && na > 0;\n", f"        const bool look = base == 0 && na > 0 && !({PM} & 2048);\n", 1),
         ("        for (int c = 0; c < NR4; c++) gj[c] = grow[c];\n",
          f"        for (int c = 0; c < NR4; c++) gj[c] = ({PM} & 4096) ? make_float4(0.f, 0.f, 0.f, 0.f) : grow[c];\n", 1),
     ],
