@@ -133,6 +133,12 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
     const int lane = lane_id();
     int found = 0;
     const T inv_x = periodic ? T(1) / box[0] : T(0), inv_y = periodic ? T(1) / box[4] : T(0), inv_z = periodic ? T(1) / box[8] : T(0);
+    // cutoff < 0.49 of the shortest box edge (a margin of 1 % where the tie test's is 1e-6): see visit()
+    bool no_ties = false;
+    if (periodic && !(periodic & 4)) {
+        const T edge = fmin(fmin(fabs(box[0]), fabs(box[4])), fabs(box[8]));
+        no_ties = cutoff2 < T(0.49 * 0.49) * edge * edge;
+    }
     auto visit = [&](bool have, int col, Vec3<T> d) {
         bool keep = false;
         T d2 = 0;
@@ -142,11 +148,17 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
             // by reciprocal is within 2e-7 |q| (fp32) of the divided one, so unless it lies that close to a half-integer both
             // round to the same integer; a wave that sees such a candidate redoes the batch with the division (rare: uniform
             // branch).  Three IEEE divisions and three round() were 51 of the ~150 instructions per batch.
+            // (round 5) No candidate that ends up INSIDE the cutoff can sit near a tie when the cutoff is safely below half of every
+            // box edge: its reduced component is at most cutoff / edge < 1/2 - margin away from the integer it rounds to, on every
+            // axis (the sequential z, y, x reduction of a triclinic cell included: the component left after each step is a component
+            // of the final displacement).  A candidate that does sit near a tie is therefore outside the cutoff with either image --
+            // rejected both ways, its displacement never written.  `no_ties` (wave-uniform, from the box) drops the test: 12 of the
+            // ~100 vector instructions per batch of 64 candidates.
             const Vec3<T> d0 = d;
             bool near = false;
             auto rq = [&](T v, T inv) {
                 const T q = v * inv, s = rint(q);
-                near = near || (fabs(q - s) > T(0.5) - kTieTol<T>() * (fabs(q) + T(1)));
+                if (!no_ties) near = near || (fabs(q - s) > T(0.5) - kTieTol<T>() * (fabs(q) + T(1)));
                 return s;
             };
             const T s3 = rq(d.z, inv_z);
@@ -155,7 +167,7 @@ __device__ __forceinline__ int walk_row(int row, const T* __restrict__ pos, cons
             d.x -= s2 * box[3]; d.y -= s2 * box[4];
             const T s1 = rq(d.x, inv_x);
             d.x -= s1 * box[0];
-            if ((periodic & 2) || __any(active && near)) {           // (bit 1: $NNPOPS_PAIRS_DIVIDE=1, the division for every candidate)
+            if ((periodic & 2) || (!no_ties && __any(active && near))) {           // (bit 1: $NNPOPS_PAIRS_DIVIDE=1, the division for every candidate)
                 d = d0;
                 const T e3 = round(d.z / box[8]);
                 d.x -= e3 * box[6]; d.y -= e3 * box[7]; d.z -= e3 * box[8];
@@ -580,7 +592,8 @@ int forward_impl(int N, const T* pos, const T* box, double cutoff, long long max
         launch_cell_build(stream, N, fpos, fbox, periodic != 0, (float)cutoff, nullptr, cb);
         const dim3 rgrid(div_up(N, 4)), rblock(256);       // one wave per row
         Staged<T>* st_rec = (Staged<T>*)w.st_rec;
-        const int periodic_flags = periodic | ((periodic && std::getenv("NNPOPS_PAIRS_DIVIDE") && std::atoi(std::getenv("NNPOPS_PAIRS_DIVIDE"))) ? 2 : 0);
+        const int periodic_flags = periodic | ((periodic && std::getenv("NNPOPS_PAIRS_DIVIDE") && std::atoi(std::getenv("NNPOPS_PAIRS_DIVIDE"))) ? 2 : 0) |
+                                   ((periodic && std::getenv("NNPOPS_PAIRS_TIE_TEST") && std::atoi(std::getenv("NNPOPS_PAIRS_TIE_TEST"))) ? 4 : 0);      // (4: keep the tie test, A/B)
         hipLaunchKernelGGL(pairs_cells_stage<T>, rgrid, rblock, 0, stream, N, pos, box, periodic_flags, cutoff2, w.grid, w.cell_start,
                            w.atom_cell, w.sorted_atom, w.sorted_pos, w.st_col, st_rec, w.row_count, ticket);
         hipLaunchKernelGGL(scan_rows, dim3(nscan), dim3(kScanBlock), 0, stream, N, w.row_count, w.row_offset, w.block_prefix, ticket,
