@@ -675,3 +675,37 @@ def test_backward_classes_regroup_when_an_atom_outgrows_its_class(monkeypatch):
     grad = sym.backprop(torch.tensor(wr, device=dev), torch.tensor(wa, device=dev)).cpu().numpy()
     assert sym.overflow_word() & 8                                    # an atom did outgrow its class (the builders say so) ...
     assert np.array_equal(grad, checked)                              # ... and its forces are those of the checked evaluation
+
+
+def test_pair_walk_of_the_builders_does_not_change_the_lists(monkeypatch):
+    """Round 5: the builders' triple loop walks the pairs of an atom as a folded rectangle (decode_pair_folded) or row-major (handles
+    whose lists exceed the Infinity Cache); either walk writes the SAME bucket-major list, so AEV and forces must agree bit for bit --
+    on a liquid (cell-grid builder) and on a batch of molecules (all-pairs builder, atoms with even and odd neighbour counts)."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    dev = torch.device("cuda:0")
+    pos, species, box = workloads.random_box(3000, density=0.1, seed=21, n_species=7)
+    mols = [workloads.conformer(50 + m, seed=300 + m) for m in range(12)]
+    mpos = np.concatenate([m[0] for m in mols]).astype(np.float32)
+    mspecies = np.concatenate([m[1] for m in mols]).astype(np.int32)
+    offsets = np.concatenate([[0], np.cumsum([len(m[0]) for m in mols])]).astype(np.int32)
+    results = {}
+    for walk in ("0", "1"):
+        monkeypatch.setenv("NNPOPS_ANI_TRI_ROW_MAJOR", walk)
+        out = []
+        for p, s, b, off in ((pos, species, box, None), (mpos, mspecies, None, offsets)):
+            sym = AniSymmetryFunctions(7, 5.1, 3.5, s, rf, af, periodic=b is not None)
+            if off is not None:
+                sym.set_molecules(off)
+            tp = torch.tensor(p, device=dev)
+            tb = torch.tensor(b, device=dev) if b is not None else None
+            radial, angular = sym.compute(tp, tb)
+            gen = torch.Generator(device=dev).manual_seed(9)
+            g_r = torch.randn(radial.shape, device=dev, generator=gen)
+            g_a = torch.randn(angular.shape, device=dev, generator=gen)
+            out.append((radial.cpu().numpy(), angular.cpu().numpy(), sym.backprop(g_r, g_a).cpu().numpy()))
+        results[walk] = out
+    for a, b in zip(results["0"], results["1"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert np.abs(results["0"][0][1]).max() > 0 and np.abs(results["0"][1][2]).max() > 0

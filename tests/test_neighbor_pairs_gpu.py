@@ -245,3 +245,45 @@ def test_division_free_cell_split_is_exact_on_grids_of_millions_of_cells(tmp_pat
                            os.path.join(root, "tools", "ubench", "split_cell_check.hip"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("triclinic", [False, True])
+def test_fine_grid_and_no_tie_test_change_nothing(monkeypatch, dtype, triclinic):
+    """Round 5: half-width cells walked whole (no per-cell binary search) and the reciprocal minimum image without its tie test
+    (cutoff below 0.49 of the shortest edge) must give the list of the round-4 path -- full-width cells, prefixes, tie test --
+    pair for pair and bit for bit, in a cubic and in a triclinic box, in both precisions; and both must be the oracle's list."""
+    from nnpops_amd import workloads
+    n, cutoff = 12000, 5.2                                              # (above the all-pairs threshold: the cell-grid path)
+    if triclinic:
+        pos, _, box = workloads.triclinic_box(n, seed=11, density=0.1)
+    else:
+        pos, _, box = workloads.random_box(n, density=0.1, seed=11, n_species=7)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    pos, box = pos.astype(npdt), box.astype(npdt)
+    max_pairs = 40 * n
+    monkeypatch.setenv("NNPOPS_PAIRS_FINE_GRID", "0")
+    monkeypatch.setenv("NNPOPS_PAIRS_TIE_TEST", "1")
+    old = _run(pos, cutoff, max_pairs, box, dtype)
+    monkeypatch.delenv("NNPOPS_PAIRS_FINE_GRID")
+    monkeypatch.delenv("NNPOPS_PAIRS_TIE_TEST")
+    new = _run(pos, cutoff, max_pairs, box, dtype)
+    assert old[3] == new[3] and 0 < new[3] < max_pairs
+    k = new[3]
+    a, b = _sorted(old[0][:, :k], old[1][:k], old[2][:k]), _sorted(new[0][:, :k], new[1][:k], new[2][:k])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    rows = new[0][0, :k]
+    assert np.all(np.diff(rows) >= 0) and np.all(new[0][1, :k] < rows)   # rows ascending, column below row: the layout of the cell path
+    assert np.all(new[0][:, k:] == -1) and np.all(np.isnan(new[2][k:]))
+    # the oracle on a sample of rows (brute force over all columns, the reference's arithmetic)
+    rng = np.random.default_rng(5)
+    starts = np.searchsorted(rows, np.arange(n + 1))
+    inv = np.linalg.inv(box.astype(np.float64))
+    for row in rng.integers(1, n, size=40):
+        d = pos[row].astype(np.float64) - pos[:row].astype(np.float64)
+        for axis in (2, 1, 0):                                          # the reference's z, y, x single-round rule
+            d -= np.round(d[:, axis] / box[axis, axis])[:, None] * box[axis].astype(np.float64)
+        want = np.nonzero((d * d).sum(1) <= cutoff * cutoff)[0]
+        got = np.sort(new[0][1, starts[row]:starts[row + 1]])
+        near = np.abs(np.sqrt((d * d).sum(1)) - cutoff) < 1e-4            # (pairs within rounding of the cutoff may go either way)
+        assert set(want[~near[want]]) <= set(got) <= set(want) | set(np.nonzero(near)[0]), row
