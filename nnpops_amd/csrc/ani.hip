@@ -64,6 +64,9 @@ struct nnpops_ani {
                                     // 33.7 -> 29.6 us, 3 000: 49.5 -> 46.3) -- at 5 000 it breaks even and at 10 000 its lower
                                     // occupancy makes it equal to the two launches; $NNPOPS_ANI_FUSE=0 / 1 forces
     bool rbwd_lanes = true;         // radial backward with a lane per neighbour (ani_radial_bwd.h) where rows read as float4
+    int scatter_mode = -1;          // leg forces stored in the receiving atom's row by the two-wave angular backward (ani_angular_bwd.h):
+                                    // -1 where every backward launch runs two waves per atom (dense systems), 0 / 1 forced ($NNPOPS_ANI_SCATTER)
+    bool scatter_now = false;       // ... decided by backprop() for the call in progress
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
     int fwd_occ = 7;                // A/B: register budget of the forward kernel (waves per SIMD)
@@ -270,6 +273,13 @@ struct Span {
     const int* ang_order;      // what the two angular kernels walk: the work-sorted schedule (check() builds it), else `order`
 };
 
+// The radial backward with a lane per neighbour (ani_radial_bwd.h) takes this call's gradient array?
+bool radial_lanes(const nnpops_ani* h, const float* radial_deriv) {
+    const int nr4 = h->hp.nR / 4;
+    return h->rbwd_lanes && h->hp.nR % 4 == 0 && nr4 >= 1 && nr4 <= 8 && h->ld_radial % 4 == 0 &&
+           (h->cap_angular == 32 || h->cap_angular == 64) && (reinterpret_cast<uintptr_t>(radial_deriv) & 15) == 0;
+}
+
 // ---- kernel dispatch over (TORCHANI, NFRP, NFZP) ----
 template <bool TA, int NFRP, int NFZP>
 int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float* out, const Span& sp) {
@@ -344,12 +354,12 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         // (round 4: what decides is the work per atom, not the LDS -- with the classes above every class of the conformer batch, the
         //  32-slot one included, is faster with two waves per atom: 304 us in one launch, 275 by class with this rule on LDS, 246
         //  with two waves everywhere; the 153-triple atoms of a liquid stay with one wave, 15.8 against 25 us)
-        if (mode == 1 && !h->backward_forced && (cl.two_waves || ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, false) > 16 * 1024)) mode = 3;
+        if (mode == 1 && !h->backward_forced && (cl.two_waves || h->scatter_now || ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, false) > 16 * 1024)) mode = 3;
         if (!vec_ok && (mode == 1 || mode == 3)) mode++;
         const bool glds = mode == 2 || mode == 4;
         const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, glds) + 15) & ~(size_t)15;
         void (*k)(const AniParams*, const AngularConsts, int, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
-                  float4*, float4*, int, int, int, const int*, int, int, int) =
+                  float4*, float4*, const int*, float4*, int, int, int, const int*, int, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
                          : (h->fwd_uniform && h->hp.nFR == NFRP && h->hp.nFZ == NFZP) ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, 1>
                                                                                        : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false>)
@@ -372,6 +382,15 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         } else if (by_class) {                                 // the clean-up launch: one instantiation per wave count will do (its speed does not matter)
             k = mode == 1 ? ani_angular_backward_pair<TA, NFRP, NFZP, 5, 1, false, false, 0, 2> : ani_angular_backward_pair<TA, NFRP, NFZP, 5, 2, false, false, 0, 2>;
         }
+        bool scat = false;
+        if constexpr (NFRP == 8 && NFZP == 4) {                // leg forces into the receivers' rows: backprop() decided (scatter_now) -- two waves, literal constants
+            if (h->scatter_now && mode == 3) {
+                scat = true;
+                k = !by_class ? ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 0, true>
+                  : c < nclasses ? ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 1, true>
+                                 : ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 2, true>;
+            }
+        }
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
         const int threads = mode >= 3 ? 128 : 64 * apg;
         if (lb * apg > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lb * apg)));
@@ -381,7 +400,8 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         const int class_mode = !by_class ? 0 : c < nclasses ? 1 : 2;
         const int groups = class_mode == 2 ? std::min(div_up(cnw, apg), 256) : div_up(cnw, apg);
         hipLaunchKernelGGL(k, dim3(groups), dim3(threads), lb * apg, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, tile, h->d_recA, h->d_recB, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, vec_ok, h->hp.NB, (int)lb,
+                           h->d_cnt_a, h->d_cnt_ro, grad_or_null, h->ld_angular, h->d_leg_force, h->d_centre_force, h->d_ids,
+                           scat ? h->d_leg_force : nullptr, vec_ok, h->hp.NB, (int)lb,
                            sp.ang_order, cw0, cnw, h->backprop_stamp);
         }
     } else {
@@ -426,7 +446,7 @@ int launch_generic(nnpops_ani* h, bool forward, const float* g, float* out, cons
         auto k = ani_angular_backward_pair<TA, 4, 4, 4, 1, false, true>;
         if (lb > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
         hipLaunchKernelGGL(k, dim3(N), dim3(64), lb, sp.stream, h->d_params, h->ac, h->cap, h->cap_angular, h->cap_angular, h->d_recA, h->d_recB, h->d_tri,
-                           h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, 0, h->hp.NB, (int)lb, nullptr, 0, N, 0);
+                           h->d_cnt_a, h->d_cnt_ro, g, h->ld_angular, h->d_leg_force, h->d_centre_force, h->d_ids, nullptr, 0, h->hp.NB, (int)lb, nullptr, 0, N, 0);
     }
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
@@ -637,6 +657,7 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_LPT")) h->lpt = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_ANI_CELL_ATOMS")) h->cell_atoms = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("NNPOPS_ANI_RBWD")) h->rbwd_lanes = std::atoi(e) != 0;
+        if (const char* e = std::getenv("NNPOPS_ANI_SCATTER")) h->scatter_mode = std::atoi(e) != 0 ? 1 : 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FINE_GRID")) h->fine_grid = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_ROWLDS")) h->fwd_row_via_lds = std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_OCC")) h->fwd_occ = std::atoi(e);
@@ -936,6 +957,15 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
     int rc = fork_streams(h, spans, nspans);
     if (rc != NNPOPS_OK) return rc;
     h->backprop_stamp = h->backprop_stamp >= 0x3fffffff ? 1 : h->backprop_stamp + 1;      // (as a float's bits: never a NaN pattern, never 0)
+    {   // Leg forces straight into the receiving atoms' rows?  Only where EVERY launch of the angular backward runs two waves per atom
+        // (the second wave does the look-up under the first one's row sums) and the radial backward is the kernel that reads such rows:
+        // dense systems (the atoms average 200 triples or more, check()), the pair-matrix kernels with 16-byte gradient loads.
+        const bool vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && (reinterpret_cast<uintptr_t>(angular_deriv) & 15) == 0;
+        const bool can = !h->generic && h->backward_kernel == 1 && !h->backward_forced && vec_ok && pair_backward_fits(h) &&
+                         radial_lanes(h, radial_deriv) && h->hp.nR == 16 && h->nstreams == 1 &&
+                         h->nfrp == 8 && h->nfzp == 4 && h->fwd_literal && h->bwd_literal && h->fwd_uniform && h->hp.nFR == 8 && h->hp.nFZ == 4 && !h->occ6;
+        h->scatter_now = can && (h->scatter_mode < 0 ? h->bwd_two_waves : h->scatter_mode != 0);
+    }
     KernelTimer merged_timer(h, NNPOPS_ANI_K_ANGULAR_BWD, spans[0].stream, /*merged=*/true);      // (spans the radial backward below)
     for (int q = 0; q < nspans; q++) {
         rc = dispatch_angular(h, false, angular_deriv, nullptr, spans[q]);
@@ -950,15 +980,17 @@ int nnpops_ani_backprop_strided(nnpops_ani_t h, const float* radial_deriv, int r
         const Span& sp = spans[q];
         KernelTimer timer(h, NNPOPS_ANI_K_RADIAL_BWD, sp.stream);
         const int nr4 = h->hp.nR / 4;
-        const bool lanes = h->rbwd_lanes && h->hp.nR % 4 == 0 && nr4 >= 1 && nr4 <= 8 && h->ld_radial % 4 == 0 &&
-                           (h->cap_angular == 32 || h->cap_angular == 64) && (reinterpret_cast<uintptr_t>(radial_deriv) & 15) == 0;
+        const bool lanes = radial_lanes(h, radial_deriv);
         if (lanes) {
             // a lane per neighbour: only this atom's own gradient row is staged in LDS
             const int lw = (int)(((size_t)h->hp.S * h->hp.nR * sizeof(float) + 15) & ~(size_t)15);
             const int wpg = kWavesPerGroup;
             const bool wide = h->cap_angular == 64;
             auto k = ani_radial_backward_lanes<4, 32>;
-            if (nr4 == 4 && sp.nw <= kRbwdLatencyAtoms) k = wide ? ani_radial_backward_lanes<4, 64, true> : ani_radial_backward_lanes<4, 32, true>;
+            if (h->scatter_now) {                              // (reads the legs from the atom's own row; sixteen radial functions: backprop() asks for nothing else)
+                k = sp.nw <= kRbwdLatencyAtoms ? (wide ? ani_radial_backward_lanes<4, 64, true, true> : ani_radial_backward_lanes<4, 32, true, true>)
+                                                              : (wide ? ani_radial_backward_lanes<4, 64, false, true> : ani_radial_backward_lanes<4, 32, false, true>);
+            } else if (nr4 == 4 && sp.nw <= kRbwdLatencyAtoms) k = wide ? ani_radial_backward_lanes<4, 64, true> : ani_radial_backward_lanes<4, 32, true>;
             else
             switch (nr4) {
                 case 1: k = wide ? ani_radial_backward_lanes<1, 64> : ani_radial_backward_lanes<1, 32>; break;
@@ -1216,10 +1248,11 @@ int nnpops_ani_describe(nnpops_ani_t h, char* text, int capacity) {
     const bool shape2x = h->nfrp == 8 && h->nfzp == 4;
     std::snprintf(text, (size_t)capacity,
                   "forward=%s backward=%d generic=%d uniform=%d grid=%d literal=%d dynamic_quads=%d fused_build=%d cap=%d cap_angular=%d "
-                  "chunk=%d classes=%d cells=%d",
+                  "chunk=%d classes=%d cells=%d scatter=%d row_major_walk=%d",
                   h->forward_kernel == 2 ? "mfma" : h->forward_kernel == 1 ? "chunked" : "merge", h->backward_kernel, (int)h->generic,
                   (int)uni, (int)(uni && h->fwd_grid), (int)(uni && h->fwd_grid && shape2x && h->fwd_literal), (int)h->fwd_dynamic,
-                  (int)(h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0), h->cap, h->cap_angular, h->fwd_chunk, (int)h->bwd_classes.size(), (int)h->last_used_cells);
+                  (int)(h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0), h->cap, h->cap_angular, h->fwd_chunk, (int)h->bwd_classes.size(), (int)h->last_used_cells,
+                  (int)h->scatter_now, h->hp.tri_row_major);      // (scatter: the last backprop() stored the leg forces in the receivers' rows)
     return NNPOPS_OK;
 }
 

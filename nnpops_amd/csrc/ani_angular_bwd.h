@@ -105,6 +105,9 @@ template <int NFRP, int NFZP>
 __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool glds) {
     return (size_t)capA * 2 * sizeof(float4) + (glds ? (size_t)NB * NFRP * NFZP * sizeof(float) : 0) +
            ((size_t)capA * (capA + 1) + (size_t)capA * (capA - 1) / 2) * sizeof(float);
+    // (LDS is handed out in 128 pieces of 1 280 bytes per CU: at 64 record slots this is 26 752 bytes = 21 pieces, six workgroups per
+    //  CU; 256 bytes more -- a table of the receivers' slots, round 5 -- were 22 pieces, five workgroups, and 12 % of the kernel's speed:
+    //  the table lives in a dead field of the records instead)
 }
 
 // GENERIC: the function list does not factor (ani_angular_generic.h): functions evaluated one by one, gradients read from
@@ -116,11 +119,15 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 // time (measured on the 1 024-conformer batch: the three class launches 233 -> 243 us with the flag's address, the stamp and the
 // per-atom limits all alive in one instantiation): a class launch keeps ONE extra scalar (the stamp) and finds the flag behind the
 // last centre force, the clean-up launch -- whose speed does not matter -- carries the rest.
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, int UNI = 0, int CLASSES = 0>
+// SCAT: the two-wave instantiation that stores the leg forces in the receiving atoms' rows (see "where the leg forces go" below);
+// everybody else is compiled without that code -- written into one kernel behind a run-time pointer test it cost the two-wave
+// kernel a third of its speed (18-22 spilled scalar registers: 32.6 -> 44 us on a 7 600-atom block of conformers).
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, int UNI = 0, int CLASSES = 0, bool SCAT = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
     const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, int tile, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
     const float* __restrict__ angular_grad, int ld_angular, float4* __restrict__ leg_force, float4* __restrict__ centre_force,
+    const int* __restrict__ ids_g, float4* __restrict__ recv,      // recv != NULL (two waves per atom only): see "where the leg forces go"
     int vec_ok, int NB, int lds_per_atom, const int* __restrict__ order, int w0, int nw,     // positions [w0, w0 + nw) of `order`
     int class_word) {      // this backprop()'s stamp (CLASSES != 0)
     // CLASSES (launches by class of atoms, nnpops_ani_check): 0 -- one launch for everybody, `tile` covers every record slot;
@@ -161,6 +168,46 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     float* grow = (float*)cursor;         if (GLDS) cursor += (size_t)NB * BLK * sizeof(float);   // upstream gradient row, canonical [bucket][a][z]
     float* Ma = (float*)cursor;           // alpha[tile][tile + 1]: Ma[e][x] = coefficient of A_e in the force of triple {e, x} on e
     float* Mb = Ma + tile * tstride;      // beta, once per unordered pair (p < q), triangular
+    // (SCAT: leg e -> slot of THIS atom in the records of the atom on that leg is kept in recB[e].x -- fc of the leg, dead once the
+    //  triples are done; .w, the leg's atom id, is still needed)
+    static_assert(!SCAT || WPA == 2, "the look-up of the receivers' slots is the second wave's work");
+
+    // Where the leg forces go.  One wave per atom (liquids): parked in leg_force[i][e]; every atom then finds itself in the id rows of
+    // its angular neighbours inside the radial backward kernel.  Two waves per atom (dense systems: molecules, where a 64-slot id row
+    // is 256 bytes and that search is most of the radial backward's 7.7 KB per atom) and recv != NULL (round 5): the SECOND wave, idle
+    // while the first adds up the rows of the pair matrix, looks the slot of this atom up in the id row of the atom on every leg, and
+    // the force is stored straight into the RECEIVING atom's row, recv[j][slot of i in the records of j] -- one writer per entry (the
+    // pair relation is symmetric: the same r^2 from both ends), the receiver reads its own row: contiguous, no search, no atomics,
+    // bitwise reproducible.  (With ONE wave per atom the same look-up was measured at +7 ... +16 us on a 15 us kernel at its
+    // register limit, docs/LAB_NOTEBOOK_r05.md: it stays in the radial backward there.)
+    // An id row is capA ints = capA / 4 16-byte pieces; QL lanes scan one row, RPP rows per pass of the wave, 8 passes in flight.
+    auto lookup_receiver_slots = [&](int i, int n) {
+        constexpr int NP = 8;
+        const int ql_shift = 29 - __builtin_clz((unsigned)capA);      // log2(capA / 4); capA is a power of two >= 32
+        const int QL = 1 << ql_shift, rpp_shift = 6 - ql_shift;
+        for (int t0 = 0; (t0 << rpp_shift) < n; t0 += NP) {
+            int4 idv[NP];
+#pragma unroll
+            for (int t = 0; t < NP; t++) {
+                const int et = (lane >> ql_shift) + ((t0 + t) << rpp_shift);
+                idv[t] = make_int4(-1, -1, -1, -1);
+                if (et < n) {
+                    const int jt = __float_as_int(recB[et].w) & kIdMask;
+                    idv[t] = reinterpret_cast<const int4*>(ids_g + (size_t)jt * capA)[lane & (QL - 1)];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NP; t++) {
+                const int et = (lane >> ql_shift) + ((t0 + t) << rpp_shift);
+                int slot = -1;
+                slot = idv[t].x == i ? 0 : slot;
+                slot = idv[t].y == i ? 1 : slot;
+                slot = idv[t].z == i ? 2 : slot;
+                slot = idv[t].w == i ? 3 : slot;
+                if (slot >= 0) recB[et].x = __int_as_float(4 * (lane & (QL - 1)) + slot);
+            }
+        }
+    };
 
     static_assert(!(GENERIC && GLDS), "generic function lists read their gradients from global memory");
     // (constants from the by-value block, padded on the host: no dependent scalar loads in the workgroup's prologue, ani_kernels.h)
@@ -220,7 +267,15 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         }
         n = min(n, tile);                                      // (tile >= capA outside class launches: a no-op)
         if (n < 2) {                                           // no triples (uniform for the workgroup): a lone leg carries no force
-            if (n == 1 && role == 0 && lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n == 1 && role == 0) {
+                if constexpr (SCAT) {                          // ... and says so in the row of the atom on it
+                    const int j = ids_g[(size_t)i * capA];
+                    for (int e = lane; e < capA; e += 64)
+                        if (ids_g[(size_t)j * capA + e] == i) recv[(size_t)j * capA + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    if (lane == 0) leg_force[(size_t)i * capA] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
             continue;
         }
         const int T = (n * (n - 1)) / 2;
@@ -273,6 +328,12 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         sync();
 
         // ---------------- row sums (first wave):  F_e = (sum_x alpha[e][x]) A_e + sum_x beta{e,x} A_x ----------------
+        if constexpr (SCAT) {
+            if (role == 1) {                                   // (the second wave meanwhile: the receivers' slots)
+                lookup_receiver_slots(i, n);
+                sync();                                        // pairs with the one in front of the first wave's first store
+            }
+        }
         if (role == 0) {
             float cx = 0.f, cy = 0.f, cz = 0.f;
             const int el = lane & 31, half = lane >> 5;
@@ -305,10 +366,16 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                     fx += own * Ae.x; fy += own * Ae.y; fz += own * Ae.z;
                 }
                 fx += __shfl_xor(fx, 32, 64); fy += __shfl_xor(fy, 32, 64); fz += __shfl_xor(fz, 32, 64);
-                // No scatter: the force on leg e of this atom is parked in leg_force[i][e] (record order) and the reaction
-                // on the centre in centre_force[i]; ani_radial_backward, which owns position_deriv[j], picks the legs up.
+                if constexpr (SCAT) {
+                    if (eb == 0) sync();                       // the receivers' slots are there
+                }
+                // The force on leg e goes to the atom on that leg (recv, see above) or is parked in leg_force[i][e] (record order); the
+                // reaction on the centre in centre_force[i]; the radial backward, which owns position_deriv[j], picks them up.
                 if (half == 0 && e < n) {
-                    leg_force[(size_t)i * capA + e] = make_float4(fx, fy, fz, 0.f);
+                    if constexpr (SCAT) {
+                        const float4 leg = recB[e];
+                        recv[(size_t)(__float_as_int(leg.w) & kIdMask) * capA + __float_as_int(leg.x)] = make_float4(fx, fy, fz, 0.f);
+                    } else leg_force[(size_t)i * capA + e] = make_float4(fx, fy, fz, 0.f);
                     cx -= fx; cy -= fy; cz -= fz;
                 }
             }

@@ -22,7 +22,10 @@ namespace nnpops {
 
 // LAT: systems that fit the chip in one round of waves (a molecule, a small box): registers are free, so every piece of the id
 // rows is requested at once and early -- the wave's time is its chain of dependent round trips, nothing else.
-template <int NR4, int CAPA, bool LAT = false>
+// RECV (round 5): the angular backward has stored every leg force in the RECEIVING atom's row (two-wave kernels, ani_angular_bwd.h):
+// `leg_force` is then recv[i][e], the force on i from the triples centred on its e-th angular neighbour -- one contiguous load per
+// lane, requested with the atom's gradient row; no id rows, no search.
+template <int NR4, int CAPA, bool LAT = false, bool RECV = false>
 __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_backward_lanes(
     const AniParams* __restrict__ P, const int* __restrict__ species, const float4* __restrict__ nbr, int cap,
     const int* __restrict__ cnt_pos, const float* __restrict__ radial_grad, int ld_radial,
@@ -57,6 +60,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_b
     // (the centre force through the SCALAR cache, requested here: no vector register -- the 65th would cost a wave per SIMD -- and
     //  no round trip behind the wave sum at the end)
     const float4 centre = centre_force[__builtin_amdgcn_readfirstlane(i)];
+    float4 own_leg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (RECV) own_leg = leg_force[(size_t)i * CAPA + min(lane, CAPA - 1)];      // (slots behind na: stale, masked below)
     for (int q = lane; q < width; q += 64) g_own[q] = gi[q];
     wave_fence();
 
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_b
         float4 leg[IF];
 #pragma unroll
         for (int t = 0; t < IF; t++) leg[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool look = base == 0 && na > 0;
+        const bool look = !RECV && base == 0 && na > 0;
         if (EARLY && look) {
             int4 idv[IF];
             int jt[IF];
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, LAT ? 4 : 8) void ani_radial_b
             }
         }
     }
+    if (RECV && lane < na) { fx += own_leg.x; fy += own_leg.y; fz += own_leg.z; }
     fx = wave_sum_lane63(fx); fy = wave_sum_lane63(fy); fz = wave_sum_lane63(fz);
     if (lane == 63) {
         if (na >= 2) { fx += centre.x; fy += centre.y; fz += centre.z; }

@@ -709,3 +709,50 @@ def test_pair_walk_of_the_builders_does_not_change_the_lists(monkeypatch):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert np.abs(results["0"][0][1]).max() > 0 and np.abs(results["0"][1][2]).max() > 0
+
+
+def test_leg_forces_in_the_receivers_rows(monkeypatch):
+    """Round 5: where every launch of the angular backward runs two waves per atom (dense systems), the second wave looks up the slot
+    of its centre atom in the records of the atom on every leg and the leg force is stored in the RECEIVING atom's row, which the
+    radial backward reads instead of searching its neighbours' id rows ($NNPOPS_ANI_SCATTER forces either way).  Same forces as the
+    gathering path up to the order of one fp32 sum, the oracle's forces within the usual bar, bitwise reproducible -- on a batch of
+    molecules (records of 64 slots, atoms with a single angular neighbour among them) and with the backward launched by classes."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    rf, af = workloads.ani2x_functions()
+    dev = torch.device("cuda:0")
+    mols = [workloads.conformer(40 + 3 * m, seed=500 + m) for m in range(10)]
+    mols.append((np.array([[0.0, 0, 0], [1.1, 0, 0], [9.0, 0, 0]], np.float32), np.array([1, 0, 3], np.int32)))      # two bonded atoms + a loner
+    pos = np.concatenate([m[0] for m in mols]).astype(np.float32)
+    species = np.concatenate([m[1] for m in mols]).astype(np.int32)
+    offsets = np.concatenate([[0], np.cumsum([len(m[0]) for m in mols])]).astype(np.int32)
+    tp = torch.tensor(pos, device=dev)
+    grads = {}
+    for scatter, classes in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("NNPOPS_ANI_SCATTER", scatter)
+        monkeypatch.setenv("NNPOPS_ANI_BWD_CLASSES", classes)
+        monkeypatch.setenv("NNPOPS_ANI_BWD_CLASS_MIN", "0")
+        monkeypatch.setenv("NNPOPS_ANI_BWD_CLASS_ATOMS", "0")
+        sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=False)
+        sym.set_molecules(offsets)
+        sym.compute(tp, None)
+        radial, angular = sym.compute(tp, None)                      # (classes and the two-wave decision are in place after a check)
+        gen = torch.Generator(device=dev).manual_seed(4)
+        g_r = torch.randn(radial.shape, device=dev, generator=gen)
+        g_a = torch.randn(angular.shape, device=dev, generator=gen)
+        a = sym.backprop(g_r, g_a).cpu().numpy()
+        b = sym.backprop(g_r, g_a).cpu().numpy()
+        assert np.array_equal(a, b)                                   # reproducible
+        assert sym.describe()["scatter"] == scatter, sym.describe()   # (the path asked for is the one that ran)
+        grads[(scatter, classes)] = a
+        wr, wa = g_r.cpu().numpy(), g_a.cpu().numpy()
+    ref = np.zeros_like(grads[("0", "0")])
+    for m in range(len(offsets) - 1):
+        lo, hi = offsets[m], offsets[m + 1]
+        o = AniOracle(7, 5.1, 3.5, species[lo:hi], rf, af, periodic=False)
+        o.forward(pos[lo:hi], None)
+        ref[lo:hi] = o.backward(wr[lo:hi], wa[lo:hi])
+    fmax = np.abs(ref).max()
+    for key, g in grads.items():
+        assert np.abs(g - ref).max() <= 1e-4 * fmax, key
+    assert np.abs(grads[("1", "0")] - grads[("0", "0")]).max() <= 2e-6 * fmax
+    assert np.array_equal(grads[("1", "0")], grads[("1", "1")])      # same arithmetic per atom, whatever launch it ran in
