@@ -1141,7 +1141,20 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
         // (classes pay when every launch can fill the chip: the 61 199-atom conformer batch 304 -> 246 us; on a 7 600-atom block of
         //  it three launches are 3 us slower than one)
         if (h->cap_angular > 48 && h->bwd_by_class && h->hp.N >= h->bwd_class_atoms) {          // (record capacities are 32, 64, 128, ...)
-            const int tiles[3] = {h->cap_angular, 48, 32}, above[3] = {44, 28, -1};      // class c: atoms with more than above[c] neighbours
+            // The pair matrix of a class is as large as the 1 280-byte pieces it occupies anyway allow (a CU hands its LDS out in 128
+            // such pieces: ani_angular_bwd.h): for "up to 44 neighbours" 47 slots are 12 pieces like 46, ten workgroups per CU where 48
+            // slots are 13 pieces and nine; the top class is sized by the busiest atom of the frame (+ 2), not by the record capacity --
+            // 59 slots are 18 pieces, seven workgroups, 64 slots 21 pieces, six.  An atom that outgrows its class is evaluated by the
+            // clean-up launch (full capacity).
+            auto pieces = [](int t) { return (32 * t + 4 * (t * (t + 1) + t * (t - 1) / 2) + 1279) / 1280; };
+            auto snap = [&](int need) {
+                int t = std::min(need, h->cap_angular);
+                while (t < h->cap_angular && pieces(t + 1) == pieces(t)) t++;
+                return t;
+            };
+            int busiest = 0;
+            for (int cnt : counts) busiest = std::max(busiest, cnt);
+            const int tiles[3] = {snap(busiest + 2), snap(46), snap(30)}, above[3] = {44, 28, -1};      // class c: atoms with more than above[c] neighbours
             // (a class of a few hundred atoms is a launch that cannot fill the chip: it takes the next class with it -- at the
             //  larger pair matrix -- until it has bwd_class_min atoms)
             int start = 0, pending = 0;
