@@ -192,7 +192,9 @@ int forward_chunk(const nnpops_ani* h, size_t fixed_lds_bytes, size_t bytes_per_
     }
     // dense systems (compact molecules: 400+ triples per atom): 256 triples per chunk are two passes where 192 are three -- a
     // 7 600-atom block of the conformer batch 40.1 -> 36.5 us, the whole batch equal
-    if (h->mean_triples >= 256.0 && h->fwd_chunk < 256 && fixed_lds_bytes + 257 * bytes_per_triple <= 160 * 1024) return 256;
+    // (round 5: 240, not 256 -- with 64-slot records 241 staged triples are 11 of the CU's 1 280-byte LDS pieces, eleven workgroups per
+    //  CU, 257 are 12 pieces and ten: forward of a 7 600-atom block 31.1 -> 30.6 us, of the whole batch 254.5 -> 250.2)
+    if (h->mean_triples >= 256.0 && h->fwd_chunk < 240 && fixed_lds_bytes + 241 * bytes_per_triple <= 160 * 1024) return 240;
     return h->fwd_chunk;
 }
 
