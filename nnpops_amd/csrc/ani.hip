@@ -168,9 +168,10 @@ struct KernelTimer {
 };
 
 // Waves per workgroup for a per-atom kernel that needs `lds_wave` bytes of LDS per wave: the largest of
-// {4, 2, 1} that does not lower the number of waves a CU can hold (160 KiB LDS, 32 wave slots).
+// {4, 2, 1} that does not lower the number of waves a CU can hold (32 wave slots; 160 KiB of LDS handed out in 128 pieces of
+// 1 280 bytes -- a workgroup occupies whole pieces, round 5).
 int waves_per_group(size_t lds_wave) {
-    auto resident = [&](int wpg) { return (int)std::min<size_t>(32, (160 * 1024 / std::max<size_t>(1, lds_wave * wpg)) * wpg); };
+    auto resident = [&](int wpg) { return (int)std::min<size_t>(32, (128 / std::max<size_t>(1, (lds_wave * wpg + 1279) / 1280)) * wpg); };
     int best = 1;
     for (int wpg : {2, 4})
         if (resident(wpg) >= resident(best)) best = wpg;

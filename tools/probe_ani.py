@@ -57,7 +57,7 @@ PATCHES = {
          f"        if (role == 0 && !({PM} & 1024)) {{\n            float cx = 0.f, cy = 0.f, cz = 0.f;\n", 1),
     ],
     "ani_radial_bwd.h": [
-        ("        const bool look = base == 0 && na > 0;\n", f"        const bool look = base == 0 && na > 0 && !({PM} & 2048);\n", 1),
+        ("        const bool look = !RECV && base == 0 && na > 0;\n", f"        const bool look = !RECV && base == 0 && na > 0 && !({PM} & 2048);\n", 1),
         ("        for (int c = 0; c < NR4; c++) gj[c] = grow[c];\n",
          f"        for (int c = 0; c < NR4; c++) gj[c] = ({PM} & 4096) ? make_float4(0.f, 0.f, 0.f, 0.f) : grow[c];\n", 1),
     ],
@@ -65,6 +65,38 @@ PATCHES = {
         ("int nnpops_ani_set_stream(nnpops_ani_t h, void* stream) {\n",
          "int nnpops_debug_set_probe(int mask) {\n    return hipMemcpyToSymbol(HIP_SYMBOL(nnpops::nnpops_probe_mask), &mask, sizeof(int)) == hipSuccess ? 0 : 1;\n}\n\n"
          "int nnpops_ani_set_stream(nnpops_ani_t h, void* stream) {\n", 1),
+    ],
+    # bits 65536 / 131072 (round 5, VERDICT r04 "next" #1): what the two angular kernels would have to do per triple WITHOUT the
+    # builder's triple list -- the pair from the folded enumeration, its species pair from the records, its place in the bucket-major
+    # staging order from per-species tables in LDS (forward), the bucket alone (backward) -- executed IN ADDITION to the product path
+    # and folded into an index through a factor that is zero at run time (bit 30 of the mask, never set): results unchanged, the
+    # instructions and LDS look-ups are all there.  With bit 1 (builder without its triple loop) this prices the whole idea.
+    "ani_angular_mfma.h#3": [
+        ("                    const int p = word & 0xff, q = (word >> 8) & 0xff;\n                    const float4 A = recA[p], B = recA[q];\n",
+         f"                    int p = word & 0xff, q = (word >> 8) & 0xff;\n"
+         f"                    if ({PM} & 65536) {{\n"
+         f"                        int p2, q2;\n"
+         f"                        const bool ok2 = decode_pair_folded(t, n, __builtin_amdgcn_rcpf((float)max(n - 1, 1)), p2, q2);\n"
+         f"                        const int A2 = __float_as_int(recB[min(p2, capA - 1)].w) >> kTagShift, B2 = __float_as_int(recB[min(q2, capA - 1)].w) >> kTagShift;\n"
+         f"                        const int S2 = 7, bucket2 = __mul24(A2, S2) - __mul24(A2, A2 - 1) / 2 + (B2 - A2);\n"
+         f"                        const int ga = qtab[A2 & 31], gb2 = qtab[32 + (B2 & 31)];                  // {{first slot | count << 8}} of the two species: two LDS look-ups\n"
+         f"                        const int ia = p2 - (ga & 0xff), ib = q2 - (gb2 & 0xff), cnt = gb2 >> 8;\n"
+         f"                        const int local = A2 == B2 ? __mul24(ia, 2 * cnt - ia - 1) / 2 + (ib - ia - 1) : __mul24(ia, cnt) + ib;\n"
+         f"                        const int pos2 = qtab[bucket2 & 63] + local + (ok2 ? 0 : 1);           // first triple of the bucket: a third look-up\n"
+         f"                        p += pos2 * (({PM} >> 30) & 1);\n"
+         f"                    }}\n"
+         f"                    const float4 A = recA[p], B = recA[q];\n", 1),
+    ],
+    "ani_angular_bwd.h#2": [
+        ("                const int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;\n",
+         f"                int p = word & 0xff, q = (word >> 8) & 0xff, bucket = word >> 16;\n"
+         f"                if ({PM} & 131072) {{\n"
+         f"                    int p2, q2;\n"
+         f"                    const bool ok2 = decode_pair_folded(t, n, __builtin_amdgcn_rcpf((float)max(n - 1, 1)), p2, q2);\n"
+         f"                    const int A2 = __float_as_int(recB[min(p2, tile - 1)].w) >> kTagShift, B2 = __float_as_int(recB[min(q2, tile - 1)].w) >> kTagShift;\n"
+         f"                    const int bucket2 = __mul24(A2, 7) - __mul24(A2, A2 - 1) / 2 + (B2 - A2) + (ok2 ? 0 : 1);\n"
+         f"                    bucket += (bucket2 + p2 + q2) * (({PM} >> 30) & 1);\n"
+         f"                }}\n", 1),
     ],
 }
 
@@ -90,6 +122,9 @@ PROBES = [
     (2048, "radial backward: no reverse lookup / leg-force gather"),
     (4096, "radial backward: neighbours' gradient rows not gathered"),
     (2048 | 4096, "radial backward: own row only"),
+    (65536, "angular forward: + per triple what phase 1 would do WITHOUT a triple list (folded decode, species pair, place from LDS tables)"),
+    (131072, "angular backward: + per triple what it would do without a triple list (folded decode, bucket from the species pair)"),
+    (1 | 65536 | 131072, "NO TRIPLE LIST, priced: builder without its triple loop, both angular kernels with the decode on top of their work"),
 ]
 
 
