@@ -1185,11 +1185,14 @@ def run_conformers(args, R):
     import numpy as np
     import torch
     from nnpops_amd import workloads
-    from nnpops_amd.parallel import shard_molecules
+    from nnpops_amd.parallel import molecule_work, shard_molecules
     rank, world, dev, dist = R.rank, R.world, R.dev, R.dist
     B = CONFORMER_BATCH
     sizes = conformer_sizes()
-    blocks = shard_molecules(sizes, world)
+    # blocks balanced by WORK (neighbour triples + a share per atom, parallel.molecule_work: host numpy at set-up), not by atoms:
+    # compact conformers hold up to 7 % more triples than loose ones of the same size and the slowest rank decides the step
+    work = [molecule_work(workloads.conformer(sizes[m], seed=1000 + m)[0], workloads.ANI2X["Rca"]) for m in range(B)]
+    blocks = shard_molecules(sizes, world, weights=work)
     offsets_all = np.concatenate([[0], np.cumsum(sizes)])
     rows = [int(offsets_all[hi] - offsets_all[lo]) for lo, hi in blocks]
     width = max(rows)
@@ -1264,7 +1267,7 @@ def run_conformers(args, R):
         t_full = elapsed / steps
         del shard
         t_blocks = []
-        for r8, (l8, h8) in enumerate(shard_molecules(sizes, 8)):
+        for r8, (l8, h8) in enumerate(shard_molecules(sizes, 8, weights=work)):
             sh = ConformerShard(sizes, l8, h8, R.local_rank, seed_offset=r8)
             buf = torch.empty((sh.n, 3), device=dev)
             t_blocks.append(_time_steps(lambda: sh.step(buf), steps, warm))
@@ -1273,7 +1276,7 @@ def run_conformers(args, R):
         out["shard8"] = {"ms_per_block_step": [round(1e3 * t, 4) for t in t_blocks], "slowest_block_ms": round(1e3 * t_max, 4),
                          "projected_scaling": round(t_full / t_max, 2),
                          "projected_scaling_with_synchronous_gather": round(t_full / (t_max + 25e-6), 2),
-                         "note": "each of the 8 blocks of shard_molecules(sizes, 8) (~128 conformers, ~7.7 k atoms) timed alone on "
+                         "note": "each of the 8 blocks of shard_molecules(sizes, 8, weights = neighbour triples + 130 per atom) (~128 conformers, ~7.7 k atoms) timed alone on "
                                  "this one device; projected = t_1024 / slowest block (gather overlapped) and / (slowest block + "
                                  "25 us assumed for a synchronous all_gather); no 8-GPU node was available to measure it"}
     if not args.no_cpu_baseline and world == 1:
