@@ -98,8 +98,9 @@ struct MfmaForward {
     float* angular;
     float4 *recA, *recB;                  // [capA] each, LDS
     float* fac;                           // [CH + 1][REC], LDS; the last record stays zero
-    int* qtab;                            // [32][2], LDS (DYN): quad slot -> {first triple | count << 16, bucket | part << 8 | parts << 16}
+    int* qtab;                            // [32][2], LDS (DYN): quad slot -> {first triple of the bucket | its size << 16, bucket | part << 8 | parts << 16}
     int dpart, dparts;                    // DYN: this quad's part of its bucket, and how many quads share the bucket
+    float dinv;                           //      1 / dparts (quotients by it: exact for the sizes that occur, see phase 2)
     int lane, role, quad, nn;
     int NB, nA, K, logK;
     int fac_addr, zdelta, zero_addr;      // (LDS addresses of phase 2 are kept as 32-bit byte offsets: one register per quad stream)
@@ -197,9 +198,14 @@ struct MfmaForward {
                 if (q0 + k > 16) q0 += shift;
                 const int kmax = wave_max_nonneg(k);
                 wave_fence();                                  // (the zeros above)
+                // (round 5) the k quads of a bucket take its triples ROUND-ROBIN (triple j goes to quad j mod k), not as k consecutive runs
+                // of L: the staging area holds a window of the bucket-major list, and a window of CH triples meets only ~CH / L of
+                // the runs -- those quads walked L steps per chunk while the others multiplied zeros, so an atom of c chunks ran c
+                // times the steps it needs (dense molecules: 800 triples, 4 chunks, 100 steps instead of 25).  Dealt round-robin every
+                // quad of a bucket has its share of every window: ~CH / 32 steps per chunk whatever the atom.
                 for (int j = 0; j < kmax; j++)
                     if (j < k) {
-                        qtab[2 * (q0 + j)] = (off + j * L) | (min(L, nb - j * L) << 16);
+                        qtab[2 * (q0 + j)] = off | (nb << 16);
                         qtab[2 * (q0 + j) + 1] = lane | (j << 8) | (k << 16);
                     }
             }
@@ -227,8 +233,9 @@ struct MfmaForward {
             dparts = e.y >> 16; dpart = (e.y >> 8) & 0xff;
             sbk[0] = dparts > 0 ? (e.y & 0xff) : -1;
             spart[0] = dpart;
-            sstart[0] = e.x & 0xffff;
-            send[0] = sstart[0] + (e.x >> 16);
+            sstart[0] = e.x & 0xffff;                          // the whole bucket: this quad's triples are first + part + j * parts
+            send[0] = sstart[0] + (int)((unsigned)e.x >> 16);
+            dinv = __builtin_amdgcn_rcpf((float)max(dparts, 1));
         }
 
         for (int c0 = 0; c0 < T; c0 += CH) {
@@ -280,9 +287,16 @@ struct MfmaForward {
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const int lo = max(sstart[s], c0), hi = min(send[s], c1);
-                if constexpr (DYN) {                           // a quad's piece is a run of consecutive triples
-                    cnt[s] = max(0, hi - lo);
-                    ra[s] = fac_addr + (lo - c0) * (REC * 4);
+                if constexpr (DYN) {                           // every dparts-th triple of the bucket, from dpart on
+                    // (floor(x / dparts) as (int)((x + 0.5) / dparts) in float: x < 2^15, dparts <= 32 -- the error of the product is
+                    //  below 1e-3 where the nearest integer boundary is 0.5 / 32 away)
+                    const int a = max(lo - sstart[s], 0), pp = max(dparts, 1);
+                    const int r = a - pp * (int)(((float)a + 0.5f) * dinv);
+                    int d = dpart - r;
+                    d += d < 0 ? pp : 0;
+                    const int first = lo + d;
+                    cnt[s] = hi > first ? (int)(((float)(hi - first + pp - 1) + 0.5f) * dinv) : 0;
+                    ra[s] = fac_addr + (first - c0) * (REC * 4);
                 } else {
                     const int first = lo + ((spart[s] - (lo - sstart[s])) & (K - 1));     // triples of a bucket are dealt round-robin
                     cnt[s] = max(0, (hi - first + K - 1) >> logK);
@@ -291,7 +305,7 @@ struct MfmaForward {
                 cmax = max(cmax, cnt[s]);
             }
             const int steps = wave_max_nonneg(cmax);             // wave-uniform trip count
-            const int stride = (DYN ? 1 : K) * REC * 4;
+            const int stride = (DYN ? max(dparts, 1) : K) * REC * 4;
             float ar[NS][NR4], az[NS][NZ4], br[NS][NR4], bz[NS][NZ4];      // operand registers, ping-pong
             auto fetch = [&](int k, float (&r)[NS][NR4], float (&z)[NS][NZ4]) {
 #pragma unroll

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--workload", default="box", choices=["box", "latency", "block", "batch"],
                     help="box: periodic liquid of --atoms atoms; latency: the 50-atom conformer of BASELINE config 1; block / batch: 128 / "
                          "1 024 conformers of config 4 in one batched handle")
+    ap.add_argument("--block", type=int, default=-1, help="block workload: the k-th of the eight work-balanced blocks of config 4 (default: the first 128 conformers)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     offsets = None
@@ -35,8 +36,16 @@ def main():
         box = None
     elif args.workload in ("block", "batch"):
         import bench
-        sizes = bench.conformer_sizes()[:128 if args.workload == "block" else 1024]
-        mols = [workloads.conformer(sizes[m], seed=1000 + m) for m in range(len(sizes))]
+        sizes = bench.conformer_sizes()
+        first = 0
+        if args.workload == "block" and args.block >= 0:
+            from nnpops_amd.parallel import molecule_work, shard_molecules
+            work = [molecule_work(workloads.conformer(sizes[m], seed=1000 + m)[0], 3.5) for m in range(len(sizes))]
+            first, last = shard_molecules(sizes, 8, weights=work)[args.block]
+            sizes = sizes[first:last]
+        else:
+            sizes = sizes[:128 if args.workload == "block" else 1024]
+        mols = [workloads.conformer(sizes[m], seed=1000 + first + m) for m in range(len(sizes))]
         pos = np.concatenate([m[0] for m in mols]).astype(np.float32)
         species = np.concatenate([m[1] for m in mols]).astype(np.int32)
         offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)

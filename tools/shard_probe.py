@@ -16,7 +16,11 @@ from nnpops_amd.parallel import shard_molecules
 
 sizes = bench.conformer_sizes()
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-lo, hi = shard_molecules(sizes, world)[0]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+from nnpops_amd import workloads
+from nnpops_amd.parallel import molecule_work
+work = [molecule_work(workloads.conformer(sizes[m], seed=1000 + m)[0], 3.5) for m in range(len(sizes))]
+lo, hi = shard_molecules(sizes, world, weights=work)[which]
 sh = bench.ConformerShard(sizes, lo, hi, 0)
 buf = torch.empty((sh.n, 3), device="cuda")
 step = lambda: sh.step(buf)
@@ -35,5 +39,6 @@ g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     step()
 t_graph = bench._time_steps(g.replay, 300, 30, repeats=1)
-print(f"{hi - lo} conformers, {sh.n} atoms: eager {1e3 * t_eager:.4f} ms, graph {1e3 * t_graph:.4f} ms; kernels (us, event brackets included): "
+print(sh.sym.describe())
+print(f"block {which}: {hi - lo} conformers, {sh.n} atoms: eager {1e3 * t_eager:.4f} ms, graph {1e3 * t_graph:.4f} ms; kernels (us, event brackets included): "
       + ", ".join(f"{k} {v:.1f}" for k, v in kt.items()), "max row / angular:", sh.sym.neighbor_stats())
