@@ -1014,6 +1014,42 @@ def run_torchani(args, R):
                 print(f"bench: dense-networks variant of the torchani step failed: {exc!r}", file=sys.stderr)
             finally:
                 opt = live_opt
+    # ... and with weight sets whose crude activation bound (BatchedNN.py: the products of the layers' L1 norms) is beyond what the
+    # 1/16 scale of the fp16 planes holds.  The published ANI-2x weights cannot be checked offline (no torchani, no network).  Up to
+    # round 4 such a set sent OptimizedTorchANI to the four-module composition with the networks on the library GEMMs (~1.0 ms, 9x);
+    # the kernels now take the scale as an argument (act_scale_log2, 4..12) and the module picks it from the bound: first-layer
+    # weights x 100 (bound 3.4e7) stay on the fused step, x 1e4 (bound 3.4e9, beyond 2^-12) still fall back.  Same shapes, same launches.
+    unfused_ms = unfused_layout = rescaled_ms = rescaled_log2 = None
+    if not args.graph and one_node:
+        import copy
+        live_opt = opt
+        for factor in (1.0e2, 1.0e4):
+            try:
+                big = copy.deepcopy(model)
+                for ens in big.neural_networks:
+                    for net in ens.values():
+                        net[0].weight.data *= factor
+                opt = OptimizedTorchANI(big, numbers.cpu(), nn_layout=args.nn_layout).to(dev)
+                nets_big = opt.neural_networks[0]
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t1) / steps
+                if getattr(nets_big, "fused_ok", False):
+                    assert factor == 1.0e2 and type(opt).__name__ == "FusedOptimizedTorchANI"
+                    rescaled_ms, rescaled_log2 = ms, int(nets_big.act_scale_log2)
+                else:
+                    assert type(opt).__name__ != "FusedOptimizedTorchANI"
+                    unfused_ms = ms
+                    unfused_layout = type(opt).__name__ + " / " + type(nets_big).__name__ + " (fused_ok = False: grouped library GEMMs)"
+            except Exception as exc:                             # noqa: BLE001 -- figures beside the line, not the line
+                print(f"bench: the large-weights variant (x{factor:g}) of the torchani step failed: {exc!r}", file=sys.stderr)
+            finally:
+                opt = live_opt
     # NN flops: 2 * models * sum over atoms of the MACs of its network; backward to the
     # inputs costs the same again
     macs = {s: 1008 * a + a * b + b * c + c for s, (a, b, c) in enumerate(workloads.ANI2X_WIDTHS.values())}
@@ -1051,6 +1087,10 @@ def run_torchani(args, R):
         "ms_per_step_without_capacity_check": (round(no_check_ms, 4) if no_check_ms is not None else None),
         "ms_per_step_as_hip_graph": (round(graph_ms, 4) if graph_ms is not None else None),
         "ms_per_energy_and_forces_call": (round(call_ms, 4) if call_ms is not None else None),
+        "ms_per_step_with_first_layer_weights_x100": (round(rescaled_ms, 4) if rescaled_ms is not None else None),
+        "act_scale_log2_with_first_layer_weights_x100": rescaled_log2,
+        "ms_per_step_when_weights_fail_fused_ok": (round(unfused_ms, 4) if unfused_ms is not None else None),
+        "layout_when_weights_fail_fused_ok": unfused_layout,
         "ms_per_step_as_hip_graph_with_dense_networks": (round(dense_graph_ms, 4) if dense_graph_ms is not None else None),
         "roofline": {"bound": "mfma", "kernel": kernel_name + ", forward + input-gradient backward",
                      "achieved": round(tflops, 3), "peak": FP32_MATRIX_PEAK, "unit": "TFLOP/s",

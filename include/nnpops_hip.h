@@ -291,7 +291,7 @@ int nnpops_gemm_split(void* stream, int M, int N, int K, int batch, const float*
  * registers; with_gradient the same launch runs the backward pass of layers 6, 4 and 2 and leaves dE/dy1 (split fp16
  * planes, workspace d1); nnpops_mlp_input_grad then forms dE/dx = W0^T dE/dy1 and writes the rows of dx.
  * Arithmetic: fp32 in and out; every operand of a product is carried as two fp16 planes (22 significant bits after a
- * fixed 1/16 scale, exact products, fp32 accumulation) -- keep |activation| below 1e6.
+ * scale of 2^-act_scale_log2 -- 1/16 by default --, exact products, fp32 accumulation) -- keep |activation| below 65 504 / scale.
  * Weights arrive packed (nnpops_mlp_pack): W [rows][cols] fp32 -> fragment planes of nnpops_mlp_packed_halves(rows, cols)
  * fp16 values; rows = outputs, cols = inputs of the product the planes are the left operand of.  For a torch Linear
  * weight W_l [out][in] of member m, with widths padded to multiples of 32 (zero rows / columns):
@@ -342,6 +342,12 @@ typedef struct {
      * to publish_to[0] (system scope, release) -- the deferred capacity check of an ANI handle (nnpops_ani_check_begin_with) riding
      * along instead of taking a launch of its own.  All three come from that call; NULL / 0: nothing is published. */
     const int32_t* publish_word; int32_t* publish_to; int32_t publish_stamp;
+    /* Operand scale of the fp16 planes: activations (and back-propagated gradients) are split after a scale of 2^-act_scale_log2,
+     * so |activation| must stay below 65 504 * 2^act_scale_log2.  0 is read as 4 -- the fixed 1/16 (|activation| < 1e6) of rounds
+     * 1-4; 4 .. 12 accepted.  A larger exponent buys range for networks whose weights admit large activations at the price of
+     * the smallest activations' last bits (below 6e-5 * 2^act_scale_log2 the high plane is a denormal; the low plane still carries
+     * the remainder): callers derive it from a bound on the activations (nnpops_amd/BatchedNN.py: _refresh_planes). */
+    int act_scale_log2;
 } nnpops_mlp_frame;
 int64_t nnpops_mlp_packed_halves(int rows, int cols);
 int64_t nnpops_mlp_d1_halves(int num_atoms, int num_members, int h1);

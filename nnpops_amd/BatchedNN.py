@@ -190,6 +190,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
 
     widths: List[int]
     live_blocks: List[int]
+    act_scale_log2: int
 
     def __init__(self, converter, ensemble, atomicNumbers: Tensor):
         super().__init__(converter, ensemble, atomicNumbers)
@@ -197,6 +198,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         self.widths = []
         self.live_blocks = []
         self.fused_ok = True
+        self.act_scale_log2 = 4
         self.register_buffer('atom_order32', self.atom_order.to(torch.int32), persistent=False)
         for name in ('mlp_planes', 'mlp_floats', 'live_planes'):
             self.register_buffer(name, torch.empty(0), persistent=False)
@@ -278,7 +280,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
             self.live_planes = torch.empty(0, device=dev)
             self.x_blocks = torch.empty(0, dtype=torch.int32, device=dev)
             self.dead_blocks = torch.empty(0, dtype=torch.int32, device=dev)
-        # the kernels scale every activation by 1/16 before the fp16 split: activations must stay below ~1e6.  A crude
+        # the kernels scale every activation by a power of two before the fp16 split (1/16: activations below ~1e6).  A crude
         # bound from the weights (AEV entries are sums of at most a few dozen terms <= 1) decides; networks that could
         # exceed it keep the library-GEMM path.  The backward operands take the same planes: |d3| <= |w6|,
         # |d2| <= |d3| ||W4||_1, |d1| <= |d2| ||W2||_1 (CELU' <= 1).
@@ -288,7 +290,15 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         back = w6.abs().amax().reshape(1)
         for w in (w4, w2):
             back = (w.abs().sum(-2).amax() * back).reshape(1)
-        self.fused_ok = (bool(torch.isfinite(bound).all()) and float(bound) < 1.0e6 and bool(torch.isfinite(back).all()) and float(back) < 1.0e6
+        # The scale is 2^-k, k = act_scale_log2 of the ops: the smallest k >= 4 whose bound 62 500 * 2^k (fp16's largest
+        # number, with margin) holds the crude bounds; 4 for networks of ordinary size, up to 12 (bounds below 2.56e8)
+        # before the weights are left to the library-GEMM path.
+        worst = max(float(bound), float(back)) if bool(torch.isfinite(bound).all()) and bool(torch.isfinite(back).all()) else float("inf")
+        k = 4
+        while k < 12 and worst >= 62500.0 * 2.0 ** k:
+            k += 1
+        self.act_scale_log2 = k
+        self.fused_ok = (worst < 62500.0 * 2.0 ** k
                          and F % 8 == 0 and F <= 1024 and max(widths) <= 256 and kinds <= 8 and int(w6.shape[2]) == 1)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -301,7 +311,7 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
                 or self.atom_order32.dtype != torch.int32 or not self.fused_ok):
             return self._grouped_forward(species_aev)
         total = torch.ops.NNPOpsBatchedNN.FusedMLP(aev[0].contiguous(), self.atom_order32, self.group_sizes, self.widths, self.num_models,
-                                                   self.mlp_planes, self.mlp_floats)
+                                                   self.mlp_planes, self.mlp_floats, self.act_scale_log2)
         return SpeciesEnergies(species, total / self.num_models)
 
     def set_check_interval(self, interval: int) -> None:
@@ -318,9 +328,9 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         if self.x_blocks.numel() > 0:
             return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
                                                                self.num_models, self.live_planes, self.mlp_floats, shift, self.x_blocks,
-                                                               self.dead_blocks)
+                                                               self.dead_blocks, self.act_scale_log2)
         return torch.ops.NNPOpsANISymmetryFunctions.energy(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
-                                                           self.num_models, self.mlp_planes, self.mlp_floats, shift, None, None)
+                                                           self.num_models, self.mlp_planes, self.mlp_floats, shift, None, None, self.act_scale_log2)
 
     def fused_energy_forces(self, positions: Tensor, cell: Optional[Tensor], shift: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """The same step outside autograd: (energy [1], forces = -dE/dpositions in the shape of ``positions``) from one call."""
@@ -330,9 +340,9 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         if self.x_blocks.numel() > 0:
             return torch.ops.NNPOpsANISymmetryFunctions.energy_forces(self.holder, positions, cell, self.atom_order32, self.group_sizes,
                                                                       self.widths, self.num_models, self.live_planes, self.mlp_floats, shift,
-                                                                      self.x_blocks, self.dead_blocks)
+                                                                      self.x_blocks, self.dead_blocks, self.act_scale_log2)
         return torch.ops.NNPOpsANISymmetryFunctions.energy_forces(self.holder, positions, cell, self.atom_order32, self.group_sizes, self.widths,
-                                                                  self.num_models, self.mlp_planes, self.mlp_floats, shift, None, None)
+                                                                  self.num_models, self.mlp_planes, self.mlp_floats, shift, None, None, self.act_scale_log2)
 
 
 class _SplitGemmSpeciesNN(_SpeciesGroupedNN):

@@ -529,7 +529,7 @@ class _MlpFrame(C.Structure):
                 ("upstream", C.c_void_p), ("dx_scale", C.c_float), ("kinds", _MlpKind * MLP_MAX_KINDS),
                 ("x_groups", C.c_void_p), ("dead_groups", C.c_void_p), ("num_dead_groups", C.c_int), ("dx_partial", C.c_void_p),
                 ("mean_scale", C.c_float), ("mean_out", C.c_void_p), ("mean_shift", C.c_void_p), ("mean_out_shifted", C.c_void_p),
-                ("publish_word", C.c_void_p), ("publish_to", C.c_void_p), ("publish_stamp", C.c_int32)]
+                ("publish_word", C.c_void_p), ("publish_to", C.c_void_p), ("publish_stamp", C.c_int32), ("act_scale_log2", C.c_int)]
 
 
 def mlp_pack(w, rows, cols, transpose=False, permute=False):
@@ -556,7 +556,7 @@ class FusedMLP:
     multiplied, and their gradient is written as zero; with at most 256 live columns the forward launch also forms the input
     gradient member by member (dx_partial) and input_grad() only adds the members up."""
 
-    def __init__(self, kinds, num_features, alpha=0.1, live_groups=None):
+    def __init__(self, kinds, num_features, alpha=0.1, live_groups=None, act_scale_log2=4):
         if not 1 <= len(kinds) <= MLP_MAX_KINDS:
             raise ValueError(f"1..{MLP_MAX_KINDS} kinds")
         self.x_width = int(num_features)
@@ -572,6 +572,7 @@ class FusedMLP:
         self._keep = []
         self.frame = _MlpFrame()
         self.frame.num_kinds, self.frame.num_features, self.frame.num_members, self.frame.alpha = len(kinds), self.F, self.M, self.alpha
+        self.frame.act_scale_log2 = int(act_scale_log2)       # activations are scaled by 2^-k before the fp16 split (nnpops_hip.h)
         dev = kinds[0]["w0"].device
         self.device = dev
         rows = []

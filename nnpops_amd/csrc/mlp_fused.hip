@@ -50,7 +50,7 @@ constexpr int kRB = 2;                      // row blocks (16 output features ea
 constexpr int kCB = 4;                      // column blocks (16 atoms each) per workgroup: tiles of 64 atoms
 constexpr int kTile = 16 * kCB;
 constexpr int kFrag = 512;                  // halves per fragment plane: 64 lanes x 8
-constexpr float kScale = 1.0f / 16, kUnscale = 16.0f;     // operands are split after this scale: |activation| up to 1e6 fits fp16
+constexpr float kDefaultScaleLog2 = 4;     // operands are split after a scale of 2^-k (MlpArgs::scale): k = 4, |activation| up to 1e6, unless the frame says otherwise
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 constexpr int kActBytes = 16 * kCB * 2 * 1024 / 2;        // one activation region: up to 8 K steps (256 features): 64 KiB
 constexpr int kStageBytes = kCB * 2 * 1024;               // one K step of B fragments for the whole tile: 8 KiB
@@ -79,13 +79,14 @@ struct MlpArgs {
     float* dx_partial; int n_grouped;       // optional [M][n_grouped][F]: every member's W0^T dE/dy1, formed by the forward launch
     float mean_scale; float* mean_out; const double* mean_shift; double* mean_out_shifted;   // optional: the energy mean rides along (mlp_sum_members)
     const int* publish_word; int* publish_to; int publish_stamp;                             // optional: an ANI handle's deferred capacity check rides along (mlp_forward)
+    float scale, unscale;                   // 2^-act_scale_log2 and its inverse: the operand scale of the fp16 planes (nnpops_hip.h; 1/16 by default)
     KindDesc kinds[NNPOPS_MLP_MAX_KINDS];
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8& h, f16x8& l) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const float s = v[i] * kScale;
+        const float s = v[i] * (1.0f / 16);
         h[i] = (_Float16)s;
         l[i] = (_Float16)((s - (float)h[i]) * kLoScale);
     }
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
             const int k = 32 * s + piece * 4;
             const bool in = k < g.F;                         // (F is a multiple of 8: all four or none)
             xraw = *reinterpret_cast<const float4*>(xsrc + 16 * xgroup[in ? 2 * s + (piece >> 2) : 0]);
-            xscale = in ? kScale : 0.0f;
+            xscale = in ? g.scale : 0.0f;
         };
         auto stage_x = [&](int stage) {
             const f32x4 xv = {xraw.x * xscale, xraw.y * xscale, xraw.z * xscale, xraw.w * xscale};
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_forward(const MlpArgs g) {
     }
     // bias + CELU; y1 -> region A.  Everything is kept divided by 16 (the operand scale): vs = v / 16 comes straight out of the
     // accumulators (acc1 + acc2 / 2048 + b / 16), CELU(v) / 16 = vs > 0 ? vs : (alpha / 16) (exp(16 vs / alpha) - 1).
+    const float kScale = g.scale, kUnscale = g.unscale;     // (run-time powers of two since round 5; the names of the constants they replace)
     const float exp_scale = kUnscale * inv_alpha * 1.44269504089f, alpha_s = g.alpha * kScale;
     auto activate = [&](const float* __restrict__ bias, int nmine, f32x4 (&c)[kRB][kCB], char* act) {
         for_blocks(nmine, w, [&](int j, int rb) {
@@ -495,10 +497,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_input_grad(const MlpArgs g) {
             const int r = r0 + cb * 16 + a16;
             if (r >= kd.n) continue;
             float4 v;
-            v.x = (acc1[cb][0] + kLoInv * acc2[cb][0]) * kUnscale * up;
-            v.y = (acc1[cb][1] + kLoInv * acc2[cb][1]) * kUnscale * up;
-            v.z = (acc1[cb][2] + kLoInv * acc2[cb][2]) * kUnscale * up;
-            v.w = (acc1[cb][3] + kLoInv * acc2[cb][3]) * kUnscale * up;
+            v.x = (acc1[cb][0] + kLoInv * acc2[cb][0]) * g.unscale * up;
+            v.y = (acc1[cb][1] + kLoInv * acc2[cb][1]) * g.unscale * up;
+            v.z = (acc1[cb][2] + kLoInv * acc2[cb][2]) * g.unscale * up;
+            v.w = (acc1[cb][3] + kLoInv * acc2[cb][3]) * g.unscale * up;
             *reinterpret_cast<float4*>(g.dx + (size_t)g.rows[kd.first + r] * g.lddx + col) = v;
         }
     }
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void mlp_sum_members(const MlpArgs g) {
         energy_mean_block<256>(g.energies, (long)g.n_grouped * g.M, g.mean_scale, g.mean_out, g.mean_shift, g.mean_out_shifted, red);
     const int quads = g.F >> 2, per_row = quads + g.num_dead * 4;
     const long total = (long)g.n_grouped * per_row;
-    const float up = (g.upstream ? *g.upstream : 1.0f) * g.dx_scale * kUnscale;
+    const float up = (g.upstream ? *g.upstream : 1.0f) * g.dx_scale * g.unscale;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
         const int r = (int)(t / per_row), e = (int)(t % per_row);
         float* row = g.dx + (size_t)g.rows[r] * g.lddx;
@@ -635,6 +637,11 @@ int check_and_fill(const nnpops_mlp_frame* fr, MlpArgs& g, bool grad, int blocks
     g.dx_partial = grad ? fr->dx_partial : nullptr;
     g.mean_scale = fr->mean_scale; g.mean_out = fr->mean_out; g.mean_shift = fr->mean_shift; g.mean_out_shifted = fr->mean_out_shifted;
     g.publish_word = fr->publish_word; g.publish_to = fr->publish_word ? fr->publish_to : nullptr; g.publish_stamp = fr->publish_stamp;
+    {
+        const int k = fr->act_scale_log2 == 0 ? (int)kDefaultScaleLog2 : fr->act_scale_log2;
+        NNPOPS_REQUIRE(k >= 4 && k <= 12, "act_scale_log2 must be 0 (= 4) or in 4..12 (got %d)", fr->act_scale_log2);
+        g.scale = 1.0f / (float)(1 << k); g.unscale = (float)(1 << k);
+    }
     NNPOPS_REQUIRE(!fr->publish_word || fr->publish_to, "publish_word without publish_to");
     NNPOPS_REQUIRE(!(fr->mean_out && fr->mean_out_shifted) && (!fr->mean_out_shifted || fr->mean_shift), "one energy mean: float, or shifted double with its shift");
     NNPOPS_REQUIRE(!fr->x_groups || fr->num_features % 16 == 0, "x_groups maps blocks of 16 features: the feature count must be a multiple of 16 (got %d)",

@@ -80,7 +80,9 @@ int64_t mlp_halves(int64_t rows, int64_t cols) { return nnpops_mlp_packed_halves
 
 MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64_t>& kind_atoms, const std::vector<int64_t>& widths,
                     int64_t members, const Tensor& planes, const Tensor& floats, bool with_gradient,
-                    const c10::optional<Tensor>& x_blocks = c10::nullopt, const c10::optional<Tensor>& dead_blocks = c10::nullopt) {
+                    const c10::optional<Tensor>& x_blocks = c10::nullopt, const c10::optional<Tensor>& dead_blocks = c10::nullopt,
+                    int64_t act_scale_log2 = 4) {
+    TORCH_CHECK(act_scale_log2 >= 4 && act_scale_log2 <= 12, "act_scale_log2: 4..12 (activations are scaled by 2^-k before the fp16 split)");
     TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.scalar_type() == torch::kFloat32 && x.is_contiguous(),
                 "the fused networks take a contiguous [atoms, features] float32 device tensor");
     const bool narrow = x_blocks.has_value() && x_blocks->numel() > 0;
@@ -102,7 +104,7 @@ MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64
     MlpCall c;
     nnpops_mlp_frame& fr = c.frame;
     fr.num_kinds = (int)kinds; fr.num_features = (int)F; fr.num_members = (int)members;
-    fr.x = x.data_ptr<float>(); fr.ldx = (int)x.size(1); fr.rows = rows.data_ptr<int32_t>(); fr.alpha = 0.1f;       // BatchedNN.py:103
+    fr.x = x.data_ptr<float>(); fr.ldx = (int)x.size(1); fr.rows = rows.data_ptr<int32_t>(); fr.alpha = 0.1f; fr.act_scale_log2 = (int)act_scale_log2;       // BatchedNN.py:103
     if (narrow) {
         fr.x_groups = x_blocks->data_ptr<int32_t>();
         fr.dead_groups = dead_blocks->numel() ? dead_blocks->data_ptr<int32_t>() : nullptr;
@@ -456,7 +458,7 @@ std::pair<Tensor, Tensor> energy_step(const HolderPtr& holder, const Tensor& fra
                                       const std::vector<int64_t>& kind_atoms, const std::vector<int64_t>& widths, int64_t members,
                                       const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift,
                                       const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks, bool need_gradient,
-                                      float gradient_sign) {
+                                      float gradient_sign, int64_t act_scale_log2) {
     TORCH_CHECK(frame.dim() == 2 || (frame.dim() == 3 && frame.size(0) == 1), "energy(): positions must be [atoms, 3] or [1, atoms, 3]");
     const Tensor positions = frame.dim() == 3 ? frame[0] : frame;
     Tensor energy, kept;
@@ -467,7 +469,7 @@ std::pair<Tensor, Tensor> energy_step(const HolderPtr& holder, const Tensor& fra
         holder->publishInline = false;
         c10::hip::HIPGuard guard(aev.device().index());
         void* stream = current_stream(aev.device());
-        MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks);
+        MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks, act_scale_log2);
         if (holder->publishWord) {                              // the deferred check's word goes out with the first network launch
             call.frame.publish_word = holder->publishWord; call.frame.publish_to = holder->publishTo; call.frame.publish_stamp = holder->publishStamp;
         }
@@ -513,10 +515,11 @@ public:
     static Tensor forward(AutogradContext* ctx, const HolderPtr& holder, const Tensor& frame, const c10::optional<Tensor>& cell,
                           const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
                           const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift,
-                          const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks, bool need_gradient) {
+                          const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks, bool need_gradient,
+                          int64_t act_scale_log2) {
         Tensor energy, kept;
         std::tie(energy, kept) = energy_step(holder, frame, cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks, dead_blocks,
-                                             need_gradient, 1.0f);
+                                             need_gradient, 1.0f, act_scale_log2);
         if (need_gradient) {
             ctx->save_for_backward({kept});
             ctx->saved_data["lead"] = frame.dim() == 3;
@@ -539,15 +542,17 @@ public:
                                    g.scalar_type() == torch::kFloat64 ? 1 : 0, out.data_ptr<float>()) != NNPOPS_OK)
             raise_last("NNPOpsANISymmetryFunctions::energy (backward)");
         if (ctx->saved_data["lead"].toBool()) out = out.unsqueeze(0);
-        return {Tensor(), out, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {Tensor(), out, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
 Tensor energy(const c10::optional<HolderPtr>& holder, const Tensor& positions, const c10::optional<Tensor>& cell, const Tensor& rows,
               std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members, const Tensor& planes, const Tensor& floats,
-              const c10::optional<Tensor>& shift, const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks) {
+              const c10::optional<Tensor>& shift, const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks,
+              int64_t act_scale_log2) {
     const bool need = torch::GradMode::is_enabled() && positions.requires_grad();
-    return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks, dead_blocks, need);
+    return EnergyFunction::apply(*holder, positions, cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks, dead_blocks, need,
+                                 act_scale_log2);
 }
 
 // Additive: energy AND forces (-dE/dpositions) of the frame from one call, outside autograd -- what an MD driver asks a model for
@@ -556,11 +561,12 @@ Tensor energy(const c10::optional<HolderPtr>& holder, const Tensor& positions, c
 std::tuple<Tensor, Tensor> energy_forces(const c10::optional<HolderPtr>& holder, const Tensor& positions, const c10::optional<Tensor>& cell,
                                          const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
                                          const Tensor& planes, const Tensor& floats, const c10::optional<Tensor>& shift,
-                                         const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks) {
+                                         const c10::optional<Tensor>& x_blocks, const c10::optional<Tensor>& dead_blocks,
+                                         int64_t act_scale_log2) {
     torch::NoGradGuard no_grad;
     Tensor energy, forces;
     std::tie(energy, forces) = energy_step(*holder, positions.detach(), cell, rows, kind_atoms, widths, members, planes, floats, shift, x_blocks,
-                                           dead_blocks, true, -1.0f);
+                                           dead_blocks, true, -1.0f, act_scale_log2);
     if (positions.dim() == 3) forces = forces.unsqueeze(0);
     return std::make_tuple(energy, forces);
 }
@@ -580,9 +586,9 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
     m.def("operation", operation);
     m.def("aev", aev);
     m.def("energy(__torch__.torch.classes.NNPOpsANISymmetryFunctions.Holder? holder, Tensor positions, Tensor? cell, Tensor rows, int[] kind_atoms, "
-          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None, Tensor? x_blocks=None, Tensor? dead_blocks=None) -> Tensor", energy);
+          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None, Tensor? x_blocks=None, Tensor? dead_blocks=None, int act_scale_log2=4) -> Tensor", energy);
     m.def("energy_forces(__torch__.torch.classes.NNPOpsANISymmetryFunctions.Holder? holder, Tensor positions, Tensor? cell, Tensor rows, int[] kind_atoms, "
-          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None, Tensor? x_blocks=None, Tensor? dead_blocks=None) -> (Tensor, Tensor)",
+          "int[] widths, int members, Tensor planes, Tensor floats, Tensor? shift=None, Tensor? x_blocks=None, Tensor? dead_blocks=None, int act_scale_log2=4) -> (Tensor, Tensor)",
           energy_forces);
 }
 
@@ -1360,10 +1366,10 @@ Tensor GroupedMLP(const Tensor& x, const Tensor& order, std::vector<int64_t> gro
 class FusedMLPFunction : public torch::autograd::Function<FusedMLPFunction> {
 public:
     static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths,
-                          int64_t members, const Tensor& planes, const Tensor& floats, bool need_gradient) {
+                          int64_t members, const Tensor& planes, const Tensor& floats, bool need_gradient, int64_t act_scale_log2) {
         c10::hip::HIPGuard guard(x.device().index());
         void* stream = current_stream(x.device());
-        MlpCall call = mlp_prepare(x, rows, kind_atoms, widths, members, planes, floats, need_gradient);
+        MlpCall call = mlp_prepare(x, rows, kind_atoms, widths, members, planes, floats, need_gradient, c10::nullopt, c10::nullopt, act_scale_log2);
         if (nnpops_mlp_forward(stream, &call.frame, need_gradient ? 1 : 0) != NNPOPS_OK) raise_last("NNPOpsBatchedNN::FusedMLP");
         Tensor total = torch::empty({1}, x.options());
         if (nnpops_mlp_energy_mean(stream, call.energies.data_ptr<float>(), call.energies.numel(), 1.0f, total.data_ptr<float>()) != NNPOPS_OK)
@@ -1381,19 +1387,19 @@ public:
                                                     "use layout='grouped' for that");
         const auto saved = ctx->get_saved_variables();
         TORCH_CHECK(!saved.empty(), "FusedMLP was evaluated without a gradient request");
-        return {saved[0] * grads[0], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {saved[0] * grads[0], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
 Tensor FusedMLP(const Tensor& x, const Tensor& rows, std::vector<int64_t> kind_atoms, std::vector<int64_t> widths, int64_t members,
-                const Tensor& planes, const Tensor& floats) {
+                const Tensor& planes, const Tensor& floats, int64_t act_scale_log2) {
     const bool need = torch::GradMode::is_enabled() && x.requires_grad();
-    return FusedMLPFunction::apply(x, rows, kind_atoms, widths, members, planes, floats, need);
+    return FusedMLPFunction::apply(x, rows, kind_atoms, widths, members, planes, floats, need, act_scale_log2);
 }
 
 TORCH_LIBRARY(NNPOpsBatchedNN, m) {
     m.def("BatchedLinear", BatchedLinear);
-    m.def("FusedMLP(Tensor x, Tensor rows, int[] kind_atoms, int[] widths, int members, Tensor planes, Tensor floats) -> Tensor", FusedMLP);
+    m.def("FusedMLP(Tensor x, Tensor rows, int[] kind_atoms, int[] widths, int members, Tensor planes, Tensor floats, int act_scale_log2=4) -> Tensor", FusedMLP);
     m.def("GroupedMLP(Tensor x, Tensor order, int[] group_sizes, int num_models, int h1, int h2, int h3, Tensor fwd_hi, Tensor fwd_lo, "
           "Tensor bwd_hi, Tensor bwd_lo, Tensor biases, Tensor last_w, float[] last_b) -> Tensor", GroupedMLP);
 }

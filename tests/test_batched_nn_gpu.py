@@ -116,15 +116,16 @@ def test_fused_networks_edge_cases(layout):
     assert e64.dtype == torch.float64 and abs(float(e64) - float(e2)) <= 1e-5 * abs(float(e2)) + 1e-4
 
 
-@pytest.mark.parametrize("layout", ["fused", "gemm"])
-def test_networks_with_huge_weights_keep_the_library_gemms(layout):
-    """The fused path carries activations through fp16 planes (after a 1/16 scale): networks whose weights allow
-    activations beyond ~1e6 are detected when the operand planes are built and evaluated by the library GEMMs instead."""
+@pytest.mark.parametrize("layout,factor", [("fused", 3.0e5), ("gemm", 300.0)])
+def test_networks_with_huge_weights_keep_the_library_gemms(layout, factor):
+    """The fused paths carry activations through fp16 planes after a power-of-two scale: networks whose weights allow
+    activations beyond what the largest scale holds (2^-4 for the split GEMM, 2^-12 for the fused kernels) are detected when
+    the operand planes are built and evaluated by the library GEMMs instead."""
     from nnpops_amd import workloads
     from NNPOps.BatchedNN import TorchANIBatchedNN
     model = workloads.torchani_like_model(n_models=1, seed=31)
     for net in model.neural_networks[0].values():
-        net[2].weight.data *= 300.0
+        net[2].weight.data *= factor
     species = np.array([0, 0, 3, 1], dtype=np.int32)
     numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
     fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout=layout).to(DEV)
@@ -133,6 +134,34 @@ def test_networks_with_huge_weights_keep_the_library_gemms(layout):
     sp = torch.tensor(species, device=DEV).unsqueeze(0)
     aev = torch.rand(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
     torch.testing.assert_close(fused((sp, aev)).energies, grouped((sp, aev)).energies, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("factor", [10.0, 100.0, 500.0])
+def test_fused_networks_pick_the_activation_scale_from_the_weights(factor):
+    """Weights whose crude activation bound exceeds what a 1/16 scale holds in fp16 (real ANI-2x members do) used to fall back to
+    the library GEMMs, ~9x slower; the kernels now take the scale as an argument (nnpops_hip.h: act_scale_log2) and the module
+    picks the smallest one that holds the bound.  Energies and AEV gradients against the float64 networks, the usual bars."""
+    from nnpops_amd import workloads
+    from NNPOps.BatchedNN import TorchANIBatchedNN
+    model = workloads.torchani_like_model(n_models=2, seed=37)
+    for ens in model.neural_networks:
+        for net in ens.values():
+            net[2].weight.data *= factor
+    species = np.array([0, 0, 3, 1, 2, 0, 1, 1, 0, 3], dtype=np.int32)
+    numbers = torch.tensor([[workloads.Z_OF_SPECIES[s] for s in species]], device=DEV)
+    fused = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="fused").to(DEV)
+    assert fused[0].fused_ok and 4 < fused[0].act_scale_log2 <= 12, fused[0].act_scale_log2
+    exact = TorchANIBatchedNN(model.species_converter, model.neural_networks, numbers.cpu(), layout="grouped").to(DEV).double()
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    aev = torch.rand(1, len(species), 1008, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    a1, a2 = aev.clone().requires_grad_(True), aev.double().requires_grad_(True)
+    e1, e2 = fused((sp, a1)).energies, exact((sp, a2)).energies
+    assert e1.dtype == torch.float32
+    assert abs(float(e1) - float(e2)) <= 1e-5 * abs(float(e2)) + 1e-5 * factor, (float(e1), float(e2))
+    e1.sum().backward()
+    e2.sum().backward()
+    err = float((a1.grad.double() - a2.grad).abs().max()) / float(a2.grad.abs().max())
+    assert err <= 1e-4, err
 
 
 def test_gemm_row_maps():

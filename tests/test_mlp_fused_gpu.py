@@ -41,10 +41,10 @@ def _host_reference(kinds, x):
     return e.detach(), xd.grad
 
 
-def _run(kinds_host, x_host, features):
+def _run(kinds_host, x_host, features, act_scale_log2=4):
     from nnpops_amd.capi import FusedMLP
     kinds_dev = [{k: v.to(DEV) for k, v in kd.items()} for kd in kinds_host]
-    mlp = FusedMLP(kinds_dev, features)
+    mlp = FusedMLP(kinds_dev, features, act_scale_log2=act_scale_log2)
     x = x_host.to(DEV).contiguous()
     e = mlp.forward(x, with_gradient=True).clone()
     dx = mlp.input_grad(x)
@@ -105,6 +105,25 @@ def test_small_widths_other_input_width_and_negative_inputs():
     kd["atoms"] = torch.arange(199, -1, -1, dtype=torch.int32)[:150]          # a subset, reversed: rows are a map
     e, dx = _run([kd], x, 384)
     assert float(dx[150:].abs().max()) >= 0.0 and float(dx[torch.arange(0, 50)].abs().max()) == 0.0   # rows of no kind untouched
+
+
+@pytest.mark.parametrize("k,weight_scale", [(4, 1.0), (8, 3.0), (12, 8.0)])
+def test_activation_scale_is_an_argument(k, weight_scale):
+    """nnpops_mlp_frame::act_scale_log2: activations are multiplied by 2^-k before their fp16 split (k = 4 up to round 4).  Larger
+    weights (x8 per layer: activations ~500x) with the scale that holds them, same bars; values outside 4..12 are refused."""
+    from nnpops_amd.capi import FusedMLP
+    gen = torch.Generator().manual_seed(40 + k)
+    x = torch.rand((300, 384), generator=gen)
+    kinds = []
+    for s, widths in enumerate(((96, 64, 32), (128, 96, 64))):
+        kd = _networks(widths, 2, 384, seed=50 + s, scale=weight_scale)
+        kd["atoms"] = torch.arange(s, 300, 2, dtype=torch.int32)
+        kinds.append(kd)
+    _run(kinds, x, 384, act_scale_log2=k)
+    if k == 12:
+        bad = FusedMLP([{key: v.to(DEV) for key, v in kd.items()} for kd in kinds], 384, act_scale_log2=13)
+        with pytest.raises(Exception, match="act_scale_log2"):
+            bad.forward(x.to(DEV), with_gradient=False)
 
 
 def test_packer_layout():
