@@ -922,7 +922,7 @@ def run_torchani(args, R):
     def step():
         tpos.grad = None
         energy = opt((numbers, tpos), cell, pbc).energies
-        energy.sum().backward()
+        energy.backward()               # (one molecule: energies is [1]; the reference's own benchmark calls it the same way, BenchmarkBatchedNN.py:75,92)
         return energy.detach()          # (not the autograd graph: one kept alive from an eager step breaks a later stream capture)
 
     steps, warm = min(args.steps, 200), min(args.warmup, 20)
