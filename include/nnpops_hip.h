@@ -234,9 +234,10 @@ int nnpops_neighbor_pairs_backward(int dtype, int num_atoms, int64_t num_slots, 
                                    const void* grad_distances, void* grad_positions, void* stream);
 /* The same with caller-provided scratch (device, 8-byte aligned, nnpops_neighbor_pairs_backward_workspace_bytes(num_atoms) bytes;
  * the entry point above takes it from the stream-ordered allocator).  Where the reference adds six floating-point atomics per pair
- * (getNeighborPairsCUDA.cu:96-100), the contributions are added as 64-bit fixed-point numbers on one scale for the call: the
- * result does not depend on the order of the additions -- bitwise reproducible -- and is within 2^-40 of the largest contribution
- * per term of the exact sum.  A NaN / infinite contribution makes every output NaN. */
+ * (getNeighborPairsCUDA.cu:96-100), the contributions are added as fixed-point numbers (two 64-bit words per component) on one
+ * scale for the call: the result does not depend on the order of the additions -- bitwise reproducible -- and is within 2^-80 of
+ * the largest contribution per term of the exact sum.  A NaN / infinite contribution makes the gradients of ITS two atoms NaN
+ * (the atoms the reference's atomicAdds poison) and leaves the others what they are without it. */
 int64_t nnpops_neighbor_pairs_backward_workspace_bytes(int num_atoms);
 int nnpops_neighbor_pairs_backward_ws(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors,
                                       const void* deltas, const void* distances, const void* grad_deltas,

@@ -380,11 +380,15 @@ __global__ void to_float_positions(int n3, const T* __restrict__ in, float* __re
 // The reference scatters six floating-point atomicAdds per pair (getNeighborPairsCUDA.cu:93-100): the sums depend on the order
 // in which the hardware happens to serve them.  The op receives nothing but the four tensors -- any list, in any order, possibly
 // edited by the caller -- so there is no row structure to rely on and no owner to gather.  Instead every contribution is turned
-// into a 64-bit FIXED-POINT number on one scale for the whole call (2^40 units for the largest contribution of the call) and added
-// with integer atomics: integer addition is associative, the result is the same bit pattern whatever the order (round 4;
-// tests/test_neighbor_pairs_gpu.py::test_backward_bitwise_reproducible).  One unit is 2^-40 of the largest contribution: 9e-13,
-// far below the resolution of either dtype's own summation.  Three launches: the largest |g| of the call (one integer atomicMax per
-// block), the accumulation, the conversion back.
+// into a FIXED-POINT number on one scale for the whole call and added with integer atomics: integer addition is associative, the
+// result is the same bit pattern whatever the order (round 4; tests/test_neighbor_pairs_gpu.py::test_backward_bitwise_reproducible).
+// Two 64-bit words per component (round 5): the first counts units of 2^-40 of the largest contribution of the call,
+// the second units of 2^-80 (the exact remainder of the first rounding, rounded once more).  A float64 contribution therefore keeps
+// all of its 53 bits unless it is more than 2^27 times smaller than the largest one of the call (float32: never loses any); with
+// the single word of round 4 a pair in near contact coarsened every other atom's gradient to 1e-12 of ITS force.  2^22 terms fit
+// either word.  A NaN / infinite contribution cannot enter an integer sum: it marks its two atoms, whose gradients come out NaN --
+// the atoms the reference's atomicAdds poison (getNeighborPairsCUDA.cu:96-100) -- and nobody else's.  Launches: the largest |g| of
+// the call (one integer atomicMax per block), the accumulation, the conversion back.
 template <typename T>
 __device__ __forceinline__ void pair_gradient(long long k, long long num_slots, const int32_t* __restrict__ neighbors,
                                               const T* __restrict__ deltas, const T* __restrict__ distances,
@@ -400,8 +404,9 @@ __device__ __forceinline__ void pair_gradient(long long k, long long num_slots, 
     for (int c = 0; c < 3; c++) g[c] = grad_deltas[3 * k + c] + deltas[3 * k + c] * gd;     // CUDA.cu:96-99
 }
 
-// scratch: [0] the bit pattern of the largest |g| (non-negative IEEE numbers order like integers), [1] set when a contribution
-// was NaN / infinite, [2 .. 2 + 3N) the accumulators
+// scratch: [0] the bit pattern of the largest |g| (non-negative IEEE numbers order like integers), [1] unused,
+// [2 .. 2 + 3N) the accumulators in units of 2^-40 of the scale, [2 + 3N .. 2 + 6N) in units of 2^-80, [2 + 6N .. 2 + 7N) the atoms
+// that received a NaN / infinite contribution
 template <typename T>
 __global__ __launch_bounds__(256) void pairs_backward_max(long long num_slots, const int32_t* __restrict__ neighbors,
                                                           const T* __restrict__ deltas, const T* __restrict__ distances,
@@ -438,7 +443,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pairs_backward_accumulate(long long num_slots, const int32_t* __restrict__ neighbors,
                                                                  const T* __restrict__ deltas, const T* __restrict__ distances,
                                                                  const T* __restrict__ grad_deltas, const T* __restrict__ grad_distances,
-                                                                 unsigned long long* __restrict__ scratch) {
+                                                                 unsigned long long* __restrict__ scratch, int N) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= num_slots) return;
     int a, b;
@@ -447,27 +452,37 @@ __global__ __launch_bounds__(256) void pairs_backward_accumulate(long long num_s
     if (a < 0) return;
     const double scale = pairs_fixed_scale(scratch);
     unsigned long long* acc = scratch + 2;
+    unsigned long long* fine = acc + 3 * (size_t)N;
+    unsigned long long* marked = fine + 3 * (size_t)N;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const double v = (double)g[c] * scale;
-        // (a NaN / infinite gradient poisons two atoms in the reference; here it cannot enter the fixed-point sum: it raises the
-        //  flag word, and every output of the call is NaN)
-        const long long q = (v == v && fabs(v) < 9.0e18) ? __double2ll_rn(v) : 0;
-        if (q != 0) {
-            atomicAdd(&acc[3 * (size_t)a + c], (unsigned long long)q);
-            atomicAdd(&acc[3 * (size_t)b + c], (unsigned long long)(-q));
+        const double v = (double)g[c] * scale;                           // |v| < 2^40 for every finite g
+        if (v == v && fabs(v) < 9.0e18) {
+            const long long q = __double2ll_rn(v);
+            const long long q2 = __double2ll_rn((v - (double)q) * 1099511627776.0);      // (the remainder is exact; |q2| <= 2^39)
+            if (q != 0) {
+                atomicAdd(&acc[3 * (size_t)a + c], (unsigned long long)q);
+                atomicAdd(&acc[3 * (size_t)b + c], (unsigned long long)(-q));
+            }
+            if (q2 != 0) {
+                atomicAdd(&fine[3 * (size_t)a + c], (unsigned long long)q2);
+                atomicAdd(&fine[3 * (size_t)b + c], (unsigned long long)(-q2));
+            }
+        } else {
+            marked[a] = 1; marked[b] = 1;                                // (benign race: everyone writes the same value)
         }
-        if (!(v == v) || !(fabs(v) < 9.0e18)) scratch[1] = 1;        // (benign race: everyone writes the same value)
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pairs_backward_finish(int n3, const unsigned long long* __restrict__ scratch, T* __restrict__ grad_positions) {
+__global__ __launch_bounds__(256) void pairs_backward_finish(int N, const unsigned long long* __restrict__ scratch, T* __restrict__ grad_positions) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n3) return;
-    const bool poisoned = scratch[1] != 0;
+    if (k >= 3 * N) return;
+    const unsigned long long* acc = scratch + 2;
+    const unsigned long long* fine = acc + 3 * (size_t)N;
+    const bool poisoned = fine[3 * (size_t)N + k / 3] != 0;
     const double inv = 1.0 / pairs_fixed_scale(scratch);
-    const double v = (double)(long long)scratch[2 + k] * inv;
+    const double v = ((double)(long long)acc[k] + (double)(long long)fine[k] * (1.0 / 1099511627776.0)) * inv;
     grad_positions[k] = poisoned ? (T)NAN : (T)v;
 }
 
@@ -618,7 +633,7 @@ int backward_impl(int N, long long num_slots, const int32_t* neighbors, const T*
                   const T* grad_deltas, const T* grad_distances, T* grad_positions, void* workspace, hipStream_t stream) {
     unsigned long long* scratch = (unsigned long long*)workspace;
     {
-        const long long words = 2 * (2 + 3 * (long long)N);
+        const long long words = 2 * (2 + 7 * (long long)N);
         hipLaunchKernelGGL(zero_words, dim3((unsigned)std::min<long long>(div_up(words, 256), 4096)), dim3(256), 0, stream, words, (int*)scratch);
     }
     if (num_slots > 0) {
@@ -626,9 +641,9 @@ int backward_impl(int N, long long num_slots, const int32_t* neighbors, const T*
         hipLaunchKernelGGL(pairs_backward_max<T>, dim3(nb_max), dim3(256), 0, stream, num_slots, neighbors, deltas, distances, grad_deltas,
                            grad_distances, scratch);
         hipLaunchKernelGGL(pairs_backward_accumulate<T>, dim3(div_up(num_slots, 256)), dim3(256), 0, stream, num_slots, neighbors, deltas,
-                           distances, grad_deltas, grad_distances, scratch);
+                           distances, grad_deltas, grad_distances, scratch, N);
     }
-    hipLaunchKernelGGL(pairs_backward_finish<T>, dim3(div_up(3 * N, 256)), dim3(256), 0, stream, 3 * N, scratch, grad_positions);
+    hipLaunchKernelGGL(pairs_backward_finish<T>, dim3(div_up(3 * N, 256)), dim3(256), 0, stream, N, scratch, grad_positions);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }
@@ -663,7 +678,7 @@ int nnpops_neighbor_pairs_forward(int dtype, int num_atoms, const void* position
 }
 
 int64_t nnpops_neighbor_pairs_backward_workspace_bytes(int num_atoms) {
-    return num_atoms < 0 ? 0 : (int64_t)sizeof(unsigned long long) * (2 + 3 * (int64_t)num_atoms);
+    return num_atoms < 0 ? 0 : (int64_t)sizeof(unsigned long long) * (2 + 7 * (int64_t)num_atoms);
 }
 
 int nnpops_neighbor_pairs_backward_ws(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors, const void* deltas,

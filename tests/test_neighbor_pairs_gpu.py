@@ -118,6 +118,56 @@ def test_backward_bitwise_reproducible(dtype):
     np.testing.assert_allclose(first.cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
 
 
+def test_backward_keeps_float64_resolution_beside_one_huge_contribution():
+    """One pair in near contact (a gradient 1e9 times the others') sets the scale of the fixed-point sums; the second word keeps the
+    other atoms' float64 gradients to 1e-13 of their own size (one word, round 4: 1e-12 of the LARGEST contribution = 1e-3 of theirs)."""
+    from nnpops_amd.capi import neighbor_pairs_backward, neighbor_pairs_forward
+    rng = np.random.default_rng(15)
+    n = 400
+    pos = 9 * rng.random((n, 3))
+    nb, dl, ds, cnt = neighbor_pairs_forward(torch.tensor(pos, device=DEV), 3.0, 40000)
+    gd = rng.standard_normal(tuple(dl.shape))
+    gs = rng.standard_normal(tuple(ds.shape))
+    k = int(torch.nonzero(nb[0] >= 0)[7])
+    gd[k] *= 1.0e9
+    got = neighbor_pairs_backward(n, nb, dl, ds, torch.tensor(gd, device=DEV), torch.tensor(gs, device=DEV)).cpu().numpy()
+    ref = neighbor_pairs_backward_oracle(n, nb.cpu().numpy(), dl.cpu().numpy(), ds.cpu().numpy(), gd, gs)
+    a, b = int(nb[0, k]), int(nb[1, k])
+    others = np.setdiff1d(np.arange(n), [a, b])
+    small = np.abs(ref[others]).max()
+    assert small < 1e3 and np.abs(ref[[a, b]]).max() > 1e8
+    assert np.abs(got[others] - ref[others]).max() <= 1e-12 * small
+    np.testing.assert_allclose(got[[a, b]], ref[[a, b]], rtol=1e-13)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_backward_nan_stays_with_the_two_atoms_of_its_pair(dtype):
+    """A pair at distance zero (grad_distance / 0) poisons its two atoms in the reference (getNeighborPairsCUDA.cu:96-100: the
+    atomicAdds of a NaN); every other atom's gradient is what it would be without that pair."""
+    from nnpops_amd.capi import neighbor_pairs_backward, neighbor_pairs_forward
+    rng = np.random.default_rng(16)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    n = 300
+    pos = (8 * rng.random((n, 3))).astype(npdt)
+    nb, dl, ds, cnt = neighbor_pairs_forward(torch.tensor(pos, device=DEV), 3.0, 40000)
+    gd = torch.tensor(rng.standard_normal(tuple(dl.shape)).astype(npdt), device=DEV)
+    gs = torch.tensor(rng.standard_normal(tuple(ds.shape)).astype(npdt), device=DEV)
+    k = int(torch.nonzero(nb[0] >= 0)[11])
+    a, b = int(nb[0, k]), int(nb[1, k])
+    ds_bad, dl_bad = ds.clone(), dl.clone()
+    ds_bad[k] = 0
+    dl_bad[k] = 0
+    got = neighbor_pairs_backward(n, nb, dl_bad, ds_bad, gd, gs).cpu().numpy()
+    nb_without = nb.clone()
+    nb_without[:, k] = -1
+    clean = neighbor_pairs_backward(n, nb_without, dl, ds, gd, gs).cpu().numpy()
+    assert np.isnan(got[[a, b]]).all()
+    others = np.setdiff1d(np.arange(n), [a, b])
+    assert np.isfinite(got[others]).all()
+    tol = 1e-5 if npdt == np.float32 else 1e-12
+    np.testing.assert_allclose(got[others], clean[others], rtol=tol, atol=tol * np.abs(clean).max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("box", [[[10, 0, 0], [0, 10, 0], [0, 0, 10]], [[10, 0, 0], [2, 12, 0], [0, 1, 11]],
                                  [[10, 0, 0], [-2, 12, 0], [0, -1, 11]]])
