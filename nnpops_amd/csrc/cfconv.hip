@@ -321,6 +321,7 @@ struct ConvParams {
     int N, W, G;
     float cutoff, sigma_inv;
     int activation;          // 0 shifted softplus, 1 tanh
+    int skip_filter_store;   // backward, half-list path: the filter rows of this list are still in `filt` from the forward call
 };
 
 template <int ACT>
@@ -1419,7 +1420,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
             const int rr = grp * 4 + q;
             const int p = 16 * t + rr;
             const float fc = ps[16 + rr];
-            if (p < pairs) {                                // uniform over the 16 lanes of a row
+            if (p < pairs && !(BWD && P.skip_filter_store)) {      // uniform over the 16 lanes of a row
                 float* frow = filt + (size_t)p * W + col;
 #pragma unroll
                 for (int cb = 0; cb < NCB; cb++)
@@ -1549,6 +1550,7 @@ struct nnpops_cfconv_neighbors {
     float* d_half_r = nullptr;
     int2* d_half_ij = nullptr;
     bool want_half = false, half_built = false;
+    unsigned long long epoch = 0;      // counts the builds: what a convolution keeps per list (its filter rows) is valid for one epoch
     bool cell_ordered = false;      // the last build went through the cell grid: d_sorted_pos lists the atoms in cell order
     int pair_cap() const { return (int)std::min<size_t>((size_t)N * cap / 2, (size_t)INT32_MAX - 1); }
 };
@@ -1600,6 +1602,11 @@ struct nnpops_cfconv {
     // filter rows F[pid][W] and pair forces s[pid] of the half-list path (+1: the all-zero row); sized on first use
     float *d_filt = nullptr, *d_pair_s = nullptr;
     size_t spill_rows = 0;
+    // whose filter rows d_filt holds (the forward call writes them; a backward call on the same build of the same list reads them
+    // back instead of storing them again: the same numbers to the last bit or two, 67 MB per call at config 3)
+    const void* filt_list = nullptr;
+    unsigned long long filt_epoch = 0;
+    bool reuse_filters = true;                     // $NNPOPS_CFCONV_REUSE_FILTERS=0: always store
 };
 
 extern "C" {
@@ -1694,6 +1701,7 @@ int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t h, const float* posi
     NNPOPS_HIP_TRY(hipGetLastError());
     h->built = true;
     h->half_built = false;
+    h->epoch++;
     h->cell_ordered = use_cells;
     if (h->want_half) return launch_half_build(h, h->stream);
     return NNPOPS_OK;
@@ -1854,6 +1862,7 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
         h->split_ok = max_w2 < limit && max_y < limit && max_dy < limit;
         int level = 2;                                      // 0: fp32 only, 1: second layer split, 2: both layers where possible
         if (const char* e = std::getenv("NNPOPS_CFCONV_SPLIT")) level = std::atoi(e);
+        if (const char* e = std::getenv("NNPOPS_CFCONV_REUSE_FILTERS")) h->reuse_filters = std::atoi(e) != 0;
         h->split_ok = h->split_ok && level != 0;
         h->split_l1 = h->split_ok && level >= 2 && G + 1 <= 64 &&
                       h2_weight_bytes_l1h(W, G) + kMaxWavesPerBlock * h2_wave_bytes(W) <= (size_t)160 * 1024;
@@ -1974,7 +1983,7 @@ int ensure_half_path(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb) {
     const size_t need = (size_t)nb->pair_cap() + 1;
     if (h->spill_rows < need) {                             // (first use, or the neighbour rows have grown: not capturable)
         dev_free(h->d_filt); dev_free(h->d_pair_s);
-        h->d_filt = nullptr; h->d_pair_s = nullptr; h->spill_rows = 0;
+        h->d_filt = nullptr; h->d_pair_s = nullptr; h->spill_rows = 0; h->filt_list = nullptr;
         int rc;
         if ((rc = dev_alloc(&h->d_filt, need * h->p.W))) return rc;
         if ((rc = dev_alloc(&h->d_pair_s, need))) return rc;
@@ -2001,13 +2010,20 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
                 auto k = h->split_l1 ? cfconv_filters_h2<ACT, NCB, BWD, true> : cfconv_filters_h2<ACT, NCB, BWD, false>;
                 if (lds > 64 * 1024)
                     NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, h->p, h->d_w1b, h->d_w1h, h->d_w1l, h->d_w2h,
+                ConvParams cp = h->p;
+                if (BWD && h->reuse_filters && h->filt_list == nb && h->filt_epoch == nb->epoch) {
+                    // (not while the stream is being captured: a replay may follow another build than the capture did)
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) cp.skip_filter_store = 1;
+                }
+                hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, cp, h->d_w1b, h->d_w1h, h->d_w1l, h->d_w2h,
                                    h->d_w2l, h->d_b2, nb->d_half_off, nb->d_half_r, nb->d_half_ij, pair_cap, x, gout, h->d_filt,
                                    h->d_pair_s);
                 launched = true;
             }
         }
     }
+    h->filt_list = nb; h->filt_epoch = nb->epoch;           // (either kernel, either direction, leaves this list's rows in d_filt)
     if (!launched) {
         const size_t budget = 160 * 1024 / sizeof(float);
         const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats_bwd(h->p.W);

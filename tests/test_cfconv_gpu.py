@@ -165,6 +165,48 @@ def test_half_list_follows_rebuilds():
     assert not np.array_equal(first[0], second[0])
 
 
+def test_backward_reads_back_the_filter_rows_of_the_forward_call(monkeypatch):
+    """A backward call that follows a forward call on the same build of the same list does not store the filter rows again (the
+    gather reads the forward call's).  Same results as with $NNPOPS_CFCONV_REUSE_FILTERS=0 (to the rounding of one filter value);
+    after a rebuild on moved atoms the kept rows are stale and are not used: bit for bit what always storing gives."""
+    from nnpops_amd.capi import CFConv, CFConvNeighbors
+    n, W, G = 1500, 128, 50
+    pos, _, box = workloads.random_box(n, seed=71)
+    rng = np.random.default_rng(72)
+    w1, w2 = (0.3 * rng.standard_normal((W, G))).astype(np.float32), (0.2 * rng.standard_normal((W, W))).astype(np.float32)
+    b1, b2 = (0.3 * rng.standard_normal(W)).astype(np.float32), (0.3 * rng.standard_normal(W)).astype(np.float32)
+    tx, tg = torch.tensor(rng.standard_normal((n, W)).astype(np.float32), device=DEV), torch.tensor(rng.standard_normal((n, W)).astype(np.float32), device=DEV)
+    tbox = torch.tensor(box, device=DEV)
+    moved = (pos + 0.3 * rng.standard_normal(pos.shape)).astype(np.float32)
+    t1, t2 = torch.tensor(pos, device=DEV), torch.tensor(moved, device=DEV)
+
+    def run(reuse, forward_first):
+        monkeypatch.setenv("NNPOPS_CFCONV_REUSE_FILTERS", "1" if reuse else "0")
+        nb, cf = CFConvNeighbors(n, 5.0, True), CFConv(n, W, G, 5.0, 0.1, "ssp", w1, b1, w2, b2, periodic=True)
+        out = []
+        nb.build(t1, tbox)
+        if forward_first:
+            out.append(cf.compute(nb, t1, tx, tbox).clone())
+        out += [t.clone() for t in cf.backprop(nb, t1, tx, tg, tbox)]
+        nb.build(t2, tbox)                              # other pairs: the rows kept from the first build must not be read
+        out += [t.clone() for t in cf.backprop(nb, t2, tx, tg, tbox)]
+        out += [t.clone() for t in cf.backprop(nb, t2, tx, tg, tbox)]      # (and a second backward call on the same build may)
+        torch.cuda.synchronize()
+        return out
+
+    kept, stored, alone = run(True, True), run(False, True), run(True, False)
+
+    def close(a, b):
+        return float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+    # (the forward kernel's rows and the backward kernel's are the same numbers up to the last bit: bias added at different points)
+    assert torch.equal(kept[0], stored[0]) and close(kept[1], stored[1]) and close(kept[2], stored[2])
+    # after the rebuild the first backward call stores its own rows, the second one reads those back: bit for bit what always storing gives
+    for k in (3, 4, 5, 6):
+        assert torch.equal(kept[k], stored[k]) and torch.equal(kept[k], alone[k - 1])
+    assert torch.equal(kept[3], kept[5]) and torch.equal(kept[4], kept[6]) and not close(kept[1], kept[3])
+
+
 def test_half_list_with_rows_longer_than_a_wave():
     """Twice the usual density: ~105 neighbours per atom overflow the 64-entry rows, check() grows them to 128 and the
     pair slots with them; the slot lookup and the gather then walk rows in two passes of 64."""

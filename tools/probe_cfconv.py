@@ -25,7 +25,9 @@ PATCHES = [
      f"                float sc = 0.f;\n                if (!({PM} & 1))\n#pragma unroll\n                for (int cb = 0; cb < NCB; cb++) {{\n                    const size_t c = (size_t)cb * 16 + col;\n", 1),
     # 2: filter rows not stored
     ("            if (p < pairs) {                                // uniform over the 16 lanes of a row\n                float* frow = filt + (size_t)p * W + col;\n",
-     f"            if (p < pairs && !({PM} & 2)) {{\n                float* frow = filt + (size_t)p * W + col;\n", 2),
+     f"            if (p < pairs && !({PM} & 2)) {{\n                float* frow = filt + (size_t)p * W + col;\n", 1),
+    ("            if (p < pairs && !(BWD && P.skip_filter_store)) {      // uniform over the 16 lanes of a row\n                float* frow = filt + (size_t)p * W + col;\n",
+     f"            if (p < pairs && !(BWD && P.skip_filter_store) && !({PM} & 2)) {{\n                float* frow = filt + (size_t)p * W + col;\n", 1),
     # 4: no derivative pass of layer 1
     ("                l1_pass(std::true_type{}, dacc);\n", f"                if (!({PM} & 4)) l1_pass(std::true_type{{}}, dacc);\n", 1),
     # 8: no second pass of layer 2 (dY1)
