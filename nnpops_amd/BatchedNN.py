@@ -300,6 +300,9 @@ class _FusedSpeciesNN(_SpeciesGroupedNN):
         self.act_scale_log2 = k
         self.fused_ok = (worst < 62500.0 * 2.0 ** k
                          and F % 8 == 0 and F <= 1024 and max(widths) <= 256 and kinds <= 8 and int(w6.shape[2]) == 1)
+        holder = getattr(self, 'holder', None)         # (the one-node step keeps dE/dAEV between the steps, cleared once for ONE list of
+        if holder is not None:                         #  live blocks: torch_binding.cpp, Holder::gradCache)
+            holder.reset_gradient_cache()
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)

@@ -399,6 +399,12 @@ public:
     // energy_step: the capacity check's word is published by nnpops_mlp_forward (frame.publish_*) instead of a launch of its own
     bool publishInline = false;
     const int32_t* publishWord = nullptr; int32_t* publishTo = nullptr; int32_t publishStamp = 0;
+    // energy_step: dE/dAEV of the frame, kept between the steps.  The networks write only the column blocks the molecule's species
+    // can fill (x_blocks); the others are zero and stay zero -- cleared once, when the buffer is made, instead of by every step
+    // (7 of the 8 MB a step of the 2 001-atom water box used to write there).  Valid for one list of live blocks.
+    Tensor gradCache;
+    const void* gradCacheBlocks = nullptr;
+    void resetGradientCache() { gradCache = Tensor(); gradCacheBlocks = nullptr; }      // (the networks' live blocks have changed: BatchedNN.py)
 private:
 };
 
@@ -497,7 +503,18 @@ std::pair<Tensor, Tensor> energy_step(const HolderPtr& holder, const Tensor& fra
             if (rc != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
         }
         if (need_gradient) {
-            Tensor daev = torch::empty_like(aev);
+            Tensor daev;
+            if (call.frame.dx_partial != nullptr && x_blocks.has_value()) {     // (the sum over the members writes the live blocks only)
+                if (!holder->gradCache.defined() || holder->gradCache.sizes() != aev.sizes() || holder->gradCache.device() != aev.device() ||
+                    holder->gradCacheBlocks != x_blocks->data_ptr()) {
+                    holder->gradCache = torch::zeros_like(aev);
+                    holder->gradCacheBlocks = x_blocks->data_ptr();
+                }
+                daev = holder->gradCache;
+                call.frame.num_dead_groups = 0;
+            } else {
+                daev = torch::empty_like(aev);
+            }
             call.frame.dx = daev.data_ptr<float>(); call.frame.lddx = (int)daev.size(1); call.frame.dx_scale = gradient_sign / (float)members;
             if (nnpops_mlp_input_grad(stream, &call.frame) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::energy");
             kept = holder->backwardFused(daev)[1];
@@ -581,6 +598,7 @@ TORCH_LIBRARY(NNPOpsANISymmetryFunctions, m) {
         .def("set_check_interval", &Holder::setCheckInterval)
         .def("overflow_flag", &Holder::overflowFlag)
         .def("set_molecules", &Holder::setMolecules)
+        .def("reset_gradient_cache", &Holder::resetGradientCache)
         .def_pickle([](const HolderPtr& self) -> std::string { return Holder::serialize(self); },
                     [](const std::string& state) -> HolderPtr { return Holder::deserialize(state); });
     m.def("operation", operation);

@@ -641,3 +641,39 @@ def test_energy_and_forces_in_one_call_equals_forward_plus_backward():
         assert torch.equal(e3, e2) and torch.equal(f3, f2)
         with pytest.raises(ValueError, match='"pbc" has to be defined'):
             module.energy_and_forces((numbers, p.detach()), cell, None)
+
+
+def test_gradient_buffer_kept_between_steps_follows_the_live_blocks():
+    """The one-node step keeps dE/dAEV between the steps and clears it ONCE (the networks write the live column blocks only, the others
+    stay zero: torch_binding.cpp, Holder::gradCache).  Forces are the same bits step after step; when the list of live blocks changes
+    (set_live_blocks with more blocks than the species need) the buffer is made again and the forces do not change beyond rounding
+    (the extra blocks multiply AEV columns that are identically zero); a frame with other positions in between leaves nothing behind."""
+    from NNPOps import OptimizedTorchANI
+    model = workloads.torchani_like_model(n_models=2, seed=12)
+    pos, species, box = workloads.water_box(90, seed=4)
+    numbers = _numbers(species)
+    module = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True], device=DEV)
+
+    def forces(xyz):
+        p = torch.tensor(xyz, device=DEV).unsqueeze(0).requires_grad_(True)
+        module((numbers, p), cell, pbc).energies.backward()
+        return p.grad.clone()
+
+    f0 = forces(pos)
+    moved = pos + 0.05 * np.random.default_rng(1).standard_normal(pos.shape).astype(np.float32)
+    f_moved = forces(moved)
+    assert torch.equal(forces(pos), f0) and not torch.equal(f_moved, f0)
+    nets = module.neural_networks[0]
+    live = list(nets.live_blocks)
+    assert 0 < len(live) < 63
+    wider = sorted(set(live) | {b for b in range(63) if b % 5 == 0})
+    nets.set_live_blocks(wider)
+    f_wide = forces(pos)
+    assert float((f_wide - f0).abs().max()) <= 1e-6 * float(f0.abs().max())
+    nets.set_live_blocks(live)
+    assert torch.equal(forces(pos), f0)
+    plain = OptimizedTorchANI(model, numbers.cpu(), fused_step=False).to(DEV)          # the four-module composition
+    p = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+    plain((numbers, p), cell, pbc).energies.backward()
+    assert float((p.grad - f0).abs().max()) <= 1e-5 * float(f0.abs().max())
