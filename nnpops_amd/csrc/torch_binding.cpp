@@ -75,13 +75,17 @@ struct MlpCall {
     Tensor energies;                  // [atoms][members]
     std::vector<Tensor> keep;         // workspaces
 };
+// workspaces of a frame that a caller with a home for them (the AEV holder of the one-node step) keeps between the steps
+struct MlpScratch {
+    Tensor partial, energies;
+};
 
 int64_t mlp_halves(int64_t rows, int64_t cols) { return nnpops_mlp_packed_halves((int)rows, (int)cols); }
 
 MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64_t>& kind_atoms, const std::vector<int64_t>& widths,
                     int64_t members, const Tensor& planes, const Tensor& floats, bool with_gradient,
                     const c10::optional<Tensor>& x_blocks = c10::nullopt, const c10::optional<Tensor>& dead_blocks = c10::nullopt,
-                    int64_t act_scale_log2 = 4) {
+                    int64_t act_scale_log2 = 4, MlpScratch* scratch = nullptr) {
     TORCH_CHECK(act_scale_log2 >= 4 && act_scale_log2 <= 12, "act_scale_log2: 4..12 (activations are scaled by 2^-k before the fp16 split)");
     TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.scalar_type() == torch::kFloat32 && x.is_contiguous(),
                 "the fused networks take a contiguous [atoms, features] float32 device tensor");
@@ -110,12 +114,20 @@ MlpCall mlp_prepare(const Tensor& x, const Tensor& rows, const std::vector<int64
         fr.dead_groups = dead_blocks->numel() ? dead_blocks->data_ptr<int32_t>() : nullptr;
         fr.num_dead_groups = (int)dead_blocks->numel();
     }
+    auto fresh = [&](Tensor& kept, at::IntArrayRef shape) {      // (a kept workspace of the right shape on the right device, or a new one)
+        if (!kept.defined() || kept.sizes() != shape || kept.device() != x.device()) kept = torch::empty(shape, x.options());
+        return kept;
+    };
     if (in_forward) {
-        Tensor partial = torch::empty({members, atoms, F}, x.options());
+        Tensor local;
+        Tensor partial = fresh(scratch ? scratch->partial : local, {members, atoms, F});
         fr.dx_partial = partial.data_ptr<float>();
         c.keep.push_back(partial);
     }
-    c.energies = torch::empty({atoms, members}, x.options());
+    {
+        Tensor local;
+        c.energies = fresh(scratch ? scratch->energies : local, {atoms, members});
+    }
     fr.energies = c.energies.data_ptr<float>();
     const at::Half* ph = planes.data_ptr<at::Half>();
     const float* pf = floats.data_ptr<float>();
@@ -404,6 +416,7 @@ public:
     // (7 of the 8 MB a step of the 2 001-atom water box used to write there).  Valid for one list of live blocks.
     Tensor gradCache;
     const void* gradCacheBlocks = nullptr;
+    MlpScratch mlpScratch;            // ... and the networks' workspaces of a step (per-member gradient shares, per-atom energies)
     void resetGradientCache() { gradCache = Tensor(); gradCacheBlocks = nullptr; }      // (the networks' live blocks have changed: BatchedNN.py)
 private:
 };
@@ -475,7 +488,8 @@ std::pair<Tensor, Tensor> energy_step(const HolderPtr& holder, const Tensor& fra
         holder->publishInline = false;
         c10::hip::HIPGuard guard(aev.device().index());
         void* stream = current_stream(aev.device());
-        MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks, act_scale_log2);
+        MlpCall call = mlp_prepare(aev, rows, kind_atoms, widths, members, planes, floats, need_gradient, x_blocks, dead_blocks, act_scale_log2,
+                                   &holder->mlpScratch);
         if (holder->publishWord) {                              // the deferred check's word goes out with the first network launch
             call.frame.publish_word = holder->publishWord; call.frame.publish_to = holder->publishTo; call.frame.publish_stamp = holder->publishStamp;
         }
