@@ -25,6 +25,7 @@
 //     time so every weight read from LDS feeds 8 (x2 channels) FMAs; weights streamed through the caches
 //     when they do not fit in LDS (W > 128).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1550,7 +1551,7 @@ struct nnpops_cfconv_neighbors {
     float* d_half_r = nullptr;
     int2* d_half_ij = nullptr;
     bool want_half = false, half_built = false;
-    unsigned long long epoch = 0;      // counts the builds: what a convolution keeps per list (its filter rows) is valid for one epoch
+    unsigned long long epoch = 0;      // number of the last build (process-wide counter): what a convolution keeps per list (its filter rows) is valid for one build
     bool cell_ordered = false;      // the last build went through the cell grid: d_sorted_pos lists the atoms in cell order
     int pair_cap() const { return (int)std::min<size_t>((size_t)N * cap / 2, (size_t)INT32_MAX - 1); }
 };
@@ -1701,7 +1702,8 @@ int nnpops_cfconv_neighbors_build(nnpops_cfconv_neighbors_t h, const float* posi
     NNPOPS_HIP_TRY(hipGetLastError());
     h->built = true;
     h->half_built = false;
-    h->epoch++;
+    static std::atomic<unsigned long long> build_counter{0};      // (unique across lists: a new list at a freed list's address is another build)
+    h->epoch = ++build_counter;
     h->cell_ordered = use_cells;
     if (h->want_half) return launch_half_build(h, h->stream);
     return NNPOPS_OK;

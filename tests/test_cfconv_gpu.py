@@ -191,6 +191,12 @@ def test_backward_reads_back_the_filter_rows_of_the_forward_call(monkeypatch):
         nb.build(t2, tbox)                              # other pairs: the rows kept from the first build must not be read
         out += [t.clone() for t in cf.backprop(nb, t2, tx, tg, tbox)]
         out += [t.clone() for t in cf.backprop(nb, t2, tx, tg, tbox)]      # (and a second backward call on the same build may)
+        # a NEW list (possibly at the freed one's address) after a forward call on the old one: another build, whatever its address
+        cf.compute(nb, t2, tx, tbox)
+        del nb
+        nb = CFConvNeighbors(n, 5.0, True)
+        nb.build(t1, tbox)
+        out += [t.clone() for t in cf.backprop(nb, t1, tx, tg, tbox)]
         torch.cuda.synchronize()
         return out
 
@@ -202,7 +208,7 @@ def test_backward_reads_back_the_filter_rows_of_the_forward_call(monkeypatch):
     # (the forward kernel's rows and the backward kernel's are the same numbers up to the last bit: bias added at different points)
     assert torch.equal(kept[0], stored[0]) and close(kept[1], stored[1]) and close(kept[2], stored[2])
     # after the rebuild the first backward call stores its own rows, the second one reads those back: bit for bit what always storing gives
-    for k in (3, 4, 5, 6):
+    for k in (3, 4, 5, 6, 7, 8):
         assert torch.equal(kept[k], stored[k]) and torch.equal(kept[k], alone[k - 1])
     assert torch.equal(kept[3], kept[5]) and torch.equal(kept[4], kept[6]) and not close(kept[1], kept[3])
 
