@@ -67,6 +67,7 @@ struct nnpops_ani {
     int scatter_mode = -1;          // leg forces stored in the receiving atom's row by the two-wave angular backward (ani_angular_bwd.h):
                                     // -1 where every backward launch runs two waves per atom (dense systems), 0 / 1 forced ($NNPOPS_ANI_SCATTER)
     bool scatter_now = false;       // ... decided by backprop() for the call in progress
+    bool last_fused_build = false;  // the last compute() ran the one-launch build + forward (what describe() reports)
     bool fine_grid = true;          // cell grid of half-cutoff cells where it fits (celllist.h: decide_grid)
     bool fwd_row_via_lds = true;    // the angular row leaves as whole-wave stores from an LDS copy
     int fwd_occ = 7;                // A/B: register budget of the forward kernel (waves per SIMD)
@@ -887,7 +888,8 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
     for (int q = 0; q < nspans; q++) {
         const Span& sp = spans[q];
         const dim3 sgrid(div_up(sp.nw, wpg_b));
-        if (build_forward_fused(h, angular)) {                 // one launch: build + radial + angular forward (timed as the build)
+        h->last_fused_build = build_forward_fused(h, angular);
+        if (h->last_fused_build) {                             // one launch: build + radial + angular forward (timed as the build)
             KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
             const BuildInputs in{box, h->d_grid, h->d_cell_start, h->d_sorted_cell, h->d_sorted_pos, h->d_hist, positions, h->d_species,
                                  h->d_segment, use_cells ? 1 : 0, per ? 1 : 0};
@@ -1267,7 +1269,10 @@ int nnpops_ani_describe(nnpops_ani_t h, char* text, int capacity) {
                   "chunk=%d classes=%d cells=%d scatter=%d row_major_walk=%d",
                   h->forward_kernel == 2 ? "mfma" : h->forward_kernel == 1 ? "chunked" : "merge", h->backward_kernel, (int)h->generic,
                   (int)uni, (int)(uni && h->fwd_grid), (int)(uni && h->fwd_grid && shape2x && h->fwd_literal), (int)h->fwd_dynamic,
-                  (int)(h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0), h->cap, h->cap_angular, h->fwd_chunk, (int)h->bwd_classes.size(), (int)h->last_used_cells,
+                  (int)(h->computed ? h->last_fused_build : (h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0)), h->cap, h->cap_angular,
+                  // (the chunk the forward kernel is launched with, not the configured floor: ADVICE r04)
+                  h->generic ? h->fwd_chunk : forward_chunk(h, (size_t)h->cap_angular * 2 * sizeof(float4), (size_t)(h->nfrp + h->nfzp) * sizeof(float)),
+                  (int)h->bwd_classes.size(), (int)h->last_used_cells,
                   (int)h->scatter_now, h->hp.tri_row_major);      // (scatter: the last backprop() stored the leg forces in the receivers' rows)
     return NNPOPS_OK;
 }
