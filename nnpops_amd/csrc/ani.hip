@@ -891,6 +891,7 @@ int nnpops_ani_compute_strided(nnpops_ani_t h, const float* positions, const flo
         h->last_fused_build = build_forward_fused(h, angular);
         if (h->last_fused_build) {                             // one launch: build + radial + angular forward (timed as the build)
             KernelTimer timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream);
+            KernelTimer merged_timer(h, NNPOPS_ANI_K_NEIGHBORS, sp.stream, /*merged=*/true);      // (merge mode brackets the same launch: ADVICE r04)
             const BuildInputs in{box, h->d_grid, h->d_cell_start, h->d_sorted_cell, h->d_sorted_pos, h->d_hist, positions, h->d_species,
                                  h->d_segment, use_cells ? 1 : 0, per ? 1 : 0};
             const BuildOutputs out{h->d_nbr, h->d_recA, h->d_recB, h->d_ids, h->d_tri, h->d_cnt_a, h->d_cnt_ro, h->d_cnt_pos, h->d_status, radial, h->ld_radial};
