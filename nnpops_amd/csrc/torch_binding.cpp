@@ -200,7 +200,10 @@ public:
         if (!impl) throw std::runtime_error("overflow_flag() called before forward()");
         const int32_t* word = nullptr;
         if (nnpops_ani_overflow_word(impl, &word) != NNPOPS_OK) raise_last("NNPOpsANISymmetryFunctions::overflow_flag");
-        return torch::from_blob(const_cast<int32_t*>(word), {1}, torch::TensorOptions().device(device).dtype(torch::kInt32));
+        // (the tensor keeps this Holder -- and with it the handle that owns the word -- alive: ADVICE r04; the word itself is cleared by
+        //  every capacity check, so "sticky" means between two checks)
+        auto self = c10::intrusive_ptr<Holder>::unsafe_reclaim_from_nonowning(this);
+        return torch::from_blob(const_cast<int32_t*>(word), {1}, [self](void*) {}, torch::TensorOptions().device(device).dtype(torch::kInt32));
     }
 
     void setCheckInterval(int64_t interval) {

@@ -677,3 +677,22 @@ def test_gradient_buffer_kept_between_steps_follows_the_live_blocks():
     p = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
     plain((numbers, p), cell, pbc).energies.backward()
     assert float((p.grad - f0).abs().max()) <= 1e-5 * float(f0.abs().max())
+
+
+def test_overflow_flag_outlives_its_module():
+    """overflow_flag() is a view of a word the AEV handle owns; the tensor keeps the Holder (and the handle) alive, so reading it after
+    the module is gone is a read of live memory (it used to dangle)."""
+    import gc
+    from NNPOps.SymmetryFunctions import TorchANISymmetryFunctions
+    pos, species, box = workloads.water_box(40, seed=2)
+    module = TorchANISymmetryFunctions(FakeConverter(), fake_aev_computer(), _numbers(species).cpu()).to(DEV)
+    sp = torch.tensor(species, device=DEV).unsqueeze(0)
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True])
+    module((sp, torch.tensor(pos, device=DEV).unsqueeze(0)), cell, pbc)
+    flag = module.overflow_flag()
+    del module
+    gc.collect()
+    torch.cuda.synchronize()
+    junk = [torch.full((1 << 16,), 7, dtype=torch.int32, device=DEV) for _ in range(8)]      # (would land on freed device memory)
+    torch.cuda.synchronize()
+    assert int(flag) == 0 and len(junk) == 8
