@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
+static const char* g_filter = nullptr;      // argv[1]: only the lines whose name contains it
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define LOOPS 1024
 
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(256) void spin(float* out, float a, float b, int n)
                 if (KIND == 29) asm volatile("v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(q[k]));
                 if (KIND == 30) asm volatile("s_and_saveexec_b64 %0, vcc\n\ts_or_b64 exec, exec, %0" : "=s"(sm) : : "vcc");
                 if (KIND == 31) asm volatile("v_add_f32 %0, %1, %0\n\ts_nop 0" : "+v"(x[k]) : "v"(a));
+                if (KIND == 32) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(y[k]) : "v"(a2), "v"(a2));
             }
     }
     asm volatile("s_waitcnt lgkmcnt(0)");
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(256) void spin(float* out, float a, float b, int n)
 
 template <int KIND>
 void run(const char* name, float* out, int per = 1) {
+    if (g_filter && !strstr(name, g_filter)) return;
     for (int W : {1, 4, 8}) {
         const int blocks = 256 * W;
         hipLaunchKernelGGL(spin<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1.0f, 0.5f, 3);
@@ -81,7 +85,9 @@ void run(const char* name, float* out, int per = 1) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_filter = argv[1];
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     float* out;
     hipMalloc(&out, sizeof(float) * 256 * 256 * 8);
     run<0>("v_add_f32", out);
@@ -109,6 +115,7 @@ int main() {
     run<19>("v_cvt_f32_i32", out);
     run<13>("v_pk_mul_f32", out);
     run<14>("v_pk_add_f32", out);
+    run<32>("v_pk_fma_f32", out);
     run<15>("v_sqrt_f32", out);
     run<16>("v_rcp_f32", out);
     run<17>("v_log_f32", out);
