@@ -834,6 +834,10 @@ def run_neighbors(args, R):
     t_nb = phase_ms(lambda: neighbor_pairs_forward(tpos, cutoff, max_pairs, tbox))
     t_fwd = phase_ms(lambda: sym.compute(tpos, tbox, radial, angular, check=False))
     t_bwd = phase_ms(lambda: sym.backprop(g_rad, g_ang, grad))
+    # the op's own backward (getNeighborPairsCUDA.cu:80-101): dE/dpositions from gradients of deltas and distances, no float atomics
+    from nnpops_amd.capi import neighbor_pairs_backward
+    g_dl, g_ds = torch.randn(dl.shape, device=dev, generator=gen), torch.randn(ds.shape, device=dev, generator=gen)
+    t_nb_bwd = phase_ms(lambda: neighbor_pairs_backward(n, nb, dl, ds, g_dl, g_ds))
     # the list's immediate consumer in the reference: direct-space PME (src/pytorch/pme/pme.py:163-165)
     from nnpops_amd.capi import pme_direct
     charges = torch.randn(n, device=dev, generator=gen) * 0.3
@@ -864,8 +868,8 @@ def run_neighbors(args, R):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"getNeighborPairs(cutoff {cutoff}, max_num_pairs {max_pairs}) + ANI-2x AEV, {n} atoms periodic, "
                                "0.1 atoms/A^3, 7 species", "atoms": n, "pairs_found": found},
-        "phases_ms": {"neighbor_pairs": round(t_nb, 4), "aev_forward": round(t_fwd, 4), "aev_backward": round(t_bwd, 4),
-                      "pme_direct": round(t_pme, 4)},
+        "phases_ms": {"neighbor_pairs": round(t_nb, 4), "neighbor_pairs_backward": round(t_nb_bwd, 4), "aev_forward": round(t_fwd, 4),
+                      "aev_backward": round(t_bwd, 4), "pme_direct": round(t_pme, 4)},
         "kernels_us": {k: round(v, 1) for k, v in kt.items()},
         "roofline": {"bound": "hbm", "kernel": "getNeighborPairs (stage, scan, emit + cell grid)", "achieved": round(nb_bytes / (t_nb * 1e-3) / 1e9, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb_bytes / (t_nb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
