@@ -696,3 +696,36 @@ def test_overflow_flag_outlives_its_module():
     junk = [torch.full((1 << 16,), 7, dtype=torch.int32, device=DEV) for _ in range(8)]      # (would land on freed device memory)
     torch.cuda.synchronize()
     assert int(flag) == 0 and len(junk) == 8
+
+
+def test_fused_step_with_a_larger_activation_scale_survives_jit_save_and_load():
+    """Weights beyond the 1/16 activation bound (first layers x 100): OptimizedTorchANI stays the one-node step with the scale the
+    bound asks for (act_scale_log2 > 4), the scripted module saved and loaded gives the same bits, and energy / forces agree with the
+    composition on the library GEMMs (1e-5 / 1e-4)."""
+    import io
+    from NNPOps import OptimizedTorchANI
+    model = workloads.torchani_like_model(n_models=2, seed=5)
+    for ens in model.neural_networks:
+        for net in ens.values():
+            net[0].weight.data *= 100.0
+    pos, species, box = workloads.water_box(60, seed=2)
+    numbers = _numbers(species)
+    module = OptimizedTorchANI(model, numbers.cpu()).to(DEV)
+    assert type(module).__name__ == "FusedOptimizedTorchANI" and 4 < module.neural_networks[0].act_scale_log2 <= 12
+    cell, pbc = torch.tensor(box, device=DEV), torch.tensor([True, True, True], device=DEV)
+
+    def run(m):
+        p = torch.tensor(pos, device=DEV).unsqueeze(0).requires_grad_(True)
+        e = m((numbers, p), cell, pbc).energies
+        e.backward()
+        return e.detach().clone(), p.grad.clone()
+
+    e0, f0 = run(module)
+    buf = io.BytesIO()
+    torch.jit.save(torch.jit.script(module), buf)
+    buf.seek(0)
+    e1, f1 = run(torch.jit.load(buf, map_location=DEV))
+    assert torch.equal(e0, e1) and torch.equal(f0, f1)
+    e2, f2 = run(OptimizedTorchANI(model, numbers.cpu(), nn_layout="grouped").to(DEV))
+    assert abs(float(e0) - float(e2)) <= 1e-5 * abs(float(e2))
+    assert float((f0 - f2).abs().max()) <= 1e-4 * float(f2.abs().max())
