@@ -107,6 +107,10 @@ int nnpops_ani_check(nnpops_ani_t h, int* max_radial_neighbors, int* max_angular
  * a non-zero word found there means that every evaluation since the previous check may have been incomplete.  The address is
  * valid for the life of the handle. */
 int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word);
+/* The same word read for the caller: waits for the handle's stream, copies the four bytes with THIS library's HIP runtime (a host
+ * layer that opens a HIP runtime of its own to copy from the address above may get a second runtime that does not know the
+ * pointer) and leaves the word as it is -- only nnpops_ani_check() clears it.  Additive. */
+int nnpops_ani_read_overflow(nnpops_ani_t h, int32_t* value);
 /* Which kernels this handle runs, as one line of `key=value` words (for logs and tests; the words may grow): forward= merge |
  * chunked | mfma; backward= kernel number; generic= the function list does not factor; uniform= one eta and one zeta; grid= eight
  * radial factors on equally spaced shifts (taken by recurrence); literal= the constants are the published ANI-2x set and the

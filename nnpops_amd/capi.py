@@ -45,6 +45,7 @@ SIGNATURES = {
     "nnpops_ani_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nnpops_ani_timing_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "nnpops_ani_overflow_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "nnpops_ani_read_overflow": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "nnpops_ani_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nnpops_ani_check_begin_with": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "nnpops_ani_set_timing_merge": (C.c_int, [C.c_void_p, C.c_int]),
@@ -249,15 +250,9 @@ class AniSymmetryFunctions:
     def overflow_word(self):
         """The builders' sticky overflow word (bit 0 rows, 1 box too small for the grid, 2 cell bins, 3 an atom outgrew its backward
         class), read from the device (blocks on the handle's stream's device)."""
-        addr = C.c_void_p()
-        _check(self._lib.nnpops_ani_overflow_word(self._h, C.byref(addr)))
-        word = C.c_int(0)
+        word = C.c_int32(0)
         torch.cuda.synchronize()
-        hip = C.CDLL("libamdhip64.so")                         # (the runtime torch has loaded already)
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        rc = hip.hipMemcpy(C.byref(word), addr, 4, 2)          # hipMemcpyDeviceToHost
-        if rc != 0:
-            raise RuntimeError(f"hipMemcpy of the overflow word failed ({rc})")
+        _check(self._lib.nnpops_ani_read_overflow(self._h, C.byref(word)))     # (copied by the library's own runtime: ADVICE r05)
         return word.value
 
     def set_timing_merge(self, merge):

@@ -1261,6 +1261,15 @@ int nnpops_ani_overflow_word(nnpops_ani_t h, const int32_t** word) {
     return NNPOPS_OK;
 }
 
+int nnpops_ani_read_overflow(nnpops_ani_t h, int32_t* value) {
+    NNPOPS_REQUIRE(h != nullptr && value != nullptr, "NULL argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(NNPOPS_ERR_HIP, "cannot select device %d", h->device);
+    NNPOPS_HIP_TRY(hipMemcpyAsync(value, h->d_status + kStatOverflow, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    NNPOPS_HIP_TRY(hipStreamSynchronize(h->stream));
+    return NNPOPS_OK;
+}
+
 int nnpops_ani_describe(nnpops_ani_t h, char* text, int capacity) {
     NNPOPS_REQUIRE(h != nullptr && text != nullptr && capacity > 0, "NULL argument");
     const bool uni = h->fwd_uniform && h->hp.nFR == h->nfrp && h->hp.nFZ == h->nfzp;

@@ -183,6 +183,10 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     // An id row is capA ints = capA / 4 16-byte pieces; QL lanes scan one row, RPP rows per pass of the wave, 8 passes in flight.
     auto lookup_receiver_slots = [&](int i, int n) {
         constexpr int NP = 8;
+        //  a leg whose atom does not list THIS atom -- its row was cut short by an overflow of cap_angular, so the
+        // pair relation is not symmetric in this frame -- must not leave fc's bits behind as a "slot": -1 = no receiver, the store is
+        // skipped (the frame is reported through the overflow word and evaluated again; until then nothing is written out of bounds).
+        for (int e = lane; e < n; e += 64) recB[e].x = __int_as_float(-1);      // (LDS operations of a wave execute in order)
         const int ql_shift = 29 - __builtin_clz((unsigned)capA);      // log2(capA / 4); capA is a power of two >= 32
         const int QL = 1 << ql_shift, rpp_shift = 6 - ql_shift;
         for (int t0 = 0; (t0 << rpp_shift) < n; t0 += NP) {
@@ -374,7 +378,9 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                 if (half == 0 && e < n) {
                     if constexpr (SCAT) {
                         const float4 leg = recB[e];
-                        recv[(size_t)(__float_as_int(leg.w) & kIdMask) * capA + __float_as_int(leg.x)] = make_float4(fx, fy, fz, 0.f);
+                        const int rslot = __float_as_int(leg.x);
+                        if ((unsigned)rslot < (unsigned)capA)      // (-1: the receiver's row does not hold this atom -- overflowed frame)
+                            recv[(size_t)(__float_as_int(leg.w) & kIdMask) * capA + rslot] = make_float4(fx, fy, fz, 0.f);
                     } else leg_force[(size_t)i * capA + e] = make_float4(fx, fy, fz, 0.f);
                     cx -= fx; cy -= fy; cz -= fz;
                 }

@@ -1607,6 +1607,7 @@ struct nnpops_cfconv {
     // back instead of storing them again: the same numbers to the last bit or two, 67 MB per call at config 3)
     const void* filt_list = nullptr;
     unsigned long long filt_epoch = 0;
+    bool graph_seen = false;      // a filters launch of this convolution has been captured into a graph: replays write d_filt unseen
     bool reuse_filters = true;                     // $NNPOPS_CFCONV_REUSE_FILTERS=0: always store
 };
 
@@ -2001,6 +2002,11 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
     if (rc != NNPOPS_OK) return rc;
     const int pair_cap = nb->pair_cap();
     bool launched = false;
+    bool capturing = true;                                  // (unknown = treated as capturing)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) capturing = false;
+    }
     if constexpr (NCB % 2 == 0) {
         if (h->split_ok) {                                  // second layer as split-fp16 matrix products
             const size_t budget = 160 * 1024;
@@ -2013,11 +2019,8 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
                 if (lds > 64 * 1024)
                     NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ConvParams cp = h->p;
-                if (BWD && h->reuse_filters && h->filt_list == nb && h->filt_epoch == nb->epoch) {
-                    // (not while the stream is being captured: a replay may follow another build than the capture did)
-                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-                    if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) cp.skip_filter_store = 1;
-                }
+                if (BWD && !capturing && !h->graph_seen && h->reuse_filters && h->filt_list == nb && h->filt_epoch == nb->epoch)
+                    cp.skip_filter_store = 1;
                 hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, cp, h->d_w1b, h->d_w1h, h->d_w1l, h->d_w2h,
                                    h->d_w2l, h->d_b2, nb->d_half_off, nb->d_half_r, nb->d_half_ij, pair_cap, x, gout, h->d_filt,
                                    h->d_pair_s);
@@ -2025,7 +2028,15 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
             }
         }
     }
-    h->filt_list = nb; h->filt_epoch = nb->epoch;           // (either kernel, either direction, leaves this list's rows in d_filt)
+    // Either kernel, either direction, leaves this list's rows in d_filt -- once it has RUN.  A launch that is only being captured has
+    // written nothing yet, and a replay of the captured graph writes d_filt behind the host's back, for whatever build of whatever list
+    // it was captured on: nothing is recorded while capturing, and a convolution that has ever been captured never
+    // reads rows back again (graph_seen) -- the host cannot know what the last replay left there.
+    // (Call-history dependence, documented: a backward call that reads the forward call's rows back differs from one that stores its
+    //  own in the last bit or two -- the forward kernel adds the second layer's bias behind the products, the backward kernel carries
+    //  it in the accumulator, docs/LAB_NOTEBOOK_r05.md #13; both are inside the parity bars, NNPOPS_CFCONV_REUSE_FILTERS=0 switches it off.)
+    if (capturing) { h->graph_seen = true; h->filt_list = nullptr; }
+    else { h->filt_list = nb; h->filt_epoch = nb->epoch; }
     if (!launched) {
         const size_t budget = 160 * 1024 / sizeof(float);
         const size_t wfl = mfma_weight_floats(h->p.W, h->p.G), per_wave = mfma_wave_floats_bwd(h->p.W);

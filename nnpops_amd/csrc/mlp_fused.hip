@@ -83,15 +83,6 @@ struct MlpArgs {
     KindDesc kinds[NNPOPS_MLP_MAX_KINDS];
 };
 
-__device__ __forceinline__ void split8(const float (&v)[8], f16x8& h, f16x8& l) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const float s = v[i] * (1.0f / 16);
-        h[i] = (_Float16)s;
-        l[i] = (_Float16)((s - (float)h[i]) * kLoScale);
-    }
-}
-
 // v (already scaled into range) -> hi + 2^-11 lo'.  The high plane is rounded toward zero two values at a time
 // (v_cvt_pkrtz_f16_f32: any fp16 near v will do, the low plane carries the exact remainder), the low plane to nearest.
 __device__ __forceinline__ void split4(const f32x4& v, f16x4& h, f16x4& l) {

@@ -677,6 +677,51 @@ def test_backward_classes_regroup_when_an_atom_outgrows_its_class(monkeypatch):
     assert np.array_equal(grad, checked)                              # ... and its forces are those of the checked evaluation
 
 
+def test_scattered_leg_forces_stay_in_bounds_on_an_overflowed_frame(monkeypatch):
+    """the two-wave angular backward stores leg forces in the RECEIVING atom's row at a slot it looks up in that
+    atom's id row.  In a frame that overflows cap_angular the rows are cut short, the pair relation is no longer symmetric, and the
+    look-up can miss: the slot must then read "no receiver" (nothing stored), not the bits of fc as an index ~16 GB out of bounds.
+    backprop() does run on such frames before the host sees the overflow word (deferred checks, check intervals, graph replays).  Canary:
+    the frame is evaluated unchecked with NNPOPS_ANI_SCATTER=1, the device survives, the overflow is reported, and the evaluation
+    repeated after check() has grown the rows gives the per-molecule oracle's forces."""
+    from nnpops_amd.capi import AniSymmetryFunctions
+    monkeypatch.setenv("NNPOPS_ANI_SCATTER", "1")
+    rf, af = workloads.ani2x_functions()
+    dev = torch.device("cuda:0")
+    mols, species = [], []
+    for m in range(48):
+        p, s = workloads.conformer(60, seed=500 + m)
+        mols.append(p)
+        species.append(s)
+    offsets = np.concatenate([[0], np.cumsum([len(p) for p in mols])]).astype(np.int32)
+    species = np.concatenate(species)
+    loose = np.concatenate([1.5 * p for p in mols]).astype(np.float32)         # capacities are fitted to this frame ...
+    tight = np.concatenate([0.8 * p for p in mols]).astype(np.float32)         # ... and this one overflows them (1.9 x the radius ratio)
+    sym = AniSymmetryFunctions(7, 5.1, 3.5, species, rf, af, periodic=False)
+    sym.set_molecules(offsets)
+    r, a = sym.compute(torch.tensor(loose, device=dev), None)                  # checked: rows fitted to the loose frame
+    gen = torch.Generator(device=dev).manual_seed(5)
+    g_r = torch.randn(r.shape, device=dev, generator=gen)
+    g_a = torch.randn(a.shape, device=dev, generator=gen)
+    sym.backprop(g_r, g_a)
+    cap_before = sym.neighbor_stats()[1]
+    tp = torch.tensor(tight, device=dev)
+    sym.compute(tp, None, check=False)                                          # overflowed, nobody has looked yet
+    sym.backprop(g_r, g_a)                                                      # must not fault or write out of bounds
+    torch.cuda.synchronize()
+    assert sym.overflow_word() & 1, (sym.overflow_word(), cap_before)          # the scenario happened: an atom outgrew its records
+    r, a = sym.compute(tp, None)                                                # check() grows the rows, evaluates again
+    grad = sym.backprop(g_r, g_a).cpu().numpy()
+    wr, wa = g_r.cpu().numpy(), g_a.cpu().numpy()
+    ref = np.zeros_like(grad)
+    for m in range(len(offsets) - 1):
+        lo, hi = offsets[m], offsets[m + 1]
+        o = AniOracle(7, 5.1, 3.5, species[lo:hi], rf, af, periodic=False)
+        o.forward(tight[lo:hi], None)
+        ref[lo:hi] = o.backward(wr[lo:hi], wa[lo:hi])
+    assert np.abs(grad - ref).max() <= FORCE_RTOL * np.abs(ref).max()
+
+
 def test_pair_walk_of_the_builders_does_not_change_the_lists(monkeypatch):
     """Round 5: the builders' triple loop walks the pairs of an atom as a folded rectangle (decode_pair_folded) or row-major (handles
     whose lists exceed the Infinity Cache); either walk writes the SAME bucket-major list, so AEV and forces must agree bit for bit --

@@ -91,12 +91,16 @@ def test_ani_random_configuration(seed, monkeypatch):
         # case is judged against the algorithm evaluated in DOUBLE precision (oracle.AniOracle64): the HIP result must be
         # within 1e-4 of the exact forces, or at least as close to them as the fp32 reference manages to be.
         assert not torchani, (err, fmax)
+        _PAPER_MODE_ESCAPES.append((seed, err / fmax))             # counted and reported by the last test of this file
         from oracle import AniOracle64
         o64 = AniOracle64(S, rcr, rca, species, rf, af, periodic=periodic, torchani=torchani)
         o64.forward(pos, box)
         g64 = o64.backward(wr, wa)
         err_ref, err_gpu = float(np.abs(g_ref - g64).max()), float(np.abs(g - g64).max())
         assert err_gpu <= max(1e-4 * fmax, 1.5 * err_ref), (err_gpu, err_ref, fmax)
+
+
+_PAPER_MODE_ESCAPES = []        # (seed, error / largest force) of every ANI fuzz case that left north_star's 1e-4 bar for the float64 judge
 
 
 @pytest.mark.parametrize("seed", range(24 * SCALE))
@@ -260,3 +264,17 @@ def test_ani_batched_molecules_random(seed):
         np.testing.assert_allclose(r[lo:hi], r_ref, rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(a[lo:hi], a_ref, rtol=2e-5, atol=2e-6)
         assert np.abs(g[lo:hi] - g_ref).max() <= 1e-4 * max(float(np.abs(g_ref).max()), 1e-6)
+
+
+def test_zz_report_paper_mode_escapes():
+    """the float64 escape of test_ani_random_configuration is an EXCEPTION to north_star's 1e-4 force bar (dense
+    paper-mode systems only, unreachable from the torch surface) -- it must be visible, not silent.  Runs last in this file: says how
+    many seeds took the escape (a warning, shown in the pytest summary and so in the GPUTEST tail) and fails if it is more than a
+    handful (3 % of the ANI seeds), which would mean the HIP arithmetic has drifted, not that a few frames are ill conditioned."""
+    import warnings
+    n_seeds = 52 * SCALE
+    if _PAPER_MODE_ESCAPES:
+        worst = max(e for _, e in _PAPER_MODE_ESCAPES)
+        warnings.warn(f"ANI fuzz: {len(_PAPER_MODE_ESCAPES)} of {n_seeds} seeds (paper mode, dense) exceeded 1e-4 of the largest force against the "
+                      f"fp32 oracle and were judged against float64 instead: seeds {[s for s, _ in _PAPER_MODE_ESCAPES]}, worst {worst:.2e}")
+    assert len(_PAPER_MODE_ESCAPES) <= max(2, int(0.03 * n_seeds)), _PAPER_MODE_ESCAPES
