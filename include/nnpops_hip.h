@@ -247,6 +247,27 @@ int nnpops_neighbor_pairs_backward_ws(int dtype, int num_atoms, int64_t num_slot
                                       const void* deltas, const void* distances, const void* grad_deltas,
                                       const void* grad_distances, void* grad_positions, void* workspace, void* stream);
 
+/* Backward WITHOUT atomics for a list the forward op emitted (round 6; replaces the atomicAdd scatter of getNeighborPairsCUDA.cu:80-101
+ * by an owner-computes gather).  Such a list is grouped by neighbors[0] (rows ascending, see above); nnpops_neighbor_pairs_build_index
+ * adds the TRANSPOSED view -- the slots sorted by neighbors[1], ascending slot inside an atom's group -- plus the first / last slot of
+ * every atom's group on either side:
+ *   index: device int32 [nnpops_neighbor_pairs_index_ints(num_atoms, num_slots)], 8-byte aligned; a function of `neighbors` alone, so
+ *          the torch op builds it once in forward() when the positions require a gradient and saves it with the list;
+ *   workspace: device scratch, 256-byte aligned, nnpops_neighbor_pairs_index_workspace_bytes(...) bytes (free after the call).
+ * nnpops_neighbor_pairs_backward_indexed then computes the same grad_positions as nnpops_neighbor_pairs_backward_ws: one pass forms
+ * g for every slot, one pass adds them up per atom (float64 accumulation, fixed order: bitwise reproducible; a NaN / infinite g
+ * reaches exactly the two atoms of its pair, as the reference's atomics do); workspace: 32-byte aligned,
+ * nnpops_neighbor_pairs_backward_indexed_workspace_bytes(dtype, num_slots) bytes.  A list that is NOT grouped by neighbors[0] (edited,
+ * shuffled, of unknown origin) must go through nnpops_neighbor_pairs_backward_ws, which assumes nothing.  Additive. */
+int64_t nnpops_neighbor_pairs_index_ints(int num_atoms, int64_t num_slots);
+int64_t nnpops_neighbor_pairs_index_workspace_bytes(int num_atoms, int64_t num_slots);
+int nnpops_neighbor_pairs_build_index(int num_atoms, int64_t num_slots, const int32_t* neighbors, int32_t* index, void* workspace,
+                                      void* stream);
+int64_t nnpops_neighbor_pairs_backward_indexed_workspace_bytes(int dtype, int64_t num_slots);
+int nnpops_neighbor_pairs_backward_indexed(int dtype, int num_atoms, int64_t num_slots, const int32_t* neighbors, const void* deltas,
+                                           const void* distances, const void* grad_deltas, const void* grad_distances,
+                                           const int32_t* index, void* grad_positions, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * PME, direct-space part (replaces computeDirect: src/pytorch/pme/pmeCUDA.cu:30-100, pmeCPU.cpp:75-163) -- the immediate
  * consumer of the pair list above (src/pytorch/pme/pme.py:163-165).  The reciprocal-space part is not built.

@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libnnpops_hip.so")
 ARCH = "gfx950"
 
 # translation units of the C-ABI library (the torch binding is built separately, see torch_binding.py)
-UNITS = ["capi_common.hip", "ani.hip", "cfconv.hip", "neighbor_pairs.hip", "batched_nn.hip", "mlp_fused.hip", "pme.hip"]
+UNITS = ["capi_common.hip", "ani.hip", "cfconv.hip", "neighbor_pairs.hip", "pairs_index.hip", "batched_nn.hip", "mlp_fused.hip", "pme.hip"]
 
 
 def _sources():

@@ -85,6 +85,12 @@ SIGNATURES = {
     "nnpops_neighbor_pairs_backward": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_backward_workspace_bytes": (C.c_int64, [C.c_int]),
+    "nnpops_neighbor_pairs_index_ints": (C.c_int64, [C.c_int, C.c_int64]),
+    "nnpops_neighbor_pairs_index_workspace_bytes": (C.c_int64, [C.c_int, C.c_int64]),
+    "nnpops_neighbor_pairs_build_index": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_neighbor_pairs_backward_indexed_workspace_bytes": (C.c_int64, [C.c_int, C.c_int64]),
+    "nnpops_neighbor_pairs_backward_indexed": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_backward_ws": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -344,6 +350,33 @@ def neighbor_pairs_backward(num_atoms, neighbors, deltas, distances, grad_deltas
                                                        _ptr(deltas.contiguous()), _ptr(distances.contiguous()),
                                                        _ptr(grad_deltas.contiguous()), _ptr(grad_distances.contiguous()),
                                                        _ptr(grad_positions), _ptr(ws), _stream_ptr(dev)))
+    return grad_positions
+
+
+def neighbor_pairs_build_index(num_atoms, neighbors):
+    """Transposed index of a list the forward op emitted (grouped by neighbors[0]): int32 tensor for neighbor_pairs_backward_indexed."""
+    dev = neighbors.device
+    L = lib()
+    slots = neighbors.size(1)
+    index = torch.empty((int(L.nnpops_neighbor_pairs_index_ints(num_atoms, slots)),), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(L.nnpops_neighbor_pairs_index_workspace_bytes(num_atoms, slots)) // 8 + 1,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _check(L.nnpops_neighbor_pairs_build_index(num_atoms, slots, _ptr(neighbors), _ptr(index), _ptr(ws), _stream_ptr(dev)))
+    return index
+
+
+def neighbor_pairs_backward_indexed(num_atoms, neighbors, deltas, distances, grad_deltas, grad_distances, index):
+    """The backward pass without atomics (owner-computes gather over the transposed index)."""
+    dev, dt = deltas.device, deltas.dtype
+    grad_positions = torch.empty((num_atoms, 3), dtype=dt, device=dev)
+    L = lib()
+    with torch.cuda.device(dev):
+        ws = torch.empty((int(L.nnpops_neighbor_pairs_backward_indexed_workspace_bytes(_DTYPE_CODE[dt], distances.numel())) // 8 + 1,),
+                         dtype=torch.int64, device=dev)
+        _check(L.nnpops_neighbor_pairs_backward_indexed(_DTYPE_CODE[dt], num_atoms, distances.numel(), _ptr(neighbors),
+                                                        _ptr(deltas.contiguous()), _ptr(distances.contiguous()),
+                                                        _ptr(grad_deltas.contiguous()), _ptr(grad_distances.contiguous()),
+                                                        _ptr(index), _ptr(grad_positions), _ptr(ws), _stream_ptr(dev)))
     return grad_positions
 
 

@@ -27,6 +27,7 @@
 #include <torch/serialize/archive.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <sstream>
 #include <stdexcept>
@@ -924,20 +925,45 @@ public:
             TORCH_CHECK(found <= slots, "Too many neighbor pairs found. Maximum is " + std::to_string(slots),
                         " but found " + std::to_string(found));
         }
-        ctx->save_for_backward({neighbors, deltas, distances});
+        // Round 6: the backward pass of a COMPACTED list is an owner-computes gather over the list's transposed index (no atomics,
+        // include/nnpops_hip.h: nnpops_neighbor_pairs_build_index).  The index is a function of `neighbors` alone and the list is
+        // grouped by row as this op emits it, so it is built here, once, when a gradient can be asked for, and travels with the saved
+        // tensors (which autograd protects against in-place edits).  max_num_pairs == -1 (one slot per candidate pair, small systems)
+        // and $NNPOPS_PAIRS_BACKWARD=fixed keep the order-independent fixed-point sums, which assume nothing about the list.
+        Tensor index;
+        const char* bwd_env = std::getenv("NNPOPS_PAIRS_BACKWARD");
+        const bool fixed_point_only = bwd_env && std::string(bwd_env) == "fixed";
+        if (positions.requires_grad() && max_pairs > 0 && !fixed_point_only) {
+            index = torch::empty({nnpops_neighbor_pairs_index_ints((int)num_atoms, slots)}, options.dtype(torch::kInt32));
+            Tensor iws = torch::empty({nnpops_neighbor_pairs_index_workspace_bytes((int)num_atoms, slots) / 8 + 1}, options.dtype(torch::kInt64));
+            if (nnpops_neighbor_pairs_build_index((int)num_atoms, slots, neighbors.data_ptr<int32_t>(), index.data_ptr<int32_t>(), iws.data_ptr(),
+                                                  stream) != NNPOPS_OK)
+                raise_last("neighbors::getNeighborPairs (transposed index)");
+        }
+        ctx->save_for_backward({neighbors, deltas, distances, index});
         ctx->saved_data["num_atoms"] = num_atoms;
         return {neighbors, deltas, distances, num_pairs};
     }
 
     static tensor_list backward(AutogradContext* ctx, tensor_list grad_outputs) {
         const auto saved = ctx->get_saved_variables();
-        const Tensor neighbors = saved[0], deltas = saved[1], distances = saved[2];
+        const Tensor neighbors = saved[0], deltas = saved[1], distances = saved[2], index = saved[3];
         const int64_t num_atoms = ctx->saved_data["num_atoms"].toInt();
         const Tensor grad_deltas = grad_outputs[1].defined() ? grad_outputs[1].contiguous() : torch::zeros_like(deltas);
         const Tensor grad_distances = grad_outputs[2].defined() ? grad_outputs[2].contiguous() : torch::zeros_like(distances);
         Tensor grad_positions = torch::empty({num_atoms, 3}, deltas.options());
         const int dtype = deltas.scalar_type() == torch::kFloat64 ? 1 : 0;
         c10::hip::HIPGuard guard(deltas.device().index());
+        if (index.defined()) {
+            Tensor terms = torch::empty({nnpops_neighbor_pairs_backward_indexed_workspace_bytes(dtype, distances.size(0)) / 8 + 1},
+                                        deltas.options().dtype(torch::kInt64));
+            if (nnpops_neighbor_pairs_backward_indexed(dtype, (int)num_atoms, distances.size(0), neighbors.data_ptr<int32_t>(), deltas.data_ptr(),
+                                                       distances.data_ptr(), grad_deltas.data_ptr(), grad_distances.data_ptr(),
+                                                       index.data_ptr<int32_t>(), grad_positions.data_ptr(), terms.data_ptr(),
+                                                       current_stream(deltas.device())) != NNPOPS_OK)
+                raise_last("neighbors::getNeighborPairs backward");
+            return {grad_positions, Tensor(), Tensor(), Tensor(), Tensor()};
+        }
         // (scratch for the order-independent fixed-point sums of the backward pass: no float atomics, nnpops_hip.h)
         Tensor workspace = torch::empty({nnpops_neighbor_pairs_backward_workspace_bytes((int)num_atoms) / 8}, deltas.options().dtype(torch::kInt64));
         if (nnpops_neighbor_pairs_backward_ws(dtype, (int)num_atoms, distances.size(0), neighbors.data_ptr<int32_t>(), deltas.data_ptr(),

@@ -168,6 +168,86 @@ def test_backward_nan_stays_with_the_two_atoms_of_its_pair(dtype):
     np.testing.assert_allclose(got[others], clean[others], rtol=tol, atol=tol * np.abs(clean).max())
 
 
+def _indexed_case(n, cutoff, max_pairs, periodic, npdt, seed):
+    from nnpops_amd.capi import neighbor_pairs_forward
+    rng = np.random.default_rng(seed)
+    edge = (n / 0.1) ** (1.0 / 3.0)                                       # liquid density: ~0.1 atoms per cubic Angstrom
+    pos = (edge * rng.random((n, 3))).astype(npdt)
+    box = torch.tensor(np.diag([edge] * 3).astype(npdt), device=DEV) if periodic else None
+    nb, dl, ds, cnt = neighbor_pairs_forward(torch.tensor(pos, device=DEV), cutoff, max_pairs, box)
+    gd = torch.tensor(rng.standard_normal(tuple(dl.shape)).astype(npdt), device=DEV)
+    gs = torch.tensor(rng.standard_normal(tuple(ds.shape)).astype(npdt), device=DEV)
+    return nb, dl, ds, int(cnt), gd, gs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", ["allpairs_1000", "cells_12000_periodic", "cells_9000_vacuum", "truncated_list", "two_atoms"])
+def test_backward_indexed(dtype, case):
+    """Round 6: the backward pass of a list the forward op emitted as an owner-computes gather over the list's transposed index
+    (no atomics; nnpops_neighbor_pairs_build_index / _backward_indexed) -- the oracle's gradient (getNeighborPairsCUDA.cu:80-101), the
+    fixed-point path's gradient to rounding, the same bits on every call; for all three searches of the forward op (all pairs,
+    cell grid periodic / vacuum), a list cut short by max_num_pairs, and the smallest system."""
+    from nnpops_amd.capi import neighbor_pairs_backward, neighbor_pairs_backward_indexed, neighbor_pairs_build_index
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    n, cutoff, max_pairs, periodic = {"allpairs_1000": (1000, 4.0, 40000, False), "cells_12000_periodic": (12000, 5.0, 400000, True),
+                                      "cells_9000_vacuum": (9000, 5.0, 300000, False), "truncated_list": (2000, 4.0, 20000, True),
+                                      "two_atoms": (2, 50.0, 4, False)}[case]
+    nb, dl, ds, found, gd, gs = _indexed_case(n, cutoff, max_pairs, periodic, npdt, seed=len(case))
+    assert (found > max_pairs) == (case == "truncated_list") and found > 0
+    index = neighbor_pairs_build_index(n, nb)
+    got = neighbor_pairs_backward_indexed(n, nb, dl, ds, gd, gs, index)
+    for _ in range(3):
+        assert torch.equal(neighbor_pairs_backward_indexed(n, nb, dl, ds, gd, gs, neighbor_pairs_build_index(n, nb)), got)
+    ref = neighbor_pairs_backward_oracle(n, nb.cpu().numpy(), dl.cpu().numpy(), ds.cpu().numpy(), gd.cpu().numpy(), gs.cpu().numpy())
+    tol = 1e-5 if npdt == np.float32 else 1e-12
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
+    fixed = neighbor_pairs_backward(n, nb, dl, ds, gd, gs).cpu().numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), fixed, rtol=tol, atol=tol * np.abs(ref).max())
+    # the index itself: `order` lists every used slot exactly once, sorted by neighbors[1], ascending slot inside a group
+    slots = nb.shape[1]
+    order = index[:slots].cpu().numpy()
+    cols = nb[1].cpu().numpy()
+    used = np.nonzero(cols >= 0)[0]
+    assert np.array_equal(order[:len(used)], used[np.argsort(cols[used], kind="stable")])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_backward_indexed_nan_stays_with_the_two_atoms_of_its_pair(dtype):
+    """The gather adds every atom's own terms only: a pair at distance zero poisons its two atoms (getNeighborPairsCUDA.cu:96-100)
+    and nobody else -- bit for bit nobody else."""
+    from nnpops_amd.capi import neighbor_pairs_backward_indexed, neighbor_pairs_build_index
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    n = 1500
+    nb, dl, ds, found, gd, gs = _indexed_case(n, 4.0, 60000, True, npdt, seed=77)
+    index = neighbor_pairs_build_index(n, nb)
+    k = int(torch.nonzero(nb[0] >= 0)[123])
+    a, b = int(nb[0, k]), int(nb[1, k])
+    ds_bad, dl_bad = ds.clone(), dl.clone()
+    ds_bad[k] = 0
+    dl_bad[k] = 0
+    got = neighbor_pairs_backward_indexed(n, nb, dl_bad, ds_bad, gd, gs, index).cpu().numpy()
+    clean = neighbor_pairs_backward_indexed(n, nb, dl, ds, gd, gs, index).cpu().numpy()
+    assert np.isnan(got[[a, b]]).all()
+    others = np.setdiff1d(np.arange(n), [a, b])
+    assert np.array_equal(got[others], clean[others])
+
+
+def test_backward_indexed_keeps_float64_resolution_beside_one_huge_contribution():
+    from nnpops_amd.capi import neighbor_pairs_backward_indexed, neighbor_pairs_build_index
+    n = 400
+    nb, dl, ds, found, gd, gs = _indexed_case(n, 3.0, 40000, False, np.float64, seed=15)
+    gdn = gd.cpu().numpy().copy()
+    k = int(torch.nonzero(nb[0] >= 0)[7])
+    gdn[k] *= 1.0e9
+    got = neighbor_pairs_backward_indexed(n, nb, dl, ds, torch.tensor(gdn, device=DEV), gs, neighbor_pairs_build_index(n, nb)).cpu().numpy()
+    ref = neighbor_pairs_backward_oracle(n, nb.cpu().numpy(), dl.cpu().numpy(), ds.cpu().numpy(), gdn, gs.cpu().numpy())
+    a, b = int(nb[0, k]), int(nb[1, k])
+    others = np.setdiff1d(np.arange(n), [a, b])
+    small = np.abs(ref[others]).max()
+    assert np.abs(got[others] - ref[others]).max() <= 1e-12 * small
+    np.testing.assert_allclose(got[[a, b]], ref[[a, b]], rtol=1e-13)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("box", [[[10, 0, 0], [0, 10, 0], [0, 0, 10]], [[10, 0, 0], [2, 12, 0], [0, 1, 11]],
                                  [[10, 0, 0], [-2, 12, 0], [0, -1, 11]]])

@@ -202,6 +202,46 @@ def test_get_neighbor_pairs_op_values_and_grads(dtype):
     assert torch.allclose(p.grad, p_ref.grad, rtol=1e-3 if dtype == torch.float32 else 1e-9, atol=1e-3 if dtype == torch.float32 else 1e-9)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [300, 9000])
+def test_get_neighbor_pairs_compacted_list_backward_is_a_gather(dtype, n, monkeypatch):
+    """Round 6: with max_num_pairs > 0 and positions that require a gradient the op saves the list's transposed index and its
+    backward is the owner-computes gather (no atomics); $NNPOPS_PAIRS_BACKWARD=fixed keeps the fixed-point sums.  Both against plain
+    autograd through the same pairs, each bitwise reproducible; also inside a captured graph (forward + backward replayed)."""
+    from NNPOps.neighbors import getNeighborPairs
+    gen = torch.Generator().manual_seed(n)
+    edge = (n / 0.1) ** (1.0 / 3.0)
+    pos = (edge * torch.rand(n, 3, generator=gen)).to(dtype).to(DEV)
+    box = (edge * torch.eye(3)).to(dtype).to(DEV)
+    slots = 40 * n
+    grads = {}
+    for mode in ("gather", "fixed"):
+        if mode == "fixed":
+            monkeypatch.setenv("NNPOPS_PAIRS_BACKWARD", "fixed")
+        p = pos.clone().requires_grad_(True)
+        nb, deltas, dist, npairs = getNeighborPairs(p, cutoff=4.0, max_num_pairs=slots, box_vectors=box)
+        assert 0 < int(npairs) < slots
+        used = nb[0] >= 0
+        loss = (deltas[used] * torch.arange(3, device=DEV, dtype=dtype)).sum() + (dist[used] ** 2).sum()
+        loss.backward()
+        grads[mode] = p.grad.clone()
+        p2 = pos.clone().requires_grad_(True)
+        getNeighborPairs(p2, cutoff=4.0, max_num_pairs=slots, box_vectors=box)
+        nb2, deltas2, dist2, _ = getNeighborPairs(p2, cutoff=4.0, max_num_pairs=slots, box_vectors=box)
+        ((deltas2[used] * torch.arange(3, device=DEV, dtype=dtype)).sum() + (dist2[used] ** 2).sum()).backward()
+        assert torch.equal(p2.grad, grads[mode])                     # the same bits on every call
+    # plain autograd through the same pairs (minimum image taken from the op's own deltas: d = p_i - p_j + shift, shift constant)
+    p_ref = pos.clone().requires_grad_(True)
+    i, j = nb[0][used].long(), nb[1][used].long()
+    shift = (deltas[used] - (pos[i] - pos[j])).detach()
+    d_ref = p_ref[i] - p_ref[j] + shift
+    ((d_ref * torch.arange(3, device=DEV, dtype=dtype)).sum() + (torch.linalg.norm(d_ref, dim=1) ** 2).sum()).backward()
+    tol = 1e-4 if dtype == torch.float32 else 1e-10
+    scale = float(p_ref.grad.abs().max())
+    for mode in grads:
+        assert float((grads[mode] - p_ref.grad).abs().max()) <= tol * scale, mode
+
+
 def test_get_neighbor_pairs_check_errors_and_graph_capture():
     from NNPOps.neighbors import getNeighborPairs
     pos = torch.zeros(4, 3, device=DEV)
