@@ -37,7 +37,6 @@ struct nnpops_ani {
     int* d_cnt_pos = nullptr;       // [N] na | nro << 16, by the same position
     float4* d_recA = nullptr;       // [N][cap_angular] sorted angular records {dx,dy,dz,r}
     float4* d_recB = nullptr;       // [N][cap_angular]                        {fc,dfc,1/r,word}
-    float4* d_recG = nullptr;       // [N][cap_angular][2] the neighbours' halves of the eight radial factors (AniParams::prod), or NULL
     int* d_ids = nullptr;           // [N][cap_angular] atom ids in record order (reverse lookup of the backward gather)
     float4* d_leg_force = nullptr;  // [N][cap_angular] angular backward: force on each leg, record order
     float4* d_centre_force = nullptr; // [N]            angular backward: reaction on the centre atom
@@ -250,9 +249,7 @@ int factor_angular(AniParams& hp, const float* af, int nA) {
 
 int alloc_rows(nnpops_ani* h) {
     dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_ids); dev_free(h->d_leg_force);
-    dev_free(h->d_recG); h->d_recG = nullptr;
     int rc;
-    if (h->hp.prod && (rc = dev_alloc(&h->d_recG, (size_t)h->hp.N * h->cap_angular * 2))) return rc;
     if ((rc = dev_alloc(&h->d_nbr, (size_t)h->hp.N * h->cap))) return rc;
     if ((rc = dev_alloc(&h->d_recA, (size_t)h->hp.N * h->cap_angular))) return rc;
     if ((rc = dev_alloc(&h->d_recB, (size_t)h->hp.N * h->cap_angular))) return rc;
@@ -262,10 +259,7 @@ int alloc_rows(nnpops_ani* h) {
     {   // the walk of the builders' triple loop follows the footprint of the lists (ani_kernels.h: decode_pair_folded)
         int row_major = (size_t)h->hp.N * triples_capacity(h->cap_angular) * sizeof(int) > ((size_t)256 << 20) ? 1 : 0;
         if (const char* e = std::getenv("NNPOPS_ANI_TRI_ROW_MAJOR")) row_major = std::atoi(e) != 0;
-        const bool moved = h->hp.recG != h->d_recG;
-        h->hp.recG = h->d_recG;
-        h->ac.recG = h->d_recG;
-        if ((row_major != h->hp.tri_row_major || moved) && h->d_params) {
+        if (row_major != h->hp.tri_row_major && h->d_params) {
             h->hp.tri_row_major = row_major;
             NNPOPS_HIP_TRY(hipMemcpy(h->d_params, &h->hp, sizeof(AniParams), hipMemcpyHostToDevice));
         }
@@ -304,11 +298,8 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
     const size_t lds_group = (size_t)lds_wave * wpg;
     const dim3 grid(div_up(N, wpg)), block(64 * wpg);
     if (forward && h->forward_kernel == 2) {
-        // (product form of the radial factors: two waves per atom, one eta / one zeta, eight shifts, the builders wrote recG)
-        const bool prod = NFRP == 8 && h->hp.prod && h->d_recG && h->fwd_waves_per_atom == 2 && h->fwd_uniform && h->fwd_grid && h->hp.nFR == NFRP &&
-                          h->hp.nFZ == NFZP && h->fwd_occ != 6 && h->fwd_occ != 8;
-        const int CH = forward_chunk(h, (size_t)h->cap_angular * (prod ? 3 : 2) * sizeof(float4), (size_t)(NFRP + NFZP) * sizeof(float));
-        const size_t lds2 = ang_fwd_mfma_lds_bytes<NFRP, NFZP>(h->cap_angular, CH, prod);
+        const int CH = forward_chunk(h, (size_t)h->cap_angular * 2 * sizeof(float4), (size_t)(NFRP + NFZP) * sizeof(float));
+        const size_t lds2 = ang_fwd_mfma_lds_bytes<NFRP, NFZP>(h->cap_angular, CH);
         const int lw = (int)((lds2 + 15) & ~(size_t)15);
         int vec_ok = h->fwd_identity && h->ld_angular % 4 == 0 && ((uintptr_t)out & 15) == 0;
         if (vec_ok) vec_ok |= (h->store_mode << 1) | (h->fwd_row_via_lds ? 8 : 0);     // (bits 1-2: flavour of the row stores, bit 3: row assembled in LDS)
@@ -324,14 +315,6 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
             if constexpr (NFRP == 8 && NFZP == 4) {            // the published ANI-2x constants: kernels that carry them as literals
                 if (uni && h->fwd_literal && h->fwd_occ != 6 && h->fwd_occ != 8)
                     k = dyn ? ani_angular_forward_mfma<TA, 8, 4, 2, 7, 2, true> : ani_angular_forward_mfma<TA, 8, 4, 2, 7, 2>;
-            }
-            if constexpr (NFRP == 8) {
-                if (prod) {
-                    k = dyn ? ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, 1, true, true> : ani_angular_forward_mfma<TA, NFRP, NFZP, 2, 7, 1, false, true>;
-                    if constexpr (NFZP == 4) {
-                        if (h->fwd_literal) k = dyn ? ani_angular_forward_mfma<TA, 8, 4, 2, 7, 2, true, true> : ani_angular_forward_mfma<TA, 8, 4, 2, 7, 2, false, true>;
-                    }
-                }
             }
             if (lw > 64 * 1024) NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lw));
             hipLaunchKernelGGL(k, dim3(groups), dim3(128), (size_t)lw, sp.stream, h->d_params, h->cap, h->cap_angular, CH, h->d_recA,
@@ -378,10 +361,7 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
         if (mode == 1 && !h->backward_forced && (cl.two_waves || h->scatter_now || ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, false) > 16 * 1024)) mode = 3;
         if (!vec_ok && (mode == 1 || mode == 3)) mode++;
         const bool glds = mode == 2 || mode == 4;
-        // (product form of the radial factors: the instantiations that read the gradient blocks through the L1 with the literal ANI-2x set)
-        const bool bprod = NFRP == 8 && NFZP == 4 && h->hp.prod && h->d_recG && (mode == 1 || mode == 3) && h->fwd_literal && h->bwd_literal && h->fwd_uniform &&
-                           h->hp.nFR == 8 && h->hp.nFZ == 4 && !h->occ6 && !(by_class && c >= nclasses);
-        const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, glds, bprod) + 15) & ~(size_t)15;
+        const size_t lb = (ang_bwd_pair_lds_bytes<NFRP, NFZP>(tile, h->hp.NB, glds) + 15) & ~(size_t)15;
         void (*k)(const AniParams*, const AngularConsts, int, int, int, const float4*, const float4*, const int*, const int*, const int*, const float*, int,
                   float4*, float4*, const int*, float4*, int, int, int, const int*, int, int, int) =
             mode == 1 ? (h->occ6 ? ani_angular_backward_pair<TA, NFRP, NFZP, 6, 1, false>
@@ -413,13 +393,6 @@ int launch_angular(nnpops_ani* h, bool forward, const float* grad_or_null, float
                 k = !by_class ? ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 0, true>
                   : c < nclasses ? ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 1, true>
                                  : ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 2, true>;
-            }
-        }
-        if constexpr (NFRP == 8 && NFZP == 4) {
-            if (bprod) {
-                if (mode == 1) k = by_class ? ani_angular_backward_pair<TA, 8, 4, 5, 1, false, false, 2, 1, false, true> : ani_angular_backward_pair<TA, 8, 4, 5, 1, false, false, 2, 0, false, true>;
-                else if (scat) k = by_class ? ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 1, true, true> : ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 0, true, true>;
-                else k = by_class ? ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 1, false, true> : ani_angular_backward_pair<TA, 8, 4, 5, 2, false, false, 2, 0, false, true>;
             }
         }
         const int apg = mode >= 3 ? 1 : std::max(1, std::min(kWavesPerGroup, h->bwd_atoms_per_group));
@@ -655,24 +628,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
         if (const char* e = std::getenv("NNPOPS_ANI_FWD_LITERAL")) h->fwd_literal = h->fwd_literal && std::atoi(e) != 0;
         if (const char* e = std::getenv("NNPOPS_ANI_BWD_LITERAL")) h->bwd_literal = std::atoi(e) != 0;
     }
-    {   // Product form of the radial factors (AniParams::prod): one eta on eight equally spaced shifts, every exponent inside fp32's range
-        // (the halves 2^(c/2 (r - Rs_a)^2), r in [0, Rca], and the pair factor 2^(-c/4 (r_p - r_q)^2))
-        hp.prod = 0; hp.recG = nullptr; hp.prod_ce = 0.f;
-        if (h->fwd_uniform && h->fwd_grid && hp.nFR == 8 && h->nfrp == 8) {
-            const double rs0 = hp.fr_rs[0], d = ((double)hp.fr_rs[7] - rs0) / 7.0, c = 0.5 * (double)hp.fr_c[0];
-            const double far = std::max({std::fabs(rs0), std::fabs((double)hp.fr_rs[7]), std::fabs((double)hp.rca - rs0), std::fabs((double)hp.rca - hp.fr_rs[7])});
-            const bool in_range = std::fabs(c) * far * far < 120.0 && 0.5 * std::fabs(c) * (double)hp.rca * hp.rca < 120.0 &&
-                                  2.0 * std::fabs(c * d) * far + 9.0 * std::fabs(c) * d * d < 120.0;
-            GeoRadial& g = hp.geo_half;
-            g.rs1 = (float)(rs0 + d); g.c = (float)c; g.k1 = (float)(-2.0 * c * d); g.k0 = (float)(c * d * d);
-            g.q = (float)std::exp2(2.0 * c * d * d); g.q4 = (float)std::exp2(8.0 * c * d * d); g.qi4 = (float)std::exp2(-8.0 * c * d * d);
-            g.d4 = (float)(4.0 * d);
-            hp.prod_ce = -0.25f * hp.fr_c[0];
-            hp.prod = in_range ? 1 : 0;
-            if (h->fwd_literal && hp.prod_ce != Ani2xAngular::prod_ce) hp.prod = 0;      // (cannot happen: c is compared bit for bit above)
-        }
-        if (const char* e = std::getenv("NNPOPS_ANI_PROD")) hp.prod = hp.prod && std::atoi(e) != 0;
-    }
     // Matrix-core forward kernel: quads are handed the species pairs that can occur among this system's atoms.
     {
         std::vector<char> present(num_species, 0);
@@ -803,7 +758,6 @@ int nnpops_ani_create(nnpops_ani_t* out, int num_atoms, int num_species, float r
     {   // the angular backward kernel's constants, by value: every factor slot behind the real ones holds its neutral value
         AngularConsts& c = h->ac;
         c.N = hp.N; c.nA = hp.nA;
-        c.recG = h->d_recG; c.prod_ce = hp.prod_ce;
         for (int a = 0; a < kMaxFactor; a++) {
             const bool live = !h->generic && a < hp.nFR;
             c.fr_c[a] = live ? hp.fr_c[a] : 0.f; c.fr_rs[a] = live ? hp.fr_rs[a] : 0.f; c.fr_negeta[a] = live ? -hp.fr_eta[a] : 0.f;
@@ -828,7 +782,6 @@ int nnpops_ani_destroy(nnpops_ani_t h) {
     if (!h) return NNPOPS_OK;
     DeviceGuard guard(h->device);
     dev_free(h->d_params); dev_free(h->d_species); dev_free(h->d_segment);
-    dev_free(h->d_recG);
     dev_free(h->d_nbr); dev_free(h->d_recA); dev_free(h->d_recB); dev_free(h->d_tri); dev_free(h->d_cnt_a); dev_free(h->d_cnt_ro); dev_free(h->d_cnt_pos); dev_free(h->d_status);
     dev_free(h->d_ids); dev_free(h->d_leg_force); dev_free(h->d_centre_force); dev_free(h->d_bucket_offsets);
     dev_free(h->d_hist); dev_free(h->d_bins);
@@ -1323,14 +1276,14 @@ int nnpops_ani_describe(nnpops_ani_t h, char* text, int capacity) {
     const bool shape2x = h->nfrp == 8 && h->nfzp == 4;
     std::snprintf(text, (size_t)capacity,
                   "forward=%s backward=%d generic=%d uniform=%d grid=%d literal=%d dynamic_quads=%d fused_build=%d cap=%d cap_angular=%d "
-                  "chunk=%d classes=%d cells=%d scatter=%d row_major_walk=%d product_form=%d",
+                  "chunk=%d classes=%d cells=%d scatter=%d row_major_walk=%d",
                   h->forward_kernel == 2 ? "mfma" : h->forward_kernel == 1 ? "chunked" : "merge", h->backward_kernel, (int)h->generic,
                   (int)uni, (int)(uni && h->fwd_grid), (int)(uni && h->fwd_grid && shape2x && h->fwd_literal), (int)h->fwd_dynamic,
                   (int)(h->computed ? h->last_fused_build : (h->fuse_forward < 0 ? h->hp.N <= kFuseAtoms : h->fuse_forward != 0)), h->cap, h->cap_angular,
                   // (the chunk the forward kernel is launched with, not the configured floor: ADVICE r04)
                   h->generic ? h->fwd_chunk : forward_chunk(h, (size_t)h->cap_angular * 2 * sizeof(float4), (size_t)(h->nfrp + h->nfzp) * sizeof(float)),
                   (int)h->bwd_classes.size(), (int)h->last_used_cells,
-                  (int)h->scatter_now, h->hp.tri_row_major, h->hp.prod);      // (scatter: the last backprop() stored the leg forces in the receivers' rows)
+                  (int)h->scatter_now, h->hp.tri_row_major);      // (scatter: the last backprop() stored the leg forces in the receivers' rows)
     return NNPOPS_OK;
 }
 

@@ -97,82 +97,13 @@ __device__ __forceinline__ void triple_forces_pk(const float4& A, const float4& 
     beta = dadd;
 }
 
-// Round 6: the same with the radial factors in PRODUCT form (AniParams::prod; one eta, eight shifts): R_a = G_a(p) G_a(q) E with the
-// neighbours' halves G read from LDS and the pair factor E = 2^(ce (r_p - r_q)^2) -- linear in everything downstream -- multiplied
-// into the three sums at the end: one transcendental and four packed products where the direct form takes eight and twelve.
-template <bool TORCHANI, int NFZP>
-__device__ __forceinline__ void triple_forces_prod(const float4& A, const float4& A2, const float4& B, const float4& B2,
-                                                   const float4& Gp0, const float4& Gp1, const float4& Gq0, const float4& Gq1,
-                                                   const float* Gb, float pce, const float (&frs)[8], float fren0,
-                                                   const float (&zz)[NFZP], const float (&zc)[NFZP], const float (&zs)[NFZP],
-                                                   const float (&zb)[NFZP], float& alpha_p, float& alpha_q, float& beta) {
-    constexpr int NFRP = 8;
-    const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
-    const v2f rb2 = {g.rbar, g.rbar}, c2 = {g.c, g.c}, s2 = {g.s, g.s}, one = {1.0f, 1.0f};
-    const float dr = A.w - B.w;
-    const float E = fast_exp2(pce * dr * dr);
-    const v2f R2[4] = {v2f{Gp0.x, Gp0.y} * v2f{Gq0.x, Gq0.y}, v2f{Gp0.z, Gp0.w} * v2f{Gq0.z, Gq0.w},
-                       v2f{Gp1.x, Gp1.y} * v2f{Gq1.x, Gq1.y}, v2f{Gp1.z, Gp1.w} * v2f{Gq1.z, Gq1.w}};
-    float R[NFRP], dR[NFRP];
-#pragma unroll
-    for (int a = 0; a < NFRP; a += 2) {
-        const v2f sh = rb2 - v2f{frs[a], frs[a + 1]};
-        const v2f d = (v2f{fren0, fren0} * sh) * R2[a / 2];       // d/dr_ij of exp(-eta (rbar-Rs)^2): rbar carries 1/2 (ref :306)
-        R[a] = R2[a / 2].x; R[a + 1] = R2[a / 2].y; dR[a] = d.x; dR[a + 1] = d.y;
-    }
-    v2f U[NFZP / 2], V[NFZP / 2];
-#pragma unroll
-    for (int z = 0; z < NFZP / 2; z++) { U[z] = v2f{0.f, 0.f}; V[z] = v2f{0.f, 0.f}; }
-#pragma unroll
-    for (int a = 0; a < NFRP; a++) {
-        const v2f ra = {R[a], R[a]}, da = {dR[a], dR[a]};
-#pragma unroll
-        for (int z = 0; z < NFZP; z += 4) {
-            const float4 gv = *reinterpret_cast<const float4*>(Gb + a * NFZP + z);
-            const v2f g01 = {gv.x, gv.y}, g23 = {gv.z, gv.w};
-            U[z / 2] += g01 * ra;     V[z / 2] += g01 * da;
-            U[z / 2 + 1] += g23 * ra; V[z / 2 + 1] += g23 * da;
-        }
-    }
-    v2f S0 = {0.f, 0.f}, Sr = {0.f, 0.f}, Sth = {0.f, 0.f};
-#pragma unroll
-    for (int z = 0; z < NFZP; z += 2) {
-        const v2f zc2 = {zc[z], zc[z + 1]}, zs2 = {zs[z], zs[z + 1]};
-        const v2f cz = c2 * zc2 + s2 * zs2;               // cos(theta - ths)
-        const v2f sz = s2 * zc2 - c2 * zs2;               // sin(theta - ths)
-        v2f x = one + cz;
-        x.x = fmaxf(x.x, 1e-30f); x.y = fmaxf(x.y, 1e-30f);
-        const v2f lg = {fast_log2(x.x), fast_log2(x.y)};
-        const v2f e = v2f{zz[z] - 1.0f, zz[z + 1] - 1.0f} * lg + v2f{zb[z], zb[z + 1]};
-        const v2f Zm1 = {fast_exp2(e.x), fast_exp2(e.y)};
-        const v2f Z = Zm1 * x;
-        const v2f dZ = (v2f{-zz[z], -zz[z + 1]} * Zm1) * sz;
-        S0 += U[z / 2] * Z;
-        Sr += V[z / 2] * Z;
-        Sth += U[z / 2] * dZ;
-    }
-    const float s0 = (S0.x + S0.y) * E, sr = (Sr.x + Sr.y) * E, sth = (Sth.x + Sth.y) * E;
-    const float t1 = A2.y * B2.x * s0 + g.fcfc * sr;
-    const float t2 = A2.x * B2.y * s0 + g.fcfc * sr;
-    const float t3 = g.fcfc * sth;
-    const float dot = A.x * B.x + A.y * B.y + A.z * B.z;
-    const float iprod = A2.z * B2.z;
-    const float damp = TORCHANI ? 0.95f : 1.0f;
-    const float dadd = -damp * fast_rcp(g.s) * iprod * t3;
-    const float ka = dot * A2.z * A2.z, kb = dot * B2.z * B2.z;
-    const float s1 = t1 * A2.z, s2f = t2 * B2.z;
-    alpha_p = s1 - dadd * ka;
-    alpha_q = s2f - dadd * kb;
-    beta = dadd;
-}
-
 // WPA: waves per atom (1: a 64-lane workgroup owns an atom; 2: a 128-lane workgroup, the waves take alternate batches).
 // GLDS: the atom's upstream gradient row is staged in LDS (true), or every triple reads its 128-byte block straight from
 // global memory through the vector L1 (false; needs the 16-byte layout `vec_ok`): 3.5 KB less LDS per atom, i.e. more
 // atoms in flight per CU -- these kernels are bound by latency x occupancy, not by issue slots or bytes.
 template <int NFRP, int NFZP>
-__host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool glds, bool prod = false) {
-    return (size_t)capA * (prod ? 4 : 2) * sizeof(float4) + (glds ? (size_t)NB * NFRP * NFZP * sizeof(float) : 0) +
+__host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool glds) {
+    return (size_t)capA * 2 * sizeof(float4) + (glds ? (size_t)NB * NFRP * NFZP * sizeof(float) : 0) +
            ((size_t)capA * (capA + 1) + (size_t)capA * (capA - 1) / 2) * sizeof(float);
     // (LDS is handed out in 128 pieces of 1 280 bytes per CU: at 64 record slots this is 26 752 bytes = 21 pieces, six workgroups per
     //  CU; 256 bytes more -- a table of the receivers' slots, round 5 -- were 22 pieces, five workgroups, and 12 % of the kernel's speed:
@@ -191,7 +122,7 @@ __host__ __device__ inline size_t ang_bwd_pair_lds_bytes(int capA, int NB, bool 
 // SCAT: the two-wave instantiation that stores the leg forces in the receiving atoms' rows (see "where the leg forces go" below);
 // everybody else is compiled without that code -- written into one kernel behind a run-time pointer test it cost the two-wave
 // kernel a third of its speed (18-22 spilled scalar registers: 32.6 -> 44 us on a 7 600-atom block of conformers).
-template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, int UNI = 0, int CLASSES = 0, bool SCAT = false, bool PROD = false>
+template <bool TORCHANI, int NFRP, int NFZP, int OCC, int WPA, bool GLDS, bool GENERIC = false, int UNI = 0, int CLASSES = 0, bool SCAT = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_backward_pair(
     const AniParams* __restrict__ P, const AngularConsts C, int cap, int capA, int tile, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a, const int* __restrict__ cnt_ro,
@@ -234,8 +165,6 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     char* cursor = lds_raw + (size_t)slot_in_group * lds_per_atom;
     float4* recA = (float4*)cursor;       cursor += (size_t)tile * sizeof(float4);
     float4* recB = (float4*)cursor;       cursor += (size_t)tile * sizeof(float4);
-    static_assert(!PROD || (UNI != 0 && NFRP == 8 && !GENERIC), "the product form is for one eta on eight shifts");
-    float4* recG = (float4*)cursor;       if (PROD) cursor += (size_t)tile * 2 * sizeof(float4);    // the neighbours' halves of the radial factors
     float* grow = (float*)cursor;         if (GLDS) cursor += (size_t)NB * BLK * sizeof(float);   // upstream gradient row, canonical [bucket][a][z]
     float* Ma = (float*)cursor;           // alpha[tile][tile + 1]: Ma[e][x] = coefficient of A_e in the force of triple {e, x} on e
     float* Mb = Ma + tile * tstride;      // beta, once per unordered pair (p < q), triangular
@@ -378,10 +307,6 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
             if (lane < tile) { recA[lane] = recA_first; recB[lane] = recB_first; }
             for (int e = lane + 64; e < n; e += 64) { recA[e] = recA_g[(size_t)i * capA + e]; recB[e] = recB_g[(size_t)i * capA + e]; }
         }
-        if constexpr (PROD) {
-            const float4* gsrc = C.recG + (size_t)i * capA * 2;
-            for (int e = tid; e < 2 * n; e += NT) recG[e] = gsrc[e];
-        }
         sync();
 
         // ---------------- lane = triple; with two waves, alternate batches ----------------
@@ -395,10 +320,6 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
                     triple_forces_generic<TORCHANI>(P, nA, recA[p], recB[p], recA[q], recB[q], g + bucket * nA, ap, aq, bt);
                 } else {
                     const float* Gb = GLDS ? grow + bucket * BLK : g + bucket * BLK;
-                    if constexpr (PROD)
-                        triple_forces_prod<TORCHANI, NFZP>(recA[p], recB[p], recA[q], recB[q], recG[2 * p], recG[2 * p + 1], recG[2 * q], recG[2 * q + 1],
-                                                           Gb, UNI == 2 ? Ani2xAngular::prod_ce : C.prod_ce, frs, fren[0], zz, zc, zs, zb, ap, aq, bt);
-                    else
                     triple_forces_pk<TORCHANI, NFRP, NFZP>(recA[p], recB[p], recA[q], recB[q], Gb, frc, frs, fren,
                                                            zz, zc, zs, zb, ap, aq, bt);
                 }

@@ -34,9 +34,9 @@ typedef float mfma_f4 __attribute__((ext_vector_type(4)));
 constexpr int kFwdSlots = 32;          // 2 sets x 16 quads
 
 template <int NFRP, int NFZP>
-__host__ __device__ inline size_t ang_fwd_mfma_lds_bytes(int capA, int CH, bool prod = false) {
-    // records (PROD: three 16-byte pieces per slot) | staged factors (+ the zero record) | 32 x 2 ints: the per-atom quad table of the balanced phase 2 (DYN)
-    return (size_t)capA * (prod ? 3 : 2) * sizeof(float4) + (size_t)(CH + 1) * (NFRP + NFZP) * sizeof(float) + 64 * sizeof(int);
+__host__ __device__ inline size_t ang_fwd_mfma_lds_bytes(int capA, int CH) {
+    // records | staged factors (+ the zero record) | 32 x 2 ints: the per-atom quad table of the balanced phase 2 (DYN)
+    return (size_t)capA * 2 * sizeof(float4) + (size_t)(CH + 1) * (NFRP + NFZP) * sizeof(float) + 64 * sizeof(int);
 }
 
 template <int W>
@@ -87,14 +87,9 @@ __device__ __forceinline__ const float* lds_ptr(int byte_address) {
 // shared by consecutive quads of ONE wave (never across the two), whose partial blocks are added with a segmented shuffle before
 // the row is assembled; species pairs without triples get no quad at all (the row is zero-filled first).  Steps: 14 -> ~9 for the
 // 7-species liquid, 9 -> 5 for water.
-// PROD (round 6; UNI with eight radial factors): the radial factors of a triple in PRODUCT form (AniParams::prod) -- the records in LDS
-// are then  U[slot] = {unit vector of the leg, r}  and  Gf[slot] = fc x {G_0, G_4, G_1, G_5 | G_2, G_6, G_3, G_7} (the order of the
-// staged record), three 16-byte pieces per slot; a triple's eight radial factors, cutoff functions included, are four packed products,
-// and the pair factor 2^(ce (r_p - r_q)^2) -- its one transcendental -- rides on the angular factors where fc fc used to.
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, int UNI = 0, bool DYN = false, bool PROD = false>
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, int UNI = 0, bool DYN = false>
 struct MfmaForward {
     static_assert(!DYN || WPA == 2, "the per-atom quad table is built by the first of two waves");
-    static_assert(!PROD || (UNI != 0 && NFRP == 8), "the product form is for one eta on eight equally spaced shifts");
     static constexpr int NR4 = NFRP / 4, NZ4 = NFZP / 4, REC = NFRP + NFZP;
     static constexpr int NS = 2 / WPA;                         // quad sets run by this wave
 
@@ -113,7 +108,6 @@ struct MfmaForward {
     float frc[NFRP], frs[NFRP], zz[NFZP], zc[NFZP], zs[NFZP], zb[NFZP];   // constants of the two factor families (wave-uniform)
     float frc0, zz0, zb0;                                                 // UNI: the shared eta / zeta / bias
     GeoRadial geo;                                                        // UNI with eight radial factors: the recurrence's constants
-    float pce;                                                            // PROD: exponent of the pair factor
 
     __device__ __forceinline__ void sync() const {
         if constexpr (WPA == 2) __syncthreads();
@@ -130,9 +124,7 @@ struct MfmaForward {
         K = P->fwd_split; logK = 31 - __builtin_clz(K);
         recA = (float4*)lds;
         recB = recA + capA;
-        fac = (float*)(recB + (PROD ? 2 : 1) * capA);
-        pce = 0.f;
-        if constexpr (PROD) pce = UNI == 2 ? Ani2xAngular::prod_ce : P->prod_ce;
+        fac = (float*)(recB + capA);
         qtab = (int*)(fac + (size_t)(CH + 1) * REC);
         fac_addr = (int)(uintptr_t)fac + (lane & 3) * (NR4 * 4);                   // this lane's R pieces in record 0
         zdelta = NFRP * 4 + (lane & 3) * (NZ4 * 4) - (lane & 3) * (NR4 * 4);       // from the R pieces to the Z pieces
@@ -256,29 +248,10 @@ struct MfmaForward {
                 const int next_word = (t + 64 * WPA < T) ? tri_at(t + 64 * WPA) : 0;
                 if (t < c1) {
                     const int p = word & 0xff, q = (word >> 8) & 0xff;
-                    float vr[NFRP], vz[NFZP];
-                    TripleGeom g;
-                    if constexpr (PROD) {
-                        const float4 A = recA[p], B = recA[q];             // {unit vector, r}
-                        const float4 Gp0 = recB[2 * p], Gp1 = recB[2 * p + 1], Gq0 = recB[2 * q], Gq1 = recB[2 * q + 1];
-                        const float dot = A.x * B.x + A.y * B.y + A.z * B.z;
-                        if (TORCHANI) {
-                            g.c = 0.95f * dot;                             // ref :391-393
-                            g.s = fast_sqrt(1.0f - g.c * g.c);
-                        } else {
-                            g.c = fminf(fmaxf(dot, -1.0f), 1.0f);
-                            const float cx = A.y * B.z - A.z * B.y, cy = A.z * B.x - A.x * B.z, cz = A.x * B.y - A.y * B.x;
-                            g.s = fminf(fast_sqrt(cx * cx + cy * cy + cz * cz), 1.0f);
-                        }
-                        const float dr = A.w - B.w;
-                        g.fcfc = fast_exp2(pce * dr * dr);                 // (fc fc is inside the products below: this is what multiplies the Z factors)
-                        const v2f a0 = v2f{Gp0.x, Gp0.y} * v2f{Gq0.x, Gq0.y}, a1 = v2f{Gp0.z, Gp0.w} * v2f{Gq0.z, Gq0.w};
-                        const v2f a2 = v2f{Gp1.x, Gp1.y} * v2f{Gq1.x, Gq1.y}, a3 = v2f{Gp1.z, Gp1.w} * v2f{Gq1.z, Gq1.w};
-                        vr[0] = a0.x; vr[1] = a0.y; vr[2] = a1.x; vr[3] = a1.y; vr[4] = a2.x; vr[5] = a2.y; vr[6] = a3.x; vr[7] = a3.y;
-                    } else {
                     const float4 A = recA[p], B = recA[q];
                     const float4 A2 = recB[p], B2 = recB[q];
-                    g = triple_geometry<TORCHANI>(A, A2, B, B2);
+                    const TripleGeom g = triple_geometry<TORCHANI>(A, A2, B, B2);
+                    float vr[NFRP], vz[NFZP];
                     if constexpr (UNI && NFRP == 8) {          // one eta, equally spaced shifts: four transcendentals for the eight factors
                         v2f R04, R15, R26, R37, Y;             // the record holds {R0, R4, R1, R5 | R2, R6, R3, R7}: the pairs as they come
                         radial_factors_geo8(g.rbar, geo, R04, R15, R26, R37, Y);
@@ -290,7 +263,6 @@ struct MfmaForward {
                             const float sh = g.rbar - frs[a];
                             vr[(a & 3) * NR4 + (a >> 2)] = fast_exp2((UNI ? frc0 : frc[a]) * sh * sh);
                         }
-                    }
                     }
 #pragma unroll
                     for (int z = 0; z < NFZP; z++) {
@@ -470,7 +442,7 @@ struct MfmaForward {
     }
 };
 
-template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC, int UNI = 0, bool DYN = false, bool PROD = false>
+template <bool TORCHANI, int NFRP, int NFZP, int WPA, int OCC, int UNI = 0, bool DYN = false>
 __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani_angular_forward_mfma(
     const AniParams* __restrict__ P, int cap, int capA, int CH, const float4* __restrict__ recA_g,
     const float4* __restrict__ recB_g, const int* __restrict__ tri_g, const int* __restrict__ cnt_a,
@@ -479,11 +451,8 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int wig = __builtin_amdgcn_readfirstlane(wave_in_group());        // wave-uniform: keeps per-atom addressing scalar
     const int slot_in_group = WPA == 2 ? 0 : wig;               // which atom of the workgroup
-    static_assert(!PROD || WPA == 2, "the product-form records are staged by two waves");
-    MfmaForward<TORCHANI, NFRP, NFZP, WPA, UNI, DYN, PROD> F;
+    MfmaForward<TORCHANI, NFRP, NFZP, WPA, UNI, DYN> F;
     F.init(P, capA, CH, vec_ok, angular, ld_angular, lds_raw + (size_t)slot_in_group * lds_per_atom, WPA == 2 ? wig : 0);
-    const float4* recG_g = nullptr;
-    if constexpr (PROD) recG_g = P->recG;
     F.write_zero_record();
     const int lane = F.lane, NB = F.NB;
 
@@ -501,21 +470,7 @@ __global__ __launch_bounds__(WPA == 2 ? 128 : 64 * kWavesPerGroup, OCC) void ani
         //  72 registers of seven waves per SIMD, 20 bytes of scratch: 17.5 -> 18.7 us.  The backward kernel keeps that form.)
         F.atom(i, n, [&](int t) { return tri[t]; }, [&](int b) { return boff_g[b]; },
                [&]() {
-                   if constexpr (PROD) {                       // first wave: unit vectors; second wave: the neighbours' factors with fc folded in
-                       if (F.role == 0) {
-                           for (int e = lane; e < n; e += 64) {
-                               const float4 a = recA_g[(size_t)i * capA + e], b = recB_g[(size_t)i * capA + e];
-                               F.recA[e] = make_float4(a.x * b.z, a.y * b.z, a.z * b.z, a.w);
-                           }
-                       } else {
-                           for (int e = lane; e < n; e += 64) {
-                               const float fc = recB_g[(size_t)i * capA + e].x;
-                               const float4 g0 = recG_g[((size_t)i * capA + e) * 2], g1 = recG_g[((size_t)i * capA + e) * 2 + 1];
-                               F.recB[2 * e] = make_float4(fc * g0.x, fc * g1.x, fc * g0.y, fc * g1.y);          // {G_0, G_4, G_1, G_5}
-                               F.recB[2 * e + 1] = make_float4(fc * g0.z, fc * g1.z, fc * g0.w, fc * g1.w);      // {G_2, G_6, G_3, G_7}
-                           }
-                       }
-                   } else if constexpr (WPA == 2) {            // one array each
+                   if constexpr (WPA == 2) {                   // one array each
                        const float4* src = (F.role == 0 ? recA_g : recB_g) + (size_t)i * capA;
                        float4* dst = F.role == 0 ? F.recA : F.recB;
                        for (int e = lane; e < n; e += 64) dst[e] = src[e];

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(128, OCC) void ani_build_forward(const AniParams* _
             } else {
                 finalize_angular(P, stage, n, out.recA + (size_t)i * capA, out.recB + (size_t)i * capA, out.ids + (size_t)i * capA, capA,
                                  out.tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G,
-                                 P->prod ? P->recG + (size_t)i * capA * 2 : nullptr, recA_l, recB_l, tri_l);
+                                 recA_l, recB_l, tri_l);
             }
         }
         __syncthreads();

@@ -71,7 +71,6 @@ struct Ani2xAngular {
     static constexpr float zs0 = 0x1.87de2c0000000p-2f, zs1 = 0x1.d906bc0000000p-1f, zs2 = 0x1.d906be0000000p-1f, zs3 = 0x1.87de2e0000000p-2f;      // sin(ShfZ)
     static constexpr float rs_0 = 0x1.99999a0000000p-1f, rs_1 = 0x1.2333340000000p+0f, rs_2 = 0x1.79999a0000000p+0f, rs_3 = 0x1.d000000000000p+0f, rs_4 = 0x1.1333340000000p+1f, rs_5 = 0x1.3e66660000000p+1f, rs_6 = 0x1.69999a0000000p+1f, rs_7 = 0x1.94cccc0000000p+1f;      // ShfA
     static constexpr float negeta = -0x1.9000000000000p+3f;
-    static constexpr float prod_ce = 0x1.2089fc0000000p+2f;      // -c / 4 (exact)
     static constexpr float rs1 = 0x1.2333340000000p+0f, c = -0x1.2089fc0000000p+4f, k1 = 0x1.8587140000000p+3f, k0 = -0x1.06ee600000000p+1f, q = 0x1.daf9060000000p-5f, q4 = 0x1.7b326e0000000p-17f, qi4 = 0x1.59a8220000000p+16f, d4 = 0x1.5999980000000p+0f;      // GeoRadial
 };
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -131,16 +130,6 @@ struct AniParams {
     int fwd_absent[kMaxBuckets];
     int fwd_zero_shift;              // log2 of the lanes that zero one absent block (16 bytes each), <= 6
     GeoRadial geo;                   // UNI forward kernel with eight radial factors (valid when the host set nnpops_ani::fwd_grid)
-    // Round 6, product form of the radial factors (one eta, eight equally spaced shifts): with a = r_p - Rs, b = r_q - Rs,
-    //     ((a + b) / 2)^2 = a^2 / 2 + b^2 / 2 - (r_p - r_q)^2 / 4    =>    exp(-eta (rbar - Rs_a)^2) = G_a(p) G_a(q) exp(eta (r_p - r_q)^2 / 4)
-    // with G_a(j) = exp(-eta (r_j - Rs_a)^2 / 2) computed ONCE PER NEIGHBOUR by the builders (recG: eight floats per record slot, by the
-    // same recurrence as the forward kernel's, on eta / 2) -- a triple then costs one transcendental for its radial part instead of four
-    // (forward, recurrence) or eight (backward).  Relative error of a factor <= 9e-6 where the factor is above 1e-6 (rms 7e-7: smaller
-    // than the direct form's 1e-6, whose exponent is rounded at twice the magnitude), tests/test_ani_gpu.py.
-    int prod;                        // builders write recG; the PROD instantiations of the angular kernels read it
-    float4* recG;                    // [N][capA][2] device array: {G_0 .. G_3}, {G_4 .. G_7} of every angular neighbour, record order
-    GeoRadial geo_half;              // the recurrence's constants for eta / 2
-    float prod_ce;                   // eta log2(e) / 4: the exponent of the pair factor 2^(prod_ce (r_p - r_q)^2)
 };
 
 // What the angular BACKWARD kernel needs of the parameter block, passed BY VALUE in the kernel arguments.  Read through the AniParams
@@ -151,8 +140,6 @@ struct AniParams {
 // arguments it parks even more scalars in vector lanes and measured 17.7 -> 18.5 us.
 struct AngularConsts {
     int N, nA;
-    const float4* recG;                                                     // AniParams::recG / prod_ce (PROD instantiations)
-    float prod_ce;
     float fr_c[kMaxFactor], fr_rs[kMaxFactor], fr_negeta[kMaxFactor];       // -eta log2(e), Rs, -eta; 0 behind nFR
     float fz_zeta[8], fz_cos[8], fz_sin[8], fz_bias[8];                     // zeta (1 behind nFZ), cos / sin(thetas), 1 - zeta
 };
@@ -321,15 +308,12 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
                                                  float4* __restrict__ recA, float4* __restrict__ recB,
                                                  int* __restrict__ ids, int capA, int* __restrict__ tri,
                                                  int* __restrict__ boff_out, const AtomGroups& G,
-                                                 float4* __restrict__ recG = nullptr,      // [capA][2] of this atom, or NULL (AniParams::prod off)
                                                  float4* recA_l = nullptr, float4* recB_l = nullptr, int* tri_l = nullptr) {
     // (recA_l / recB_l / tri_l: LDS copies for a forward pass that follows in the same workgroup, ani_build_forward.h)
     const int lane = lane_id();
     const int S = P->S, NB = P->NB;
     const float inv_rca = P->inv_rca;
     for (int bk = lane; bk < NB; bk += 64) { G.ba[bk] = P->bkt_a[bk]; G.bb[bk] = P->bkt_b[bk]; }
-    GeoRadial gh{};
-    if (recG) gh = P->geo_half;
     auto emit = [&](const float4& r4, int rank) {
         const float r = fast_sqrt(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z);       // ~1 ulp, like everything downstream
         float sn, cs;
@@ -341,12 +325,6 @@ __device__ __forceinline__ void finalize_angular(const AniParams* __restrict__ P
         store_wt(recB + rank, b2);
         if (recA_l) { recA_l[rank] = a; recB_l[rank] = b2; }
         store_wt(ids + rank, __float_as_int(r4.w) & kIdMask);        // compact copy for the backward gather's reverse lookup
-        if (recG) {                                            // the neighbour's half of every radial factor (AniParams::prod)
-            v2f R04, R15, R26, R37, Y;
-            radial_factors_geo8(r, gh, R04, R15, R26, R37, Y);
-            store_wt(recG + 2 * rank, make_float4(R04.x, R15.x, R26.x, R37.x));
-            store_wt(recG + 2 * rank + 1, make_float4(R04.y, R15.y, R26.y, R37.y));
-        }
     };
     if (n <= 64) {
         // one neighbour per lane: the stable species sort is S ballots, no LDS traffic, no fences
@@ -548,8 +526,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_allpairs(co
     flush_row(row, stage, cap, na, nro);
     radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
-                     tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G,
-                     P->prod ? P->recG + (size_t)i * capA * 2 : nullptr);
+                     tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G);
 }
 
 // Cell-grid search (celllist.h): one wave per atom walks the 3x3x3 stencil of its cell; candidates
@@ -633,8 +610,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void ani_neighbors_cells(const
     flush_row(row, stage, cap, na, nro);
     radial_forward_from_lds(P, stage, cap, n, nro_c, rscratch, radial + (size_t)i * ld_radial);
     finalize_angular(P, stage, n, recA + (size_t)i * capA, recB + (size_t)i * capA, ids + (size_t)i * capA, capA,
-                     tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G,
-                     P->prod ? P->recG + (size_t)i * capA * 2 : nullptr);
+                     tri + (size_t)i * triples_capacity(capA), P->bucket_offsets + (size_t)i * (P->NB + 1), G);
 }
 
 // =============================================================================================
