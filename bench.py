@@ -804,14 +804,7 @@ def run_neighbors(args, R):
         sym.backprop(g_rad, g_ang, grad)
 
     steps, warm = min(args.steps, 50), min(args.warmup, 10)
-    for _ in range(warm):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = _time_steps(step, steps, warm) * steps         # (SIDE_PROTOCOL)
     sym.enable_timing(True)
     step()                                             # one extra step with the handle's own kernel brackets
     torch.cuda.synchronize()
@@ -835,9 +828,15 @@ def run_neighbors(args, R):
     t_fwd = phase_ms(lambda: sym.compute(tpos, tbox, radial, angular, check=False))
     t_bwd = phase_ms(lambda: sym.backprop(g_rad, g_ang, grad))
     # the op's own backward (getNeighborPairsCUDA.cu:80-101): dE/dpositions from gradients of deltas and distances, no float atomics
-    from nnpops_amd.capi import neighbor_pairs_backward
+    # (round 6: an owner-computes gather over the list's transposed index, which the torch op builds in forward() when the positions
+    #  require a gradient; the fixed-point integer atomics of rounds 4-5 -- what a list of unknown origin still takes -- beside it)
+    from nnpops_amd.capi import neighbor_pairs_backward, neighbor_pairs_backward_indexed, neighbor_pairs_build_index
     g_dl, g_ds = torch.randn(dl.shape, device=dev, generator=gen), torch.randn(ds.shape, device=dev, generator=gen)
-    t_nb_bwd = phase_ms(lambda: neighbor_pairs_backward(n, nb, dl, ds, g_dl, g_ds))
+    pair_index = neighbor_pairs_build_index(n, nb)
+    t_nb_bwd = phase_ms(lambda: neighbor_pairs_backward_indexed(n, nb, dl, ds, g_dl, g_ds, pair_index))
+    t_nb_index = phase_ms(lambda: neighbor_pairs_build_index(n, nb))
+    t_nb_bwd_fixed = phase_ms(lambda: neighbor_pairs_backward(n, nb, dl, ds, g_dl, g_ds))
+    nb_bwd_bytes = found * 40 + n * 12                    # (2 ints + 3 + 1 floats of the list, 3 + 1 floats of gradient) per pair in, 12 bytes per atom out
     # the list's immediate consumer in the reference: direct-space PME (src/pytorch/pme/pme.py:163-165)
     from nnpops_amd.capi import pme_direct
     charges = torch.randn(n, device=dev, generator=gen) * 0.3
@@ -863,12 +862,14 @@ def run_neighbors(args, R):
                                                                   ("add_tile_offsets", 1), ("fill_cells", 1), ("order_cells", 1)])
     out = {
         "metric": "getNeighborPairs + ANI-2x AEV forward+backward evaluations/sec, 100k-atom periodic box, cutoff 5.2 A",
-        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm, "timing_protocol": SIDE_PROTOCOL,
         "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"getNeighborPairs(cutoff {cutoff}, max_num_pairs {max_pairs}) + ANI-2x AEV, {n} atoms periodic, "
                                "0.1 atoms/A^3, 7 species", "atoms": n, "pairs_found": found},
-        "phases_ms": {"neighbor_pairs": round(t_nb, 4), "neighbor_pairs_backward": round(t_nb_bwd, 4), "aev_forward": round(t_fwd, 4),
+        "phases_ms": {"neighbor_pairs": round(t_nb, 4), "neighbor_pairs_backward": round(t_nb_bwd, 4),
+                      "neighbor_pairs_transposed_index": round(t_nb_index, 4), "neighbor_pairs_backward_fixed_point": round(t_nb_bwd_fixed, 4),
+                      "aev_forward": round(t_fwd, 4),
                       "aev_backward": round(t_bwd, 4), "pme_direct": round(t_pme, 4)},
         "kernels_us": {k: round(v, 1) for k, v in kt.items()},
         "roofline": {"bound": "hbm", "kernel": "getNeighborPairs (stage, scan, emit + cell grid)", "achieved": round(nb_bytes / (t_nb * 1e-3) / 1e9, 2),
@@ -878,6 +879,10 @@ def run_neighbors(args, R):
                      "angular_forward": {"algorithmic_bytes": ang_bytes, "us": round(kt.get("angular_forward", 0.0), 1),
                                          "achieved": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3, 2),
                                          "frac": round(ang_bytes / max(kt.get("angular_forward", 0.0), 1e-3) / 1e3 / HBM_PEAK_GBS, 5)},
+                     "neighbor_pairs_backward": {"algorithmic_bytes": nb_bwd_bytes, "achieved": round(nb_bwd_bytes / (t_nb_bwd * 1e-3) / 1e9, 2),
+                                                 "frac": round(nb_bwd_bytes / (t_nb_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                                 "note": "pairs_backward_terms + pairs_backward_gather (no atomics); the index it walks is built once per "
+                                                         "forward call that can be differentiated: phases_ms.neighbor_pairs_transposed_index"},
                      "pme_direct": {"algorithmic_bytes": pme_bytes, "achieved": round(pme_bytes / (t_pme * 1e-3) / 1e9, 2),
                                     "frac": round(pme_bytes / (t_pme * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                     "note": "energy + dE/dpositions + dE/dcharges on the pair list above (owner computes: pme_direct_pairs parks every contribution in the second atom's row, pme_direct_gather sums them in a fixed order; no float atomics)"},
@@ -964,11 +969,9 @@ def run_torchani(args, R):
         elapsed, energy, forces = replay_as_graph()
         tpos.grad = forces
     else:
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            energy = step()
+        elapsed = _time_steps(step, steps, warm) * steps     # (SIDE_PROTOCOL)
+        energy = step()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(energy).all()) and bool(torch.isfinite(tpos.grad).all())
     # the same eager loop without the per-call capacity check of the AEV holder (one host round trip per step): what a production
     # loop at known density runs (set_check_interval, cf. check_errors of getNeighborPairs); one checked step follows
@@ -1078,7 +1081,7 @@ def run_torchani(args, R):
                                 if args.nn_layout == "fused" else (None, None))
     out = {
         "metric": "OptimizedTorchANI energy+forces evaluations/sec, 2001-atom periodic water box, 8 models, fp32",
-        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm, "timing_protocol": SIDE_PROTOCOL,
         "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" + (" (network products: operands split into two fp16 planes, products exact, fp32 accumulation)" if split else ""),
         "data": "synthetic",
@@ -1202,10 +1205,27 @@ class ConformerShard:
         self.sym.backprop(self.g_rad, self.g_ang, out)
 
 
-def _time_steps(fn, steps, warm, repeats=3):
-    """Seconds per call: best of `repeats` timed loops (a loop that starts on a device whose clocks have dropped during a
-    second of host-side set-up reads up to 2.5x high)."""
+SIDE_PROTOCOL = ("settle (>= 0.2 s of untimed steps), then the best of 3 loops of `steps` steps, each behind `warmup` untimed steps and closed by "
+                 "torch.cuda.synchronize()")
+
+
+def _settle(fn, seconds=0.2, chunk=25):
+    """Untimed steps until `seconds` of wall clock have passed: a device that has just been handed to this process, or has idled through a
+    second of host-side set-up, runs its first loops up to 2.5x slow (the headline has its own --settle phase for the same reason)."""
     import torch
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(chunk):
+            fn()
+        torch.cuda.synchronize()
+
+
+def _time_steps(fn, steps, warm, repeats=3, settle=True):
+    """Seconds per call, ONE protocol for every side line and for both operands of every ratio between side lines:
+    SIDE_PROTOCOL above -- so that the driver's `--steps 20 --warmup 5` reproduces what a 100-step run reports."""
+    import torch
+    if settle:
+        _settle(fn)
     best = None
     for _ in range(repeats):
         for _ in range(warm):
@@ -1265,16 +1285,19 @@ def run_conformers(args, R):
             pending[b] = dist.all_gather_into_tensor(gathered[b], padded[b], async_op=True)
 
     steps, warm = min(args.steps, 100), min(args.warmup, 10)
-    for _ in range(warm):
-        step()
-    drain()
-    R.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    drain()
-    R.barrier()
-    elapsed = R.max_over_ranks(time.perf_counter() - t0)
+    if not dist:
+        elapsed = _time_steps(step, steps, warm) * steps     # (SIDE_PROTOCOL: the same as the eight blocks below)
+    else:
+        for _ in range(max(warm, 200)):                      # (a count, the same on every rank: every step holds a collective)
+            step()
+        drain()
+        R.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        drain()
+        R.barrier()
+        elapsed = R.max_over_ranks(time.perf_counter() - t0)
     last = (counter[0] - 1) & 1 if dist else 0
     own = padded[last][:n]
     assert bool(torch.isfinite(own).all())
@@ -1292,7 +1315,7 @@ def run_conformers(args, R):
     out = {
         "metric": "AEV+forces evaluations/sec of a 1024-conformer batch (ANI-2x, ~60 atoms each)",
         "value": round(steps / elapsed, 3), "unit": "batch evals/s", "n_gpus": world, "steps": steps,
-        "warmup": warm, "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True,
+        "warmup": warm, "timing_protocol": SIDE_PROTOCOL if world == 1 else "200 untimed steps, then one loop of `steps` steps between barriers, max over ranks", "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "ANI-2x AEV forward+backward, 1024 independent conformers of 50-70 atoms, contiguous batch "
                                "blocks per GPU, one batched handle per GPU, one asynchronous all_gather of the forces per step "
@@ -1320,6 +1343,8 @@ def run_conformers(args, R):
         out["shard8"] = {"ms_per_block_step": [round(1e3 * t, 4) for t in t_blocks], "slowest_block_ms": round(1e3 * t_max, 4),
                          "projected_scaling": round(t_full / t_max, 2),
                          "projected_scaling_with_synchronous_gather": round(t_full / (t_max + 25e-6), 2),
+                         "protocol": "both operands of the projections -- the whole batch (ms_per_step of this line) and every block -- are timed by the "
+                                     "same function: " + SIDE_PROTOCOL,
                          "note": "each of the 8 blocks of shard_molecules(sizes, 8, weights = neighbour triples + 130 per atom) (~128 conformers, ~7.7 k atoms) timed alone on "
                                  "this one device; projected = t_1024 / slowest block (gather overlapped) and / (slowest block + "
                                  "25 us assumed for a synchronous all_gather); no 8-GPU node was available to measure it"}
@@ -1392,17 +1417,9 @@ def run_cfconv(args, R):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(g_xg, eager_xg) and torch.equal(g_pg, eager_pg)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            graph.replay()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        elapsed = _time_steps(graph.replay, steps, warm) * steps
     else:
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        elapsed = _time_steps(step, steps, warm) * steps     # (SIDE_PROTOCOL)
     flops_fwd = 2.0 * (G * W + W * W) * pairs            # per half pair
     split = os.environ.get("NNPOPS_CFCONV_SPLIT", "1") != "0" and os.environ.get("NNPOPS_CFCONV_HALF", "1") != "0"
     tflops = flops_fwd / (tf * 1e-3) / 1e12
@@ -1415,7 +1432,7 @@ def run_cfconv(args, R):
     cf_bwd_traffic, cf_bwd_by_kernel = side_traffic(args, R, "cfconv", [(bw_names[0], 1), (bw_names[1], 1)]) if cf_traffic is not None else (None, None)
     out_json = {
         "metric": "CFConv build+forward+backward evaluations/sec, W=128 G=50 cutoff 5 A, 10k-atom periodic box",
-        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "value": round(steps / elapsed, 3), "unit": "evals/s", "n_gpus": 1, "steps": steps, "warmup": warm, "timing_protocol": SIDE_PROTOCOL,
         "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" + (" (dense layers: operands split into two fp16 planes, products exact, fp32 accumulation)" if split else ""),
         "data": "synthetic",
