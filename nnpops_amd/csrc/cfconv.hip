@@ -1461,6 +1461,394 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// cfconv_filters_h2x2 (round 6): the FORWARD filters kernel with 32 pairs per wave and layer 2 fed from registers.
+//
+// What bound cfconv_filters_h2 forward (profiles/r05_cfconv_lds_mfma_counters_pmc.txt): not the matrix pipe (~30 % busy) but the LDS
+// pipe (83 % of the busy cycles) -- every 16-pair tile streams BOTH W2 planes (64 KB) and the W1 planes through it, and writes and
+// re-reads its own Y1 planes: 104 ds_read_b128 (1 KB each, 128 bytes per clock for the whole CU) for 144 matrix instructions.
+// Two changes, both about operand traffic:
+//   * a wave takes TWO 16-pair tiles per pass: every W1 / W2 fragment it reads from LDS feeds the matrix instructions of both
+//     (weight reads per pair halve);
+//   * layer 1 is computed transposed, so a lane ends with filters {16 cb + 4 grp + q} of ITS pair -- which IS a valid A fragment of
+//     layer 2's 16 x 16 x 32 instruction if the K index of a step is read as {32 s + 4 grp + i, 32 s + 16 + 4 grp + i}: the order of
+//     K inside a step is free as long as both operands agree, so the W2 planes are staged into LDS with that permutation of their
+//     8-byte pieces and Y1 never goes through LDS at all (no plane writes, no plane reads, no fences, 8 KB of LDS per wave less).
+// 96 ds_read_b128 per 32 pairs (48 per 16: less than half) for 288 matrix instructions.  Same arithmetic as cfconv_filters_h2
+// (split-fp16 products, fp32 accumulation, bias behind the products); the rows agree with the 16-pair kernel's to the last bit or two
+// (the matrix instruction adds the 32 products of a step in another order), tests/test_cfconv_gpu.py.
+// ---------------------------------------------------------------------------------------------
+template <int ACT, int NCB, int U, int WAVES>      // U: 16-pair tiles per pass of a wave (1 or 2); WAVES: waves per workgroup
+__global__ __launch_bounds__(64 * WAVES) void cfconv_filters_h2x2(
+    ConvParams P, const _Float16* __restrict__ w1h, const _Float16* __restrict__ w1l, const _Float16* __restrict__ w2h,
+    const _Float16* __restrict__ w2l, const float* __restrict__ b2, const int* __restrict__ half_off, const float* __restrict__ half_r,
+    int pair_cap, float* __restrict__ filt) {
+    constexpr int W = NCB * 16;
+    static_assert(W % 32 == 0, "the K steps of layer 2 are 32 wide");
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int G = P.G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    char* s_w2h = ldsb;                                      // [W][W] halves, K pieces permuted inside every step, slots swizzled (h2_slot)
+    char* s_w2l = s_w2h + (size_t)W * W * 2;
+    const int row1 = h2_l1_row_bytes(G), slots1 = h2_l1_slots(G);
+    char* s_w1h = s_w2l + (size_t)W * W * 2;                 // W1 planes [W][row1 bytes]
+    char* s_w1l = s_w1h + (size_t)W * row1;
+    float* ps = reinterpret_cast<float*>(s_w1l + (size_t)W * row1) + wave * 128;     // r | fc of the wave's 16 U pairs
+    for (int q = tid; q < W * (W / 8); q += blockDim.x) {    // 16-byte slots of the W2 planes: slot 4 s + grp <- K pieces {32 s + 4 grp, 32 s + 16 + 4 grp}
+        const int f2 = q / (W / 8), slot = q % (W / 8);
+        const int k0 = 32 * (slot >> 2) + 4 * (slot & 3);
+        const f16x4 h0 = *reinterpret_cast<const f16x4*>(w2h + (size_t)f2 * W + k0), h1 = *reinterpret_cast<const f16x4*>(w2h + (size_t)f2 * W + k0 + 16);
+        const f16x4 l0 = *reinterpret_cast<const f16x4*>(w2l + (size_t)f2 * W + k0), l1 = *reinterpret_cast<const f16x4*>(w2l + (size_t)f2 * W + k0 + 16);
+        *reinterpret_cast<f16x8*>(s_w2h + h2_slot<W>(f2, slot)) = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<f16x8*>(s_w2l + h2_slot<W>(f2, slot)) = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+    for (int q = tid; q < W * (row1 / 16); q += blockDim.x) {
+        reinterpret_cast<f16x8*>(s_w1h)[q] = reinterpret_cast<const f16x8*>(w1h)[q];
+        reinterpret_cast<f16x8*>(s_w1l)[q] = reinterpret_cast<const f16x8*>(w1l)[q];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)                                    // the all-zero row behind the last slot (entries without a mirror image)
+        for (int q = tid; q < W; q += blockDim.x) filt[(size_t)pair_cap * W + q] = 0.f;
+
+    const int col = lane & 15, grp = lane >> 4;
+    const float mu_step = P.cutoff / (float)(G - 1);
+    const float gscale = -0.5f * kLog2e * P.sigma_inv * P.sigma_inv;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int pairs = min(half_off[P.N], pair_cap);
+    constexpr int PP = 16 * U;                               // pairs per pass
+    const int tiles = (pairs + PP - 1) / PP;
+    const int total_waves = gridDim.x * waves_per_block;
+    int t = blockIdx.x * waves_per_block + wave;
+    auto request = [&](int tile) {                           // lanes 0..31 (the others mirror them)
+        const int p = PP * tile + (lane & (PP - 1));
+        return (tile < tiles && p < pairs) ? half_r[p] : -1.f;
+    };
+    float my_r = request(t);
+    for (; t < tiles; t += total_waves) {
+        if (lane < PP) {
+            const float r = my_r >= 0.f ? my_r : 1.0f;
+            ps[lane] = r;
+            ps[64 + lane] = my_r >= 0.f ? 0.5f * cospif(r / P.cutoff) + 0.5f : 0.f;
+        }
+        const float next_r = request(t + total_waves);
+        wave_fence();
+        // ---- layer 1, transposed, both tiles: y[u][cb][q] = S1 of filter 16 cb + 4 grp + q for the pair `col` of tile u ----
+        f32x4 y[U][NCB];
+        {
+            f32x4 lo[U][NCB];
+            float rp[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) rp[u] = ps[16 * u + col];
+            auto l1_step = [&](auto first, int s) {
+                constexpr bool kFirst = decltype(first)::value;
+                f16x8 gh[U], gl[U];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int g = 32 * s + 8 * grp + i;
+                        const float d = rp[u] - (float)g * mu_step;
+                        float v = g < G ? fast_exp2(gscale * d * d) : 0.f;             // ref :151-154
+                        if (g == G) v = 1.0f;                                          // the bias column of the planes
+                        gh[u][i] = (_Float16)v;
+                        gl[u][i] = split_lo(v, gh[u][i]);
+                    }
+                const int slot = min(4 * s + grp, slots1 - 1);      // a slot past the row meets all-zero Gaussians
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    const int off = (cb * 16 + col) * row1 + slot * 16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(s_w1h + off);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(s_w1l + off);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        y[u][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gh[u], kFirst ? zero : y[u][cb], 0, 0, 0);
+                        lo[u][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gl[u], kFirst ? zero : lo[u][cb], 0, 0, 0);
+                        lo[u][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, gh[u], lo[u][cb], 0, 0, 0);
+                    }
+                }
+            };
+            l1_step(std::true_type{}, 0);
+            if (32 < G + 1) l1_step(std::false_type{}, 1);  // (wave-uniform: more than 31 Gaussians)
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) y[u][cb] += kLoInv * lo[u][cb];
+        }
+        // ---- activation and split in registers: the A fragments of layer 2, step s = {filters of cb 2 s, filters of cb 2 s + 1} ----
+        f16x8 ah[U][NCB / 2], al[U][NCB / 2];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float yv = activate_fast<ACT>(y[u][cb][q]);
+                    const _Float16 hq = (_Float16)yv;
+                    ah[u][cb >> 1][(cb & 1) * 4 + q] = hq;
+                    al[u][cb >> 1][(cb & 1) * 4 + q] = split_lo(yv, hq);
+                }
+        // ---- layer 2, transposed as well (the W2 fragment is the A operand, the Y1 fragment -- same lane layout -- the B operand):
+        //      S2[u][filter 16 cb + 4 grp + q][pair col]: a lane ends with FOUR CONSECUTIVE filters of its pair, i.e. 16-byte pieces of
+        //      the filter row (a store instruction of the wave covers 1 KB where the pair-major layout's 4-byte stores covered 256 bytes);
+        //      every W2 fragment serves both tiles ----
+        f32x4 acc2[U][NCB];
+        auto l2_step = [&](auto first, int s) {
+            constexpr bool kFirst = decltype(first)::value;
+            const int slot = 4 * s + grp;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                const int f2 = cb * 16 + col;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(s_w2h + h2_slot<W>(f2, slot));
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(s_w2l + h2_slot<W>(f2, slot));
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    y[u][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[u][s], kFirst ? zero : y[u][cb], 0, 0, 0);
+                    acc2[u][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[u][s], kFirst ? zero : acc2[u][cb], 0, 0, 0);
+                    acc2[u][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[u][s], acc2[u][cb], 0, 0, 0);
+                }
+            }
+        };
+        l2_step(std::true_type{}, 0);
+#pragma unroll
+        for (int s = 1; s < W / 32; s++) l2_step(std::false_type{}, s);
+        // ---- the filter rows of my two pairs: 16 bytes per column block ----
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = PP * t + 16 * u + col;
+            const float fc = ps[64 + 16 * u + col];
+            if (p < pairs) {
+                float* frow = filt + (size_t)p * W + 4 * grp;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    const float4 bias = *reinterpret_cast<const float4*>(b2 + cb * 16 + 4 * grp);
+                    const f32x4 v = y[u][cb] + kLoInv * acc2[u][cb];
+                    *reinterpret_cast<float4*>(frow + cb * 16) = make_float4(fc * (v[0] + bias.x), fc * (v[1] + bias.y), fc * (v[2] + bias.z), fc * (v[3] + bias.w));      // ref :175
+                    // (plain stores: `nt` / `sc1` rows were measured -- they leave the filters kernel at 54 - 66 us and cost the gather, which
+                    //  then finds fewer of the rows in the caches, 12 us)
+                }
+            }
+        }
+        my_r = next_r;
+        wave_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cfconv_filters_h2b (round 6): the BACKWARD filters kernel on the same footing -- no Y1 / dY1 planes in LDS, every weight
+// fragment read once per tile.
+//
+// cfconv_filters_h2<.., BWD> runs four matrix passes per 16-pair tile (layer 1 values, layer 1 d/dr, layer 2 on Y1, layer 2 on dY1),
+// each with its own walk over the weight planes in LDS (208 ds_read_b128 per tile), writes and re-reads two sets of A planes, and
+// gathers x / gout with 128 four-byte loads per lane.  Here:
+//   * layer 1: values and d/dr in ONE pass -- the derivative Gaussians are the value Gaussians times -(r - mu) / sigma^2, no second
+//     set of exponentials -- every W1 fragment feeds six matrix instructions;
+//   * activation, derivative and the two splits in registers; Y1 and dY1 ARE layer 2's operand fragments (K permuted inside a step,
+//     cfconv_filters_h2x2), so nothing goes through LDS and the two layer-2 passes become one: every W2 fragment feeds six
+//     matrix instructions -- 96 ds_read_b128 per tile in all;
+//   * layer 2 transposed (the W2 fragment is the A operand): a lane ends with S2 and dS2 of FOUR CONSECUTIVE filters of its own pair,
+//     so the filter row leaves as 16-byte pieces and x / gout of the pair's two atoms arrive as 16-byte loads (32 per lane instead
+//     of 128), the contraction needs two cross-lane steps instead of sixteen.
+// Same arithmetic as cfconv_filters_h2 (split-fp16 products, fp32 accumulation, second layer's bias in the accumulator).
+// ---------------------------------------------------------------------------------------------
+template <int ACT, int NCB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void cfconv_filters_h2b(
+    ConvParams P, const _Float16* __restrict__ w1h, const _Float16* __restrict__ w1l, const _Float16* __restrict__ w2h,
+    const _Float16* __restrict__ w2l, const float* __restrict__ b2, const int* __restrict__ half_off, const float* __restrict__ half_r,
+    const int2* __restrict__ half_ij, int pair_cap, const float* __restrict__ x, const float* __restrict__ gout,
+    float* __restrict__ filt, float* __restrict__ pair_s) {
+    constexpr int W = NCB * 16;
+    static_assert(W % 32 == 0, "the K steps of layer 2 are 32 wide");
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int G = P.G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    char* s_w2h = ldsb;                                      // [W][W] halves, K pieces permuted inside every step, slots swizzled (h2_slot)
+    char* s_w2l = s_w2h + (size_t)W * W * 2;
+    const int row1 = h2_l1_row_bytes(G), slots1 = h2_l1_slots(G);
+    char* s_w1h = s_w2l + (size_t)W * W * 2;                 // W1 planes [W][row1 bytes]
+    char* s_w1l = s_w1h + (size_t)W * row1;
+    float* s_b2 = reinterpret_cast<float*>(s_w1l + (size_t)W * row1);      // [W] (read per tile from here: as global loads the compiler hoists all of
+                                                                           //      them out of the tile loop and spills them, 32 registers)
+    float* ps = s_b2 + W + wave * 96;                        // r | fc | dfc | 1/r | i | j of the wave's 16 pairs
+    for (int q = tid; q < W; q += blockDim.x) s_b2[q] = b2[q];
+    for (int q = tid; q < W * (W / 8); q += blockDim.x) {    // slot 4 s + grp <- K pieces {32 s + 4 grp, 32 s + 16 + 4 grp}
+        const int f2 = q / (W / 8), slot = q % (W / 8);
+        const int k0 = 32 * (slot >> 2) + 4 * (slot & 3);
+        const f16x4 h0 = *reinterpret_cast<const f16x4*>(w2h + (size_t)f2 * W + k0), h1 = *reinterpret_cast<const f16x4*>(w2h + (size_t)f2 * W + k0 + 16);
+        const f16x4 l0 = *reinterpret_cast<const f16x4*>(w2l + (size_t)f2 * W + k0), l1 = *reinterpret_cast<const f16x4*>(w2l + (size_t)f2 * W + k0 + 16);
+        *reinterpret_cast<f16x8*>(s_w2h + h2_slot<W>(f2, slot)) = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<f16x8*>(s_w2l + h2_slot<W>(f2, slot)) = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+    for (int q = tid; q < W * (row1 / 16); q += blockDim.x) {
+        reinterpret_cast<f16x8*>(s_w1h)[q] = reinterpret_cast<const f16x8*>(w1h)[q];
+        reinterpret_cast<f16x8*>(s_w1l)[q] = reinterpret_cast<const f16x8*>(w1l)[q];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {                                  // the all-zero row behind the last slot (entries without a mirror image)
+        for (int q = tid; q < W; q += blockDim.x) filt[(size_t)pair_cap * W + q] = 0.f;
+        if (tid == 0) pair_s[pair_cap] = 0.f;
+    }
+
+    const int col = lane & 15, grp = lane >> 4;
+    const float mu_step = P.cutoff / (float)(G - 1);
+    const float sig2 = P.sigma_inv * P.sigma_inv;
+    const float gscale = -0.5f * kLog2e * sig2;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int pairs = min(half_off[P.N], pair_cap);
+    const int tiles = (pairs + 15) >> 4;
+    const int total_waves = gridDim.x * waves_per_block;
+    int t = blockIdx.x * waves_per_block + wave;
+    auto request = [&](int tile, float& r, int2& ij) {      // lanes 0..15 (the others mirror them)
+        const int p = 16 * tile + (lane & 15);
+        r = -1.f;
+        ij = make_int2(0, 0);
+        if (tile < tiles && p < pairs) { r = half_r[p]; ij = half_ij[p]; }
+    };
+    float my_r;
+    int2 my_ij;
+    request(t, my_r, my_ij);
+    for (; t < tiles; t += total_waves) {
+        if (lane < 16) {
+            float r = 1.0f, fc = 0.f, dfc = 0.f;
+            if (my_r >= 0.f) {
+                r = my_r;
+                float sn, cs;
+                sincospif(r / P.cutoff, &sn, &cs);
+                fc = 0.5f * cs + 0.5f;                                                  // ref :301-303
+                dfc = -(0.5f * kPi / P.cutoff) * sn;                                    // ref :305-307
+            }
+            ps[lane] = r; ps[16 + lane] = fc; ps[32 + lane] = dfc; ps[48 + lane] = 1.0f / r;
+            ps[64 + lane] = __int_as_float(my_ij.x); ps[80 + lane] = __int_as_float(my_ij.y);
+        }
+        float next_r;
+        int2 next_ij;
+        request(t + total_waves, next_r, next_ij);
+        wave_fence();
+        // ---- layer 1, transposed, values and d/dr together: S1 / dS1 of filter 16 cb + 4 grp + q for the pair `col`; then the activation,
+        //      its derivative and the two splits: layer 2's operand fragments, step s = {filters of cb 2 s, of cb 2 s + 1}.  The column
+        //      blocks in two halves (registers) ----
+        constexpr int HB = NCB >= 4 ? NCB / 2 : NCB;         // column blocks per half
+        f16x8 ah[NCB / 2], al[NCB / 2], dh[NCB / 2], dl[NCB / 2];
+        const float rp = ps[col];
+#pragma unroll
+        for (int half = 0; half < NCB / HB; half++) {
+            f32x4 y[HB], dy[HB], lo[HB], dlo[HB];
+            auto l1_step = [&](auto first, int s) {
+                constexpr bool kFirst = decltype(first)::value;
+                f16x8 gh, gl, dgh, dgl;
+                const float d0 = rp - (float)(32 * s + 8 * grp) * mu_step;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int g = 32 * s + 8 * grp + i;
+                    const float d = d0 - (float)i * mu_step;
+                    float v = g < G ? fast_exp2(gscale * d * d) : 0.f;                 // ref :151-154
+                    float dv = -d * sig2 * v;                                          // ref :242
+                    if (g == G) { v = 1.0f; dv = 0.f; }                                // the bias column of the planes
+                    gh[i] = (_Float16)v;   gl[i] = split_lo(v, gh[i]);
+                    dgh[i] = (_Float16)dv; dgl[i] = split_lo(dv, dgh[i]);
+                }
+                const int slot = min(4 * s + grp, slots1 - 1);      // a slot past the row meets all-zero Gaussians
+#pragma unroll
+                for (int c = 0; c < HB; c++) {
+                    const int off = ((half * HB + c) * 16 + col) * row1 + slot * 16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(s_w1h + off);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(s_w1l + off);
+                    y[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gh, kFirst ? zero : y[c], 0, 0, 0);
+                    dy[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, dgh, kFirst ? zero : dy[c], 0, 0, 0);
+                    lo[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, gl, kFirst ? zero : lo[c], 0, 0, 0);
+                    dlo[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, dgl, kFirst ? zero : dlo[c], 0, 0, 0);
+                    lo[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, gh, lo[c], 0, 0, 0);
+                    dlo[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, dgh, dlo[c], 0, 0, 0);
+                }
+            };
+            l1_step(std::true_type{}, 0);
+            if (32 < G + 1) l1_step(std::false_type{}, 1);  // (wave-uniform: more than 31 Gaussians)
+#pragma unroll
+            for (int c = 0; c < HB; c++) {
+                const int cb = half * HB + c;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float yv, dact;
+                    activate_d_fast<ACT>(y[c][q] + kLoInv * lo[c][q], yv, dact);
+                    const float dv = (dy[c][q] + kLoInv * dlo[c][q]) * dact;           // dY1
+                    const _Float16 hq = (_Float16)yv, dq = (_Float16)dv;
+                    ah[cb >> 1][(cb & 1) * 4 + q] = hq;
+                    al[cb >> 1][(cb & 1) * 4 + q] = split_lo(yv, hq);
+                    dh[cb >> 1][(cb & 1) * 4 + q] = dq;
+                    dl[cb >> 1][(cb & 1) * 4 + q] = split_lo(dv, dq);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- layer 2 on Y1 and dY1 together, transposed: S2 / dS2 of filter 16 cb + 4 grp + q for the pair `col`; the column blocks in
+        //      two halves (four accumulator sets of eight blocks do not fit the registers next to the 64 of the operand fragments), each
+        //      followed by its part of the epilogue: the filter row (16-byte pieces), dy2 = dfc S2 + fc dS2, the contraction with
+        //      x / gout of the pair's two atoms ----
+        const int p = 16 * t + col;
+        const float fc = ps[16 + col], dfc = ps[32 + col];
+        const int ai = __float_as_int(ps[64 + col]), aj = __float_as_int(ps[80 + col]);      // (a padding row carries i = j = 0 and is not stored)
+        const float* xi = x + (size_t)ai * W + 4 * grp;
+        const float* xj = x + (size_t)aj * W + 4 * grp;
+        const float* gi = gout + (size_t)ai * W + 4 * grp;
+        const float* gj = gout + (size_t)aj * W + 4 * grp;
+        const bool store = p < pairs && !P.skip_filter_store;
+        float sc = 0.f;
+#pragma unroll
+        for (int half = 0; half < NCB / HB; half++) {
+            f32x4 s2[HB], ds2[HB], lo2[HB], dlo2[HB];
+            // (x / gout of the pair's two atoms for this half's filters: requested HERE, a matrix pass ahead of their use -- behind the
+            //  pass their round trip to the L2 would be exposed once per half with two waves per SIMD to hide it)
+            float4 vxi[HB], vgi[HB], vxj[HB], vgj[HB];
+#pragma unroll
+            for (int c = 0; c < HB; c++) {
+                const int off = (half * HB + c) * 16;
+                vxi[c] = *reinterpret_cast<const float4*>(xi + off); vgi[c] = *reinterpret_cast<const float4*>(gi + off);
+                vxj[c] = *reinterpret_cast<const float4*>(xj + off); vgj[c] = *reinterpret_cast<const float4*>(gj + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < HB; c++) {
+                const float4 bias = *reinterpret_cast<const float4*>(s_b2 + (half * HB + c) * 16 + 4 * grp);
+                s2[c] = f32x4{bias.x, bias.y, bias.z, bias.w};
+                ds2[c] = zero; lo2[c] = zero; dlo2[c] = zero;
+            }
+#pragma unroll
+            for (int s = 0; s < W / 32; s++) {
+                const int slot = 4 * s + grp;
+#pragma unroll
+                for (int c = 0; c < HB; c++) {
+                    const int f2 = (half * HB + c) * 16 + col;
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(s_w2h + h2_slot<W>(f2, slot));
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(s_w2l + h2_slot<W>(f2, slot));
+                    s2[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[s], s2[c], 0, 0, 0);
+                    ds2[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, dh[s], ds2[c], 0, 0, 0);
+                    lo2[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[s], lo2[c], 0, 0, 0);
+                    dlo2[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, dh[s], dlo2[c], 0, 0, 0);
+                    lo2[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[s], lo2[c], 0, 0, 0);
+                    dlo2[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, dl[s], dlo2[c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (one step's weight fragments in flight: left alone the scheduler requests all four steps' at once)
+            }
+#pragma unroll
+            for (int c = 0; c < HB; c++) {
+                const int off = (half * HB + c) * 16;
+                const f32x4 v = s2[c] + kLoInv * lo2[c], dv = ds2[c] + kLoInv * dlo2[c];
+                if (store) *reinterpret_cast<float4*>(filt + (size_t)p * W + off + 4 * grp) = make_float4(fc * v[0], fc * v[1], fc * v[2], fc * v[3]);      // ref :175
+                const f32x4 d2 = dfc * v + fc * dv;                                    // ref :276
+                sc += d2[0] * (vxj[c].x * vgi[c].x + vxi[c].x * vgj[c].x) + d2[1] * (vxj[c].y * vgi[c].y + vxi[c].y * vgj[c].y) +
+                      d2[2] * (vxj[c].z * vgi[c].z + vxi[c].z * vgj[c].z) + d2[3] * (vxj[c].w * vgi[c].w + vxi[c].w * vgj[c].w);      // ref :286
+            }
+            if (half + 1 < NCB / HB) __builtin_amdgcn_sched_barrier(0);      // (the second half's accumulators after the first half's epilogue)
+        }
+        sc += __shfl_xor(sc, 16, 64);
+        sc += __shfl_xor(sc, 32, 64);
+        if (grp == 0 && p < pairs) pair_s[p] = sc * ps[48 + col];
+        my_r = next_r; my_ij = next_ij;
+        wave_fence();
+    }
+}
+
 // Owner-computes gather behind cfconv_filters_mfma: one wave per atom, lanes = filter channels.
 //   forward   out[i]   = sum_e F[pid_e] * x[j_e]                                                     ref :180-183
 //   backward  dE/dx[i] = sum_e F[pid_e] * gout[j_e] ,  dE/dpos[i] = -sum_e s[pid_e] * delta_e        ref :284-291
@@ -2016,15 +2404,53 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
                 const int wpb = (int)std::min<size_t>(kMaxWavesPerBlock, (budget - wb) / per_wave);
                 const size_t lds = wb + (size_t)wpb * per_wave;
                 auto k = h->split_l1 ? cfconv_filters_h2<ACT, NCB, BWD, true> : cfconv_filters_h2<ACT, NCB, BWD, false>;
-                if (lds > 64 * 1024)
-                    NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if constexpr (!BWD) {
+                    // forward, both layers split: 32 pairs per wave, layer 2 fed from registers (cfconv_filters_h2x2; $NNPOPS_CFCONV_FWD32=0: the 16-pair kernel)
+                    static const bool fwd32 = !(std::getenv("NNPOPS_CFCONV_FWD32") && std::atoi(std::getenv("NNPOPS_CFCONV_FWD32")) == 0);
+                    if (h->split_l1 && fwd32) {
+                        // (measured, 10 000 atoms: two tiles per pass on 8 waves 45.8 us; one tile per pass on 12 waves -- three per SIMD,
+                        //  154 registers -- 50.5 us; on 16 waves, spilling, 68.6 us: the weight reads a second tile shares are worth more than a third wave)
+                        // (... and on FOUR waves -- one per SIMD, 512 registers -- two tiles per pass 57.0 us, four tiles per pass 84.8 us)
+                        auto k2 = cfconv_filters_h2x2<ACT, NCB, 2, kMaxWavesPerBlock>;
+                        const int wv = kMaxWavesPerBlock;
+                        const size_t lds2 = h2_weight_bytes_l1h(h->p.W, h->p.G) + (size_t)wv * 128 * sizeof(float);
+                        if (lds2 > 64 * 1024)
+                            NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                        hipLaunchKernelGGL(k2, dim3(h->blocks), dim3(64 * wv), lds2, h->stream, h->p, h->d_w1h, h->d_w1l, h->d_w2h, h->d_w2l,
+                                           h->d_b2, nb->d_half_off, nb->d_half_r, pair_cap, h->d_filt);
+                        launched = true;
+                    }
+                }
                 ConvParams cp = h->p;
                 if (BWD && !capturing && !h->graph_seen && h->reuse_filters && h->filt_list == nb && h->filt_epoch == nb->epoch)
                     cp.skip_filter_store = 1;
+                if constexpr (BWD) {
+                    // backward, both layers split: one pass per layer, operands from registers (cfconv_filters_h2b; $NNPOPS_CFCONV_BWD1=0: the four-pass kernel)
+                    static const bool bwd1 = !(std::getenv("NNPOPS_CFCONV_BWD1") && std::atoi(std::getenv("NNPOPS_CFCONV_BWD1")) == 0);
+                    if (h->split_l1 && bwd1) {
+                        // FOUR waves per workgroup: one per SIMD, which gives the wave all 512 registers of its lanes.  The kernel holds four
+                        // accumulator sets, four sets of operand fragments and the x / gout rows of its pair: ~410 registers.  With two waves per
+                        // SIMD (256 each) it spills 444 bytes per lane and takes 206 us; with one, nothing is spilled: 99 us (the four-pass kernel,
+                        // two waves per SIMD: 125.5 us).  Widths below 128 fit two waves per SIMD.
+                        static const int bw_env = std::getenv("NNPOPS_CFCONV_BWD_WAVES") ? std::atoi(std::getenv("NNPOPS_CFCONV_BWD_WAVES")) : 0;
+                        const int wv = bw_env == 4 || bw_env == 8 ? bw_env : (NCB >= 6 ? 4 : 8);
+                        auto k2 = wv == 4 ? cfconv_filters_h2b<ACT, NCB, 4> : cfconv_filters_h2b<ACT, NCB, 8>;
+                        const size_t lds2 = h2_weight_bytes_l1h(h->p.W, h->p.G) + ((size_t)h->p.W + wv * 96) * sizeof(float);
+                        if (lds2 > 64 * 1024)
+                            NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                        hipLaunchKernelGGL(k2, dim3(h->blocks), dim3(64 * wv), lds2, h->stream, cp, h->d_w1h, h->d_w1l, h->d_w2h, h->d_w2l,
+                                           h->d_b2, nb->d_half_off, nb->d_half_r, nb->d_half_ij, pair_cap, x, gout, h->d_filt, h->d_pair_s);
+                        launched = true;
+                    }
+                }
+                if (!launched) {
+                if (lds > 64 * 1024)
+                    NNPOPS_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(k, dim3(h->blocks), dim3(64 * wpb), lds, h->stream, cp, h->d_w1b, h->d_w1h, h->d_w1l, h->d_w2h,
                                    h->d_w2l, h->d_b2, nb->d_half_off, nb->d_half_r, nb->d_half_ij, pair_cap, x, gout, h->d_filt,
                                    h->d_pair_s);
                 launched = true;
+                }
             }
         }
     }
