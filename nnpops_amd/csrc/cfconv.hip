@@ -1737,11 +1737,10 @@ __global__ __launch_bounds__(64 * WAVES) void cfconv_filters_h2b(
             auto l1_step = [&](auto first, int s) {
                 constexpr bool kFirst = decltype(first)::value;
                 f16x8 gh, gl, dgh, dgl;
-                const float d0 = rp - (float)(32 * s + 8 * grp) * mu_step;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int g = 32 * s + 8 * grp + i;
-                    const float d = d0 - (float)i * mu_step;
+                    const float d = rp - (float)g * mu_step;
                     float v = g < G ? fast_exp2(gscale * d * d) : 0.f;                 // ref :151-154
                     float dv = -d * sig2 * v;                                          // ref :242
                     if (g == G) { v = 1.0f; dv = 0.f; }                                // the bias column of the planes
@@ -2406,7 +2405,7 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
                 auto k = h->split_l1 ? cfconv_filters_h2<ACT, NCB, BWD, true> : cfconv_filters_h2<ACT, NCB, BWD, false>;
                 if constexpr (!BWD) {
                     // forward, both layers split: 32 pairs per wave, layer 2 fed from registers (cfconv_filters_h2x2; $NNPOPS_CFCONV_FWD32=0: the 16-pair kernel)
-                    static const bool fwd32 = !(std::getenv("NNPOPS_CFCONV_FWD32") && std::atoi(std::getenv("NNPOPS_CFCONV_FWD32")) == 0);
+                    const bool fwd32 = !(std::getenv("NNPOPS_CFCONV_FWD32") && std::atoi(std::getenv("NNPOPS_CFCONV_FWD32")) == 0);
                     if (h->split_l1 && fwd32) {
                         // (measured, 10 000 atoms: two tiles per pass on 8 waves 45.8 us; one tile per pass on 12 waves -- three per SIMD,
                         //  154 registers -- 50.5 us; on 16 waves, spilling, 68.6 us: the weight reads a second tile shares are worth more than a third wave)
@@ -2426,13 +2425,13 @@ int launch_half_mfma(nnpops_cfconv* h, nnpops_cfconv_neighbors* nb, const float*
                     cp.skip_filter_store = 1;
                 if constexpr (BWD) {
                     // backward, both layers split: one pass per layer, operands from registers (cfconv_filters_h2b; $NNPOPS_CFCONV_BWD1=0: the four-pass kernel)
-                    static const bool bwd1 = !(std::getenv("NNPOPS_CFCONV_BWD1") && std::atoi(std::getenv("NNPOPS_CFCONV_BWD1")) == 0);
+                    const bool bwd1 = !(std::getenv("NNPOPS_CFCONV_BWD1") && std::atoi(std::getenv("NNPOPS_CFCONV_BWD1")) == 0);
                     if (h->split_l1 && bwd1) {
                         // FOUR waves per workgroup: one per SIMD, which gives the wave all 512 registers of its lanes.  The kernel holds four
                         // accumulator sets, four sets of operand fragments and the x / gout rows of its pair: ~410 registers.  With two waves per
                         // SIMD (256 each) it spills 444 bytes per lane and takes 206 us; with one, nothing is spilled: 99 us (the four-pass kernel,
                         // two waves per SIMD: 125.5 us).  Widths below 128 fit two waves per SIMD.
-                        static const int bw_env = std::getenv("NNPOPS_CFCONV_BWD_WAVES") ? std::atoi(std::getenv("NNPOPS_CFCONV_BWD_WAVES")) : 0;
+                        const int bw_env = std::getenv("NNPOPS_CFCONV_BWD_WAVES") ? std::atoi(std::getenv("NNPOPS_CFCONV_BWD_WAVES")) : 0;
                         const int wv = bw_env == 4 || bw_env == 8 ? bw_env : (NCB >= 6 ? 4 : 8);
                         auto k2 = wv == 4 ? cfconv_filters_h2b<ACT, NCB, 4> : cfconv_filters_h2b<ACT, NCB, 8>;
                         const size_t lds2 = h2_weight_bytes_l1h(h->p.W, h->p.G) + ((size_t)h->p.W + wv * 96) * sizeof(float);
