@@ -850,6 +850,8 @@ def run_neighbors(args, R):
     pe[1].record()
     torch.cuda.synchronize()
     t_pme = pe[0].elapsed_time(pe[1]) / 20
+    # (round 6) ... and over the list's transposed index, as the torch op runs it on the list of a differentiable getNeighborPairs call
+    t_pme_indexed = phase_ms(lambda: pme_direct(tpos, charges, nb, dl, ds, no_excl, 0.6, 332.063713, index=pair_index))
     pme_bytes = max_pairs * 12 + found * 16 + n * 16 + n * 16      # list read (neighbor ids of every slot, delta + r of live ones), q + derivatives
     nb_bytes = n * 12 + found * 24                      # positions in, (2 ints + 3 floats + 1 float) per pair out
     ang_bytes = n * 16 + n * sym.angular_width * 4
@@ -870,7 +872,7 @@ def run_neighbors(args, R):
         "phases_ms": {"neighbor_pairs": round(t_nb, 4), "neighbor_pairs_backward": round(t_nb_bwd, 4),
                       "neighbor_pairs_transposed_index": round(t_nb_index, 4), "neighbor_pairs_backward_fixed_point": round(t_nb_bwd_fixed, 4),
                       "aev_forward": round(t_fwd, 4),
-                      "aev_backward": round(t_bwd, 4), "pme_direct": round(t_pme, 4)},
+                      "aev_backward": round(t_bwd, 4), "pme_direct": round(t_pme, 4), "pme_direct_indexed": round(t_pme_indexed, 4)},
         "kernels_us": {k: round(v, 1) for k, v in kt.items()},
         "roofline": {"bound": "hbm", "kernel": "getNeighborPairs (stage, scan, emit + cell grid)", "achieved": round(nb_bytes / (t_nb * 1e-3) / 1e9, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb_bytes / (t_nb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -885,6 +887,8 @@ def run_neighbors(args, R):
                                                          "forward call that can be differentiated: phases_ms.neighbor_pairs_transposed_index"},
                      "pme_direct": {"algorithmic_bytes": pme_bytes, "achieved": round(pme_bytes / (t_pme * 1e-3) / 1e9, 2),
                                     "frac": round(pme_bytes / (t_pme * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "indexed": {"achieved": round(pme_bytes / (t_pme_indexed * 1e-3) / 1e9, 2), "frac": round(pme_bytes / (t_pme_indexed * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                                "note": "nnpops_pme_direct_indexed: pme_direct_terms + pme_direct_gather_indexed over the list's transposed index (no atomics); what torch.ops.pme.pme_direct runs on the list of a getNeighborPairs call that can be differentiated"},
                                     "note": "energy + dE/dpositions + dE/dcharges on the pair list above (owner computes: pme_direct_pairs parks every contribution in the second atom's row, pme_direct_gather sums them in a fixed order; no float atomics)"},
                      "aev_step": {"algorithmic_bytes": aev_bytes,
                                   "achieved": round(aev_bytes / ((t_fwd + t_bwd) * 1e-3) / 1e9, 2)}},

@@ -287,6 +287,16 @@ int nnpops_pme_direct(int num_atoms, int64_t num_pairs, int max_exclusions, cons
                       const int32_t* neighbors, const float* deltas, const float* distances, const int32_t* exclusions,
                       float alpha, float coulomb, float* energy, float* position_deriv, float* charge_deriv, void* workspace,
                       void* stream);
+/* The same sums over the pair list's transposed index (round 6: nnpops_neighbor_pairs_build_index above) for a list the forward op of
+ * getNeighborPairs emitted: one streaming pass over the slots + an owner-computes gather, no atomics, no rows of incoming entries,
+ * float64 accumulation in a fixed order (bitwise reproducible).  `index` must have been built from exactly this `neighbors`; workspace:
+ * nnpops_pme_direct_indexed_workspace_bytes(num_pairs, num_atoms) bytes (32 bytes per slot).  Everything else as nnpops_pme_direct,
+ * which remains the entry point for lists of unknown origin.  Additive. */
+int64_t nnpops_pme_direct_indexed_workspace_bytes(int64_t num_pairs, int num_atoms);
+int nnpops_pme_direct_indexed(int num_atoms, int64_t num_pairs, int max_exclusions, const float* positions, const float* charges,
+                              const int32_t* neighbors, const float* deltas, const float* distances, const int32_t* exclusions,
+                              const int32_t* index, float alpha, float coulomb, float* energy, float* position_deriv,
+                              float* charge_deriv, void* workspace, void* stream);
 
 /* ---- dense layers of the ANI atomic networks (reference src/pytorch/BatchedNN.cpp:30-50, BatchedNN.py:37-122) ----
  * C[M x N] = A[M x K] B with fp32 in and out; the products run on the half-precision matrix instruction with every

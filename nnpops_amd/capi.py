@@ -82,6 +82,9 @@ SIGNATURES = {
     "nnpops_pme_direct_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "nnpops_pme_direct": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nnpops_pme_direct_indexed_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "nnpops_pme_direct_indexed": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_backward": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nnpops_neighbor_pairs_backward_workspace_bytes": (C.c_int64, [C.c_int]),
@@ -380,9 +383,10 @@ def neighbor_pairs_backward_indexed(num_atoms, neighbors, deltas, distances, gra
     return grad_positions
 
 
-def pme_direct(positions, charges, neighbors, deltas, distances, exclusions, alpha, coulomb):
+def pme_direct(positions, charges, neighbors, deltas, distances, exclusions, alpha, coulomb, index=None):
     """Direct-space PME on a pair list (reference src/pytorch/pme/pmeCUDA.cu:30-100) through the C ABI.
-    -> (energy float32[1], dE/dpositions [N, 3], dE/dcharges [N]); `exclusions` int32 [N, max], rows sorted descending."""
+    -> (energy float32[1], dE/dpositions [N, 3], dE/dcharges [N]); `exclusions` int32 [N, max], rows sorted descending.
+    index: the list's transposed index (neighbor_pairs_build_index) -- the list must then be one the forward op emitted: no atomics."""
     _dev_f32(positions, "positions")
     _dev_f32(charges, "charges")
     n, pairs = positions.size(0), neighbors.size(1)
@@ -393,6 +397,14 @@ def pme_direct(positions, charges, neighbors, deltas, distances, exclusions, alp
     pos_deriv = torch.empty((n, 3), dtype=torch.float32, device=dev)
     charge_deriv = torch.empty((n,), dtype=torch.float32, device=dev)
     L = lib()
+    if index is not None:
+        ws = torch.empty((int(L.nnpops_pme_direct_indexed_workspace_bytes(pairs, n)),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _check(L.nnpops_pme_direct_indexed(n, pairs, max_excl, _ptr(positions), _ptr(charges), _ptr(neighbors.contiguous()),
+                                               _ptr(deltas.contiguous()), _ptr(distances.contiguous()), _ptr(exclusions) if max_excl else None,
+                                               _ptr(index), float(alpha), float(coulomb), _ptr(energy), _ptr(pos_deriv), _ptr(charge_deriv),
+                                               _ptr(ws), _stream_ptr(dev)))
+        return energy, pos_deriv, charge_deriv
     ws = torch.empty((int(L.nnpops_pme_direct_workspace_bytes(pairs, n, max_excl)),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _check(L.nnpops_pme_direct(n, pairs, max_excl, _ptr(positions), _ptr(charges), _ptr(neighbors.contiguous()),

@@ -215,20 +215,129 @@ __global__ __launch_bounds__(kPmeBlock) void pme_direct_gather(int num_atoms, in
 }
 
 // workgroup partials -> energy, always in the same order
-__global__ __launch_bounds__(256) void pme_sum_partials(const double* __restrict__ partial, int count, float* __restrict__ energy) {
-    __shared__ double red[256];
+__global__ __launch_bounds__(1024) void pme_sum_partials(const double* __restrict__ partial, int count, float* __restrict__ energy) {
+    __shared__ double red[1024];
     double e = 0.0;
-    for (int i = threadIdx.x; i < count; i += 256) e += partial[i];
+    for (int i = threadIdx.x; i < count; i += 1024) e += partial[i];      // (thousands of partials: one round trip per ten of them with 1 024 lanes)
     red[threadIdx.x] = e;
     __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
+    for (int off = 512; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
     if (threadIdx.x == 0) *energy = (float)red[0];
 }
 
+// ---- round 6: the same sums over the pair list's TRANSPOSED INDEX (pairs_index.hip) -- no atomics, no incoming rows -----------------
+// For a list the forward op of getNeighborPairs emitted (grouped by neighbors[0]) and its index: pme_direct_terms is one streaming
+// pass (per slot: the force on the second atom with dE/dq of the first, and the same force with dE/dq of the second, as two 16-byte records; the energy
+// in double per workgroup), pme_direct_gather_indexed 16 lanes per atom -- its own pairs contiguous, the pairs it is second in through
+// the index, its excluded pairs as before -- added up in double in a fixed order: bitwise reproducible without the quantisation the
+// arrival order of pme_direct_pairs' entries makes necessary, and without its one returning atomic per pair (172 us at 100 000 atoms).
+__global__ __launch_bounds__(kPmeBlock) void pme_direct_terms(long long num_pairs, int max_excl, const int* __restrict__ nb0,
+                                                             const int* __restrict__ nb1, const float* __restrict__ deltas,
+                                                             const float* __restrict__ distances, const float* __restrict__ charge,
+                                                             const int* __restrict__ excl, float alpha, float coulomb,
+                                                             float4* __restrict__ terms, float4* __restrict__ second, double* __restrict__ partial) {
+    __shared__ double red[kPmeBlock / 64];
+    double energy = 0.0;
+    const long long stride = (long long)gridDim.x * kPmeBlock;
+    for (long long i = (long long)blockIdx.x * kPmeBlock + threadIdx.x; i < num_pairs; i += stride) {
+        const int atom1 = nb0[i], atom2 = nb1[i];
+        bool include = atom1 > -1;
+        for (int j = 0; include && j < max_excl; j++) {       // exclusion rows are sorted in descending order (pme.py:93; ref :43-46)
+            const int e = excl[(long long)atom1 * max_excl + j];
+            if (e < atom2) break;
+            if (e == atom2) include = false;
+        }
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        float cd2 = 0.f;
+        if (include) {
+            const float r = distances[i];
+            const float inv_r = 1.0f / r, ar = alpha * r;
+            const float ex = expf(-ar * ar), erfc_ar = erfcf(ar);
+            const float pre = coulomb * inv_r;
+            const float c1 = charge[atom1], c2 = charge[atom2];
+            energy += (double)(pre * erfc_ar * c1 * c2);
+            const float dedr = pre * c1 * c2 * (erfc_ar + ar * ex * kTwoOverSqrtPi) * inv_r * inv_r;
+            t = make_float4(dedr * deltas[3 * i], dedr * deltas[3 * i + 1], dedr * deltas[3 * i + 2], pre * erfc_ar * c2);
+            cd2 = pre * erfc_ar * c1;
+        }
+        terms[i] = t;                                          // what the FIRST atom of the pair reads (contiguously): force, its dE/dq
+        second[i] = make_float4(t.x, t.y, t.z, cd2);           // what the SECOND atom gathers: ONE 16-byte record per pair
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) energy += __shfl_xor(energy, off, 64);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = energy;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int w = 0; w < kPmeBlock / 64; w++) e += red[w];
+        partial[blockIdx.x] = e;
+    }
+}
+
+__global__ __launch_bounds__(kPmeBlock) void pme_direct_gather_indexed(int num_atoms, int max_excl, const float* __restrict__ pos,
+                                                                      const float* __restrict__ charge, const int* __restrict__ excl,
+                                                                      float alpha, float coulomb, const int2* __restrict__ row_seg,
+                                                                      const int2* __restrict__ col_seg, const int* __restrict__ order,
+                                                                      const float4* __restrict__ terms, const float4* __restrict__ second,
+                                                                      float* __restrict__ pos_deriv, float* __restrict__ charge_deriv,
+                                                                      double* __restrict__ partial) {
+    __shared__ double red[kPmeBlock / 64];
+    double energy = 0.0;
+    const int sub = threadIdx.x & 15;
+    const int groups = gridDim.x * (kPmeBlock / 16);
+    for (int base = blockIdx.x * (kPmeBlock / 16); base < num_atoms; base += groups) {       // (whole waves iterate together: group shuffles)
+        const int atom = base + (threadIdx.x >> 4);
+        const bool live = atom < num_atoms;
+        double sx = 0.0, sy = 0.0, sz = 0.0, sq = 0.0;
+        if (live) {
+            const int2 rs = row_seg[atom], cs = col_seg[atom];
+            for (int k = rs.x + sub; k < rs.y; k += 16) {     // pairs this atom is the FIRST of: minus the force, its own dE/dq
+                const float4 t = terms[k];
+                sx -= (double)t.x; sy -= (double)t.y; sz -= (double)t.z; sq += (double)t.w;
+            }
+            for (int p = cs.x + sub; p < cs.y; p += 16) {     // pairs it is the SECOND of
+                const float4 t = second[order[p]];
+                sx += (double)t.x; sy += (double)t.y; sz += (double)t.z; sq += (double)t.w;
+            }
+            // excluded pairs of this atom: the erf() part reciprocal space cannot leave out, un-wrapped  (ref :71-99)
+            const float px = pos[3 * atom], py = pos[3 * atom + 1], pz = pos[3 * atom + 2], c1 = charge[atom];
+            for (int j = sub; j < max_excl; j += 16) {
+                const int other = excl[(long long)atom * max_excl + j];
+                if (other < 0 || other == atom) continue;
+                const float dx = px - pos[3 * other], dy = py - pos[3 * other + 1], dz = pz - pos[3 * other + 2];
+                const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float inv_r = 1.0f / r, ar = alpha * r;
+                const float e = expf(-ar * ar), erf_ar = erff(ar);
+                const float pre = coulomb * inv_r;
+                const float c2 = charge[other];
+                if (other > atom) energy -= (double)(pre * erf_ar * c1 * c2);      // once per pair
+                const float dedr = pre * c1 * c2 * (erf_ar - ar * e * kTwoOverSqrtPi) * inv_r * inv_r;
+                sx += (double)(dedr * dx); sy += (double)(dedr * dy); sz += (double)(dedr * dz);
+                sq -= (double)(pre * erf_ar * c2);
+            }
+        }
+        sx = group16_sum(sx); sy = group16_sum(sy); sz = group16_sum(sz); sq = group16_sum(sq);
+        if (live && sub == 0) {
+            pos_deriv[3 * atom] = (float)sx; pos_deriv[3 * atom + 1] = (float)sy; pos_deriv[3 * atom + 2] = (float)sz;
+            charge_deriv[atom] = (float)sq;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) energy += __shfl_xor(energy, off, 64);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = energy;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int w = 0; w < kPmeBlock / 64; w++) e += red[w];
+        partial[blockIdx.x] = e;
+    }
+}
+
 int pair_blocks(long long num_pairs) { return (int)std::min<long long>(std::max<long long>(1, (num_pairs + kPmeBlock - 1) / kPmeBlock), 256 * 16); }
+int gather_blocks_full(int num_atoms) { return (int)std::max<long long>(1, ((long long)num_atoms * 16 + kPmeBlock - 1) / kPmeBlock); }
 int gather_blocks(int num_atoms) { return (int)std::min<long long>(std::max<long long>(1, ((long long)num_atoms * 16 + kPmeBlock - 1) / kPmeBlock), 256 * 16); }
 
 // entries an atom's incoming row holds: a half list gives the atom with the lowest index ALL its neighbours (twice the
@@ -285,7 +394,43 @@ int nnpops_pme_direct(int num_atoms, int64_t num_pairs, int max_exclusions, cons
                        w.partial);
     hipLaunchKernelGGL(pme_direct_gather, dim3(gb), dim3(kPmeBlock), 0, s, num_atoms, max_exclusions, positions, charges, exclusions, alpha,
                        coulomb, w.count, w.incoming, w.cap, w.spill, position_deriv, charge_deriv, w.partial + pb);
-    hipLaunchKernelGGL(pme_sum_partials, dim3(1), dim3(256), 0, s, w.partial, pb + gb, energy);
+    hipLaunchKernelGGL(pme_sum_partials, dim3(1), dim3(1024), 0, s, w.partial, pb + gb, energy);
+    NNPOPS_HIP_TRY(hipGetLastError());
+    return NNPOPS_OK;
+}
+
+int64_t nnpops_pme_direct_indexed_workspace_bytes(int64_t num_pairs, int num_atoms) {
+    if (num_pairs < 0 || num_atoms < 0) return 0;
+    const size_t a = (sizeof(double) * (size_t)(pair_blocks(num_pairs) + gather_blocks_full(num_atoms)) + 255) & ~(size_t)255;
+    return (int64_t)(a + 2 * (((size_t)num_pairs * 16 + 255) & ~(size_t)255) + 512);
+}
+
+int nnpops_pme_direct_indexed(int num_atoms, int64_t num_pairs, int max_exclusions, const float* positions, const float* charges,
+                              const int32_t* neighbors, const float* deltas, const float* distances, const int32_t* exclusions,
+                              const int32_t* index, float alpha, float coulomb, float* energy, float* position_deriv,
+                              float* charge_deriv, void* workspace, void* stream) {
+    NNPOPS_REQUIRE(num_atoms > 0 && num_pairs >= 0 && max_exclusions >= 0, "bad sizes (atoms %d, pairs %lld, exclusions %d)", num_atoms,
+                   (long long)num_pairs, max_exclusions);
+    NNPOPS_REQUIRE(alpha > 0 && coulomb > 0, "alpha and coulomb must be positive");
+    NNPOPS_REQUIRE(positions && charges && energy && position_deriv && charge_deriv && workspace && index, "NULL device pointer");
+    NNPOPS_REQUIRE(num_pairs == 0 || (neighbors && deltas && distances), "NULL pair-list pointer");
+    NNPOPS_REQUIRE(max_exclusions == 0 || exclusions, "NULL exclusions pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int pb = pair_blocks(num_pairs), gb = gather_blocks_full(num_atoms);
+    uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    auto take = [&](size_t bytes) { const uintptr_t at = p; p += (bytes + 255) & ~(size_t)255; return at; };
+    double* partial = (double*)take(sizeof(double) * (size_t)(pb + gb));
+    float4* terms = (float4*)take((size_t)num_pairs * 16);
+    float4* second = (float4*)take((size_t)num_pairs * 16);
+    const int* order = index;
+    const int2* row_seg = (const int2*)(index + ((num_pairs + 1) & ~1ll));     // (the layout nnpops_neighbor_pairs_build_index writes)
+    const int2* col_seg = row_seg + num_atoms;
+    hipLaunchKernelGGL(pme_direct_terms, dim3(pb), dim3(kPmeBlock), 0, s, (long long)num_pairs, max_exclusions, neighbors, neighbors + num_pairs,
+                       deltas, distances, charges, exclusions, alpha, coulomb, terms, second, partial);
+    hipLaunchKernelGGL(pme_direct_gather_indexed, dim3(gb), dim3(kPmeBlock), 0, s, num_atoms, max_exclusions, positions, charges, exclusions,
+                       alpha, coulomb, row_seg, col_seg, order, (const float4*)terms, (const float4*)second, position_deriv, charge_deriv,
+                       partial + pb);
+    hipLaunchKernelGGL(pme_sum_partials, dim3(1), dim3(1024), 0, s, partial, pb + gb, energy);
     NNPOPS_HIP_TRY(hipGetLastError());
     return NNPOPS_OK;
 }

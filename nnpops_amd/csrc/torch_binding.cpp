@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -420,8 +421,10 @@ public:
     // (7 of the 8 MB a step of the 2 001-atom water box used to write there).  Valid for one list of live blocks.
     Tensor gradCache;
     const void* gradCacheBlocks = nullptr;
+    Tensor gradCacheKey;              // the list of live blocks itself, held: while the cache is valid its address cannot be freed and handed to
+    uint32_t gradCacheVersion = 0;    //   another list, and an in-place edit of the list shows in its version counter
     MlpScratch mlpScratch;            // ... and the networks' workspaces of a step (per-member gradient shares, per-atom energies)
-    void resetGradientCache() { gradCache = Tensor(); gradCacheBlocks = nullptr; }      // (the networks' live blocks have changed: BatchedNN.py)
+    void resetGradientCache() { gradCache = Tensor(); gradCacheBlocks = nullptr; gradCacheKey = Tensor(); }      // (the networks' live blocks have changed: BatchedNN.py)
 private:
 };
 
@@ -524,9 +527,11 @@ std::pair<Tensor, Tensor> energy_step(const HolderPtr& holder, const Tensor& fra
             Tensor daev;
             if (call.frame.dx_partial != nullptr && x_blocks.has_value()) {     // (the sum over the members writes the live blocks only)
                 if (!holder->gradCache.defined() || holder->gradCache.sizes() != aev.sizes() || holder->gradCache.device() != aev.device() ||
-                    holder->gradCacheBlocks != x_blocks->data_ptr()) {
+                    holder->gradCacheBlocks != x_blocks->data_ptr() || holder->gradCacheVersion != x_blocks->_version()) {
                     holder->gradCache = torch::zeros_like(aev);
                     holder->gradCacheBlocks = x_blocks->data_ptr();
+                    holder->gradCacheKey = *x_blocks;
+                    holder->gradCacheVersion = x_blocks->_version();
                 }
                 daev = holder->gradCache;
                 call.frame.num_dead_groups = 0;
@@ -880,6 +885,21 @@ TORCH_LIBRARY(NNPOpsCFConv, m) {
 // =============================================================================================
 namespace {
 
+// The transposed index of the LAST list getNeighborPairs emitted on a device with an index (round 6): pme::pme_direct, the list's
+// immediate consumer (src/pytorch/pme/pme.py:163-165), finds it here when it is handed that very list -- same storage, same version
+// counter, held alive so that the address cannot be handed to another tensor -- and then runs without atomics
+// (nnpops_pme_direct_indexed); any other list (edited, shuffled, built by the caller) takes the entry point that assumes nothing.
+struct PairIndexCache {
+    Tensor neighbors, index;
+    uint32_t version = 0;
+};
+PairIndexCache& pair_index_cache(int device) {
+    static std::mutex guard;
+    static std::vector<PairIndexCache> slots(64);
+    std::lock_guard<std::mutex> lock(guard);
+    return slots[(size_t)std::max(0, std::min(device, 63))];
+}
+
 class NeighborPairsFunction : public torch::autograd::Function<NeighborPairsFunction> {
 public:
     static tensor_list forward(AutogradContext* ctx, const Tensor& positions, const torch::Scalar& cutoff,
@@ -939,6 +959,8 @@ public:
             if (nnpops_neighbor_pairs_build_index((int)num_atoms, slots, neighbors.data_ptr<int32_t>(), index.data_ptr<int32_t>(), iws.data_ptr(),
                                                   stream) != NNPOPS_OK)
                 raise_last("neighbors::getNeighborPairs (transposed index)");
+            PairIndexCache& cache = pair_index_cache(positions.device().index());
+            cache.neighbors = neighbors; cache.index = index; cache.version = neighbors._version();
         }
         ctx->save_for_backward({neighbors, deltas, distances, index});
         ctx->saved_data["num_atoms"] = num_atoms;
@@ -1191,13 +1213,26 @@ public:
         Tensor energy = torch::empty({}, opts), pos_deriv = torch::empty({n, 3}, opts), charge_deriv = torch::empty({n}, opts);
         const float a = (float)alpha.toDouble(), k = (float)coulomb.toDouble();
         if (positions.is_cuda()) {
-            Tensor workspace = torch::empty({nnpops_pme_direct_workspace_bytes(pairs, (int)n, (int)max_excl)}, opts.dtype(torch::kUInt8));
             c10::hip::HIPGuard guard(positions.device().index());
+            const PairIndexCache& cache = pair_index_cache(positions.device().index());
+            const bool indexed = cache.index.defined() && cache.neighbors.defined() && nb.data_ptr() == cache.neighbors.data_ptr() &&
+                                 nb.sizes() == cache.neighbors.sizes() && nb._version() == cache.version &&
+                                 cache.index.numel() == nnpops_neighbor_pairs_index_ints((int)n, pairs);
+            if (indexed) {
+                Tensor workspace = torch::empty({nnpops_pme_direct_indexed_workspace_bytes(pairs, (int)n)}, opts.dtype(torch::kUInt8));
+                if (nnpops_pme_direct_indexed((int)n, pairs, (int)max_excl, pos.data_ptr<float>(), q.data_ptr<float>(), nb.data_ptr<int32_t>(),
+                                              dl.data_ptr<float>(), ds.data_ptr<float>(), max_excl ? ex.data_ptr<int32_t>() : nullptr,
+                                              cache.index.data_ptr<int32_t>(), a, k, energy.data_ptr<float>(), pos_deriv.data_ptr<float>(),
+                                              charge_deriv.data_ptr<float>(), workspace.data_ptr(), current_stream(positions.device())) != NNPOPS_OK)
+                    raise_last("pme::pme_direct");
+            } else {
+            Tensor workspace = torch::empty({nnpops_pme_direct_workspace_bytes(pairs, (int)n, (int)max_excl)}, opts.dtype(torch::kUInt8));
             if (nnpops_pme_direct((int)n, pairs, (int)max_excl, pos.data_ptr<float>(), q.data_ptr<float>(), nb.data_ptr<int32_t>(),
                                   dl.data_ptr<float>(), ds.data_ptr<float>(), max_excl ? ex.data_ptr<int32_t>() : nullptr, a, k,
                                   energy.data_ptr<float>(), pos_deriv.data_ptr<float>(), charge_deriv.data_ptr<float>(),
                                   workspace.data_ptr(), current_stream(positions.device())) != NNPOPS_OK)
                 raise_last("pme::pme_direct");
+            }
         } else {
             // host tensors: the reference registers a CPU kernel too (pmeCPU.cpp:75-163); plain loops, double energy
             pos_deriv.zero_();

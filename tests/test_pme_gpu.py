@@ -88,6 +88,54 @@ def test_full_size_properties_100k_atoms():
     assert float((pd2 - pd).abs().max()) <= 1e-4 * fmax and float((cd2 - cd).abs().max()) <= 1e-4 * float(cd.abs().max())
 
 
+@pytest.mark.parametrize("n,max_excl", [(3000, 2), (12000, 0)])
+def test_indexed_path_matches_the_oracle_and_the_delivering_path(n, max_excl):
+    """Round 6: with the list's transposed index (neighbor_pairs_build_index) the direct-space sums are one streaming pass + an
+    owner-computes gather (nnpops_pme_direct_indexed): the oracle's numbers under the same bars, the delivering path's (one returning
+    atomic per pair, order-independent quantised sums) to rounding, the same bits on every call; through the torch surface the op picks
+    the index up from the getNeighborPairs call that made the list (same storage, same version) -- bit for bit the C ABI's indexed
+    result -- and a list it does not know takes the path that assumes nothing."""
+    from nnpops_amd import capi
+    from NNPOps.neighbors import getNeighborPairs
+    pos, charges, box, excl = _salt_box(n, seed=70 + n, max_excl=max_excl)
+    cutoff, alpha, coulomb = 8.0, 0.35, 332.063713
+    tpos, tq, tbox = torch.tensor(pos, device=DEV), torch.tensor(charges, device=DEV), torch.tensor(box, device=DEV)
+    texcl = torch.tensor(excl, dtype=torch.int32, device=DEV) if max_excl else torch.zeros((n, 0), dtype=torch.int32, device=DEV)
+    slots = int(2 * n * 0.05 * 4.19 * cutoff ** 3 / 2)
+    nb, dl, ds, found = capi.neighbor_pairs_forward(tpos, cutoff, slots, tbox)
+    assert 0 < int(found) < slots
+    index = capi.neighbor_pairs_build_index(n, nb)
+    e_i, pd_i, cd_i = capi.pme_direct(tpos, tq, nb, dl, ds, texcl, alpha, coulomb, index=index)
+    for _ in range(2):
+        again = capi.pme_direct(tpos, tq, nb, dl, ds, texcl, alpha, coulomb, index=index)
+        assert all(torch.equal(a, b) for a, b in zip(again, (e_i, pd_i, cd_i)))
+    e_d, pd_d, cd_d = capi.pme_direct(tpos, tq, nb, dl, ds, texcl, alpha, coulomb)
+    e_ref, pd_ref, cd_ref = pme_direct_oracle(pos, charges, nb.cpu().numpy(), dl.cpu().numpy(), ds.cpu().numpy(),
+                                              excl if max_excl else np.zeros((n, 0), np.int64), alpha, coulomb)
+    terms = float(np.abs(cd_ref * charges).sum())
+    assert abs(float(e_i) - e_ref) <= 1e-5 * max(terms, abs(e_ref)) and abs(float(e_i) - float(e_d)) <= 1e-6 * max(terms, abs(e_ref))
+    assert np.abs(pd_i.cpu().numpy() - pd_ref).max() <= 1e-4 * np.abs(pd_ref).max()
+    assert np.abs(cd_i.cpu().numpy() - cd_ref).max() <= 1e-4 * np.abs(cd_ref).max()
+    assert float((pd_i - pd_d).abs().max()) <= 2e-6 * float(pd_d.abs().max()) and float((cd_i - cd_d).abs().max()) <= 2e-6 * float(cd_d.abs().max())
+    # the torch surface: the list of a differentiable getNeighborPairs call carries its index to pme_direct
+    p = tpos.clone().requires_grad_(True)
+    q = tq.clone().requires_grad_(True)
+    t_nb, t_dl, t_ds, _ = getNeighborPairs(p, cutoff, slots, tbox)
+    assert torch.equal(t_nb, nb)
+    energy = torch.ops.pme.pme_direct(p, q, t_nb, t_dl, t_ds, texcl, alpha, coulomb)
+    energy.backward()
+    # (pme_direct's own derivatives only: the list's deltas / distances enter it as data, exactly as in the reference, pme.cpp)
+    assert torch.equal(energy.detach().reshape(()), e_i.reshape(())) and torch.equal(q.grad, cd_i)
+    shuffled = torch.randperm(int(found), device=DEV)
+    nb_s = nb.clone()
+    nb_s[:, :int(found)] = nb[:, :int(found)][:, shuffled]
+    dl_s, ds_s = dl.clone(), ds.clone()
+    dl_s[:int(found)] = dl[:int(found)][shuffled]
+    ds_s[:int(found)] = ds[:int(found)][shuffled]
+    e_s = torch.ops.pme.pme_direct(tpos, tq, nb_s, dl_s, ds_s, texcl, alpha, coulomb)       # a list of unknown origin: correct all the same
+    assert abs(float(e_s) - e_ref) <= 1e-5 * max(terms, abs(e_ref))
+
+
 def _nine_charges():
     rng = np.random.default_rng(11)
     pos = torch.tensor((3 * rng.random((9, 3)) - 1).astype(np.float32), device=DEV)
