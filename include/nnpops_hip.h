@@ -259,6 +259,7 @@ int nnpops_neighbor_pairs_backward_ws(int dtype, int num_atoms, int64_t num_slot
  * reaches exactly the two atoms of its pair, as the reference's atomics do); workspace: 32-byte aligned,
  * nnpops_neighbor_pairs_backward_indexed_workspace_bytes(dtype, num_slots) bytes.  A list that is NOT grouped by neighbors[0] (edited,
  * shuffled, of unknown origin) must go through nnpops_neighbor_pairs_backward_ws, which assumes nothing.  Additive. */
+#define NNPOPS_PAIRS_INDEX_MAX_ATOMS 262144      /* nnpops_neighbor_pairs_build_index: 512 buckets of up to 512 atoms; beyond, NNPOPS_ERR_UNSUPPORTED */
 int64_t nnpops_neighbor_pairs_index_ints(int num_atoms, int64_t num_slots);
 int64_t nnpops_neighbor_pairs_index_workspace_bytes(int num_atoms, int64_t num_slots);
 int nnpops_neighbor_pairs_build_index(int num_atoms, int64_t num_slots, const int32_t* neighbors, int32_t* index, void* workspace,

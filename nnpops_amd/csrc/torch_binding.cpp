@@ -953,7 +953,7 @@ public:
         Tensor index;
         const char* bwd_env = std::getenv("NNPOPS_PAIRS_BACKWARD");
         const bool fixed_point_only = bwd_env && std::string(bwd_env) == "fixed";
-        if (positions.requires_grad() && max_pairs > 0 && !fixed_point_only) {
+        if (positions.requires_grad() && max_pairs > 0 && !fixed_point_only && num_atoms <= NNPOPS_PAIRS_INDEX_MAX_ATOMS) {
             index = torch::empty({nnpops_neighbor_pairs_index_ints((int)num_atoms, slots)}, options.dtype(torch::kInt32));
             Tensor iws = torch::empty({nnpops_neighbor_pairs_index_workspace_bytes((int)num_atoms, slots) / 8 + 1}, options.dtype(torch::kInt64));
             if (nnpops_neighbor_pairs_build_index((int)num_atoms, slots, neighbors.data_ptr<int32_t>(), index.data_ptr<int32_t>(), iws.data_ptr(),
