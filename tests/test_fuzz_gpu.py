@@ -235,6 +235,19 @@ def test_neighbor_pairs_random_configuration(seed):
         assert len(got) == min(num, nb.shape[1]) and len(set(got)) == len(got) and set(got) <= true_pairs
         if num <= nb.shape[1]:
             assert set(got) == true_pairs
+        # (round 6) the backward pass as a gather over the list's transposed index: the oracle's gradient, whatever the size, the
+        # padding, the truncation and the search that made the list
+        from nnpops_amd.capi import neighbor_pairs_backward_indexed, neighbor_pairs_build_index
+        from oracle import neighbor_pairs_backward_oracle
+        t_nb, t_dl, t_ds, _ = neighbor_pairs_forward(torch.tensor(pos, device=dev), cutoff, max_pairs,
+                                                     torch.tensor(box, device=dev) if box is not None else None)
+        gd = rng.standard_normal(dl.shape).astype(npdt)
+        gs = rng.standard_normal(ds.shape).astype(npdt)
+        index = neighbor_pairs_build_index(n, t_nb)
+        gp = neighbor_pairs_backward_indexed(n, t_nb, t_dl, t_ds, torch.tensor(gd, device=dev), torch.tensor(gs, device=dev), index).cpu().numpy()
+        gp_ref = neighbor_pairs_backward_oracle(n, nb, dl, ds, gd, gs)
+        tol = 1e-5 if npdt == np.float32 else 1e-12
+        np.testing.assert_allclose(gp, gp_ref, rtol=tol, atol=tol * max(float(np.abs(gp_ref).max()), 1e-30))
 
 
 @pytest.mark.parametrize("seed", range(8 * SCALE))
