@@ -38,7 +38,7 @@ namespace {
 constexpr int kMaxBucketShift = 9, kMaxBucketAtoms = 1 << kMaxBucketShift;      // atoms per bucket (= bins of the second level): 2^shift, shift <= 9, picked per call
 constexpr int kMaxBuckets = 512;                                       // bins of the first level
 static_assert(kMaxBuckets * kMaxBucketAtoms == NNPOPS_PAIRS_INDEX_MAX_ATOMS, "include/nnpops_hip.h states the limit");
-constexpr int kTile = 4096, kTileThreads = 256, kRounds = kTile / kTileThreads / 4;      // a wave takes 1 024 consecutive slots in 16 rounds of 64
+constexpr int kTile = 4096, kTileThreads = 256;      // slots per tile; a wave takes 1 024 consecutive ones in 16 rounds of 64
 constexpr int kBucketWaves = 16;
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -894,10 +894,12 @@ struct PairIndexCache {
     uint32_t version = 0;
 };
 PairIndexCache& pair_index_cache(int device) {
+    // (never destroyed: tensors released from a static destructor would reach the allocator after the runtime has shut down.  One entry per
+    //  device, i.e. the last list and its index -- 36 bytes per slot -- stay allocated until the next differentiable getNeighborPairs call.)
     static std::mutex guard;
-    static std::vector<PairIndexCache> slots(64);
+    static std::vector<PairIndexCache>* slots = new std::vector<PairIndexCache>(64);
     std::lock_guard<std::mutex> lock(guard);
-    return slots[(size_t)std::max(0, std::min(device, 63))];
+    return (*slots)[(size_t)std::max(0, std::min(device, 63))];
 }
 
 class NeighborPairsFunction : public torch::autograd::Function<NeighborPairsFunction> {
