@@ -323,6 +323,12 @@ struct ConvParams {
     float cutoff, sigma_inv;
     int activation;          // 0 shifted softplus, 1 tanh
     int skip_filter_store;   // backward, half-list path: the filter rows of this list are still in `filt` from the forward call
+    // Split-fp16 kernels, backward: dY1 = dS1 act'(S1) is multiplied by this power of two before it is split into fp16 planes and dS2 by
+    // its inverse (round 6).  Where an activation saturates (tanh) most entries of dY1 are orders of magnitude below the largest, and an
+    // fp16 plane does not hold what lies below 2^-14 of ITS scale at full precision: unscaled, the forces under tanh sat 2e-5 ... 7e-5 of
+    // the largest force from the oracle (the fp32 matrix kernel: 3e-6); scaled to the top of the fp16 range (the host's bound on
+    // |dY1|, nnpops_cfconv_create) they sit at 3e-6.  1 where the split kernels are not in use.
+    float dy_scale, dy_unscale;
 };
 
 template <int ACT>
@@ -1400,8 +1406,9 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
                 f16x4 h, l;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    h[q] = (_Float16)dacc[cb][q];
-                    l[q] = split_lo(dacc[cb][q], h[q]);
+                    const float dv = dacc[cb][q] * P.dy_scale;      // (ConvParams::dy_scale)
+                    h[q] = (_Float16)dv;
+                    l[q] = split_lo(dv, h[q]);
                 }
                 const int off = h2_slot<W>(col, 2 * cb + (grp >> 1)) + (grp & 1) * 8;
                 *reinterpret_cast<f16x4*>(a_h + off) = h;
@@ -1412,7 +1419,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void cfconv_filters_h2(
             wave_fence();
             h2_layer<NCB, W, true, false, false>(a_h, a_l, s_w2h, s_w2l, col, grp, col, dacc, acc2);
 #pragma unroll
-            for (int cb = 0; cb < NCB; cb++) dacc[cb] += kLoInv * acc2[cb];
+            for (int cb = 0; cb < NCB; cb++) dacc[cb] = (dacc[cb] + kLoInv * acc2[cb]) * P.dy_unscale;
         }
         // ---- my four pairs of the tile: the filter rows first (backward: and dy2 = dfc S2 + fc dS2 in place of dS2, after
         //      which S2 is dead and its registers serve the gathers), then the pair forces ----
@@ -1770,7 +1777,8 @@ __global__ __launch_bounds__(64 * WAVES) void cfconv_filters_h2b(
                 for (int q = 0; q < 4; q++) {
                     float yv, dact;
                     activate_d_fast<ACT>(y[c][q] + kLoInv * lo[c][q], yv, dact);
-                    const float dv = (dy[c][q] + kLoInv * dlo[c][q]) * dact;           // dY1
+                    const float dv = (dy[c][q] + kLoInv * dlo[c][q]) * dact * P.dy_scale;      // dY1, at the top of the fp16 range (ConvParams::dy_scale; the scale LAST:
+                                                                                            // as dS1 (dact scale) the same figures come out 10 x worse, tools/cfconv_split_error.py)
                     const _Float16 hq = (_Float16)yv, dq = (_Float16)dv;
                     ah[cb >> 1][(cb & 1) * 4 + q] = hq;
                     al[cb >> 1][(cb & 1) * 4 + q] = split_lo(yv, hq);
@@ -1832,7 +1840,7 @@ __global__ __launch_bounds__(64 * WAVES) void cfconv_filters_h2b(
 #pragma unroll
             for (int c = 0; c < HB; c++) {
                 const int off = (half * HB + c) * 16;
-                const f32x4 v = s2[c] + kLoInv * lo2[c], dv = ds2[c] + kLoInv * dlo2[c];
+                const f32x4 v = s2[c] + kLoInv * lo2[c], dv = (ds2[c] + kLoInv * dlo2[c]) * P.dy_unscale;
                 if (store) *reinterpret_cast<float4*>(filt + (size_t)p * W + off + 4 * grp) = make_float4(fc * v[0], fc * v[1], fc * v[2], fc * v[3]);      // ref :175
                 const f32x4 d2 = dfc * v + fc * dv;                                    // ref :276
                 sc += d2[0] * (vxj[c].x * vgi[c].x + vxi[c].x * vgj[c].x) + d2[1] * (vxj[c].y * vgi[c].y + vxi[c].y * vgj[c].y) +
@@ -2191,6 +2199,7 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
     auto* h = new nnpops_cfconv();
     h->p.N = num_atoms; h->p.W = width; h->p.G = num_gaussians; h->p.cutoff = cutoff;
     h->p.sigma_inv = 1.0f / gaussian_width; h->p.activation = activation;
+    h->p.skip_filter_store = 0; h->p.dy_scale = 1.0f; h->p.dy_unscale = 1.0f;
     h->periodic = periodic != 0; h->device = device;
     const int W = width, G = num_gaussians;
     std::vector<float> w1t((size_t)G * W), w2t((size_t)W * W);
@@ -2250,6 +2259,13 @@ int nnpops_cfconv_create(nnpops_cfconv_t* out, int num_atoms, int width, int num
             }
         const double limit = 3.0e4;                         // fp16 holds 65504; the low planes stay below 32 in any case
         h->split_ok = max_w2 < limit && max_y < limit && max_dy < limit;
+        {   // dY1 goes into its fp16 planes scaled to the top of the range (ConvParams::dy_scale): the largest power of two, up to 2^12,
+            // that keeps the bound on |dY1| below `limit`
+            int k = 0;
+            while (k < 12 && max_dy * std::ldexp(1.0, k + 1) < limit) k++;
+            h->p.dy_scale = (float)std::ldexp(1.0, k);
+            h->p.dy_unscale = (float)std::ldexp(1.0, -k);
+        }
         int level = 2;                                      // 0: fp32 only, 1: second layer split, 2: both layers where possible
         if (const char* e = std::getenv("NNPOPS_CFCONV_SPLIT")) level = std::atoi(e);
         if (const char* e = std::getenv("NNPOPS_CFCONV_REUSE_FILTERS")) h->reuse_filters = std::atoi(e) != 0;

@@ -258,12 +258,13 @@ def test_register_fed_filters_kernels_agree_with_the_plane_kernels(monkeypatch, 
     _case(pos, box, W, G, 5.0, 0.1, act, seed=31, keep=old)
     for key in ("y", "xg", "pg"):
         scale = np.abs(old[key]).max()
-        # (forces under tanh: every split-fp16 kernel, the plane kernels of rounds 3-5 included, sits 2e-5 ... 7e-5 of the largest force
-        #  from the oracle where the fp32 matrix kernel sits at 3e-6 -- inside north_star's 1e-4, measured with tools/cfconv_split_error.py;
-        #  two kernels that differ in the order of their sums differ from each other by as much)
-        bar = FORCE_RTOL if (key == "pg" and act == "tanh") else 3e-6
-        assert np.abs(new[key] - old[key]).max() <= bar * scale, key
-        assert np.abs(swapped[key] - new[key]).max() <= bar * scale, key
+        assert np.abs(new[key] - old[key]).max() <= 3e-6 * scale, key
+        assert np.abs(swapped[key] - new[key]).max() <= 3e-6 * scale, key
+    # Round 6: dY1 goes into its fp16 planes scaled to the top of the fp16 range (ConvParams::dy_scale).  Unscaled, the forces under tanh --
+    # whose saturated neurons leave most of dY1 orders of magnitude below its largest entries -- sat 2e-5 ... 7e-5 of the largest force from
+    # the oracle, in every split-fp16 kernel since round 3; now they sit where the fp32 matrix kernel sits (tools/cfconv_split_error.py).
+    for keep in (new, old):
+        assert np.abs(keep["pg"] - keep["pg_ref"]).max() <= 8e-6 * np.abs(keep["pg_ref"]).max()
     # a ragged last pass (pairs not a multiple of 32) and a molecule (all-pairs list)
     monkeypatch.delenv("NNPOPS_CFCONV_FWD32")
     monkeypatch.delenv("NNPOPS_CFCONV_BWD1")
