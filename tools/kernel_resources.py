@@ -18,7 +18,7 @@ def g(b, k):
 
 
 for b, dn in zip(blocks, dem):
-    short = re.sub(r"\(.*", "", dn).replace("void nnpops::", "")
+    short = re.sub(r"\(.*", "", dn.replace("(anonymous namespace)::", "")).replace("void nnpops::", "").replace("void ", "")
     if filters and not any(f in short for f in filters):
         continue
     print("%-100s vgpr %3d agpr %3d sgpr %3d scratch %4d occ %2d" % (short[:100], g(b, "VGPRs"), g(b, "AGPRs"), g(b, "SGPRs"),
