@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kTileThreads) void pairs_index_histogram(long long 
             const long long k = base + r * kTileThreads + tid;
             if (k < num_slots) {
                 const int c = cols[k];
-                if (c >= 0) atomicAdd(&bins[c >> shift], 1);      // (LDS, integer: the counts do not depend on the order)
+                if ((unsigned)c < (unsigned)num_atoms) atomicAdd(&bins[c >> shift], 1);      // (an id outside the system is treated as unused, never as a bin)      // (LDS, integer: the counts do not depend on the order)
             }
         }
     }
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kTileThreads) void pairs_index_partition(long long 
     for (int r = 0; r < R; r++) {
         const long long k = base + wave * (kTile / 4) + r * 64 + lane;
         key[r] = k < num_slots ? cols[k] : -1;
+        if ((unsigned)key[r] >= (unsigned)num_atoms) key[r] = -1;      // (as the histogram counted)
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
